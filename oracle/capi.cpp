@@ -1,0 +1,466 @@
+// ORACLE (test infrastructure, NOT product code): C entry points for ctypes.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "discretization.hpp"
+#include "models.hpp"
+#include "sc.hpp"
+#include "socp.hpp"
+
+using namespace oracle;
+
+namespace
+{
+
+template <class M>
+int flowImpl(const double *x, const double *u, const double *par, double *f, double *A, double *B)
+{
+    M m;
+    for (int i = 0; i < M::NP; i++)
+        m.par[i] = par[i];
+    m.computef(x, u, f);
+    m.computeJacobians(x, u, A, B);
+    return 0;
+}
+
+template <class M>
+int discretizeImpl(int K, int foh, int vt, const double *par, const double *X, const double *U, double t, double *A,
+                   double *B, double *C, double *s, double *z)
+{
+    M m;
+    for (int i = 0; i < M::NP; i++)
+        m.par[i] = par[i];
+    TrajectoryData td;
+    td.initialize(M::NX, M::NU, K, foh != 0);
+    std::memcpy(td.X.data(), X, td.X.size() * sizeof(double));
+    std::memcpy(td.U.data(), U, td.U.size() * sizeof(double));
+    td.t = t;
+    DiscretizationData dd;
+    dd.initialize(M::NX, M::NU, K, foh != 0, vt != 0);
+    multipleShooting(m, td, dd);
+    std::memcpy(A, dd.A.data(), dd.A.size() * sizeof(double));
+    std::memcpy(B, dd.B.data(), dd.B.size() * sizeof(double));
+    if (foh)
+        std::memcpy(C, dd.C.data(), dd.C.size() * sizeof(double));
+    if (vt)
+        std::memcpy(s, dd.s.data(), dd.s.size() * sizeof(double));
+    std::memcpy(z, dd.z.data(), dd.z.size() * sizeof(double));
+    return 0;
+}
+
+struct SCHandleBase
+{
+    virtual ~SCHandleBase() {}
+    virtual int solve(int warm) = 0;
+    virtual SCAlgorithm<RocketQuat> *rq() { return nullptr; }
+    virtual SCAlgorithm<Rocket2d> *r2() { return nullptr; }
+};
+
+template <class M>
+struct SCHandle : SCHandleBase
+{
+    M model;
+    std::unique_ptr<SCAlgorithm<M>> alg;
+    SCHandle(const std::string &root, int K)
+    {
+        const std::string folder = root + "/" + M::modelName();
+        model.loadParameters(folder);
+        alg.reset(new SCAlgorithm<M>(&model, folder, K));
+        alg->initialize();
+    }
+    int solve(int warm) override
+    {
+        alg->solve(warm != 0);
+        return alg->solver_failed ? -1 : 0;
+    }
+    SCAlgorithm<RocketQuat> *rq() override;
+    SCAlgorithm<Rocket2d> *r2() override;
+};
+template <>
+SCAlgorithm<RocketQuat> *SCHandle<RocketQuat>::rq() { return alg.get(); }
+template <>
+SCAlgorithm<Rocket2d> *SCHandle<RocketQuat>::r2() { return nullptr; }
+template <>
+SCAlgorithm<RocketQuat> *SCHandle<Rocket2d>::rq() { return nullptr; }
+template <>
+SCAlgorithm<Rocket2d> *SCHandle<Rocket2d>::r2() { return alg.get(); }
+
+template <class F>
+auto withAlg(void *h, F f)
+{
+    SCHandleBase *b = static_cast<SCHandleBase *>(h);
+    if (b->rq())
+        return f(*b->rq());
+    return f(*b->r2());
+}
+
+} // namespace
+
+extern "C"
+{
+
+int oracle_model_dims(int model, int *dims)
+{
+    if (model == 0)
+    {
+        dims[0] = RocketQuat::NX;
+        dims[1] = RocketQuat::NU;
+        dims[2] = RocketQuat::NP;
+    }
+    else
+    {
+        dims[0] = Rocket2d::NX;
+        dims[1] = Rocket2d::NU;
+        dims[2] = Rocket2d::NP;
+    }
+    return 0;
+}
+
+int oracle_flow(int model, const double *x, const double *u, const double *par, double *f, double *A, double *B)
+{
+    return model == 0 ? flowImpl<RocketQuat>(x, u, par, f, A, B) : flowImpl<Rocket2d>(x, u, par, f, A, B);
+}
+
+int oracle_rkf78_tableau(double *c, double *a, double *b)
+{
+    const RKF78Tableau &T = rkf78();
+    for (int i = 0; i < 13; i++)
+    {
+        c[i] = T.c[i];
+        b[i] = T.b[i];
+        for (int j = 0; j < 13; j++)
+            a[i * 13 + j] = T.a[i][j];
+    }
+    return 0;
+}
+
+// y'' = -omega^2 y, (y, y') from (1, 0): convergence-order probe for the stepper
+int oracle_rkf78_harmonic(double omega, double dt, int N, double *y)
+{
+    std::vector<double> v{1., 0.};
+    auto ode = [&](const std::vector<double> &s, std::vector<double> &d, double) {
+        d[0] = s[1];
+        d[1] = -omega * omega * s[0];
+    };
+    integrateRKF78(ode, v, dt, N);
+    y[0] = v[0];
+    y[1] = v[1];
+    return 0;
+}
+
+int oracle_discretize(int model, int K, int foh, int vt, const double *par, const double *X, const double *U, double t,
+                      double *A, double *B, double *C, double *s, double *z)
+{
+    return model == 0 ? discretizeImpl<RocketQuat>(K, foh, vt, par, X, U, t, A, B, C, s, z)
+                      : discretizeImpl<Rocket2d>(K, foh, vt, par, X, U, t, A, B, C, s, z);
+}
+
+int oracle_simulate(int model, const double *par, double dt, const double *u0, const double *u1, double *x)
+{
+    if (model == 0)
+    {
+        RocketQuat m;
+        for (int i = 0; i < RocketQuat::NP; i++)
+            m.par[i] = par[i];
+        simulate(m, dt, u0, u1, x);
+    }
+    else
+    {
+        Rocket2d m;
+        for (int i = 0; i < Rocket2d::NP; i++)
+            m.par[i] = par[i];
+        simulate(m, dt, u0, u1, x);
+    }
+    return 0;
+}
+
+// ---- generic SOCP (dense input, small tests) ----
+// info: [exitflag, iter, pcost, dcost, pres, dres, gap]
+int oracle_socp_solve(int n, int p, int l, int ncones, const int *q, const double *c, const double *A, const double *b,
+                      const double *G, const double *h, double *x, double *y, double *z, double *s, double *info)
+{
+    Socp prob;
+    prob.addVars(n, 0);
+    for (int j = 0; j < n; j++)
+        prob.c[j] = c[j];
+    for (int r = 0; r < p; r++)
+    {
+        SocpRow row;
+        for (int j = 0; j < n; j++)
+            if (A[r * n + j] != 0.)
+                row.t.push_back({j, A[r * n + j]});
+        row.rhs = b[r];
+        row.key = 2;
+        prob.eq.push_back(row);
+    }
+    int m = l;
+    for (int k = 0; k < ncones; k++)
+        m += q[k];
+    auto mkrow = [&](int r) {
+        SocpRow row;
+        for (int j = 0; j < n; j++)
+            if (G[r * n + j] != 0.)
+                row.t.push_back({j, G[r * n + j]});
+        row.rhs = h[r];
+        row.key = 1;
+        return row;
+    };
+    int r = 0;
+    for (; r < l; r++)
+        prob.lp.push_back(mkrow(r));
+    for (int k = 0; k < ncones; k++)
+    {
+        std::vector<SocpRow> cone;
+        for (int i = 0; i < q[k]; i++, r++)
+            cone.push_back(mkrow(r));
+        prob.soc.push_back(cone);
+    }
+    // order: cone rows first would hit zero pivots for variables outside all cones; use
+    // variables (delta) -> cone rows -> equality rows, which is always quasi-definite
+    for (int j = 0; j < n; j++)
+        prob.var_key[j] = 0;
+    SocpSolver solver(prob);
+    SocpResult R = solver.solve();
+    for (int j = 0; j < n; j++)
+        x[j] = R.x[j];
+    for (int j = 0; j < p; j++)
+        y[j] = R.y[j];
+    for (int j = 0; j < m; j++)
+    {
+        z[j] = R.z[j];
+        s[j] = R.s[j];
+    }
+    info[0] = R.exitflag;
+    info[1] = R.iter;
+    info[2] = R.pcost;
+    info[3] = R.dcost;
+    info[4] = R.pres;
+    info[5] = R.dres;
+    info[6] = R.gap;
+    return 0;
+}
+
+// ---- SC driver ----
+void *oracle_sc_create(int model, const char *config_root, int K_override)
+{
+    try
+    {
+        if (model == 0)
+            return new SCHandle<RocketQuat>(config_root, K_override);
+        return new SCHandle<Rocket2d>(config_root, K_override);
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_sc_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void oracle_sc_destroy(void *h) { delete static_cast<SCHandleBase *>(h); }
+
+int oracle_sc_set_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
+{
+    return withAlg(h, [&](auto &a) {
+        a.socp_settings.feastol = feastol;
+        a.socp_settings.abstol = abstol;
+        a.socp_settings.reltol = reltol;
+        a.socp_settings.maxit = maxit;
+        return 0;
+    });
+}
+int oracle_sc_set_solver(void *h, int kind)
+{
+    return withAlg(h, [&](auto &a) {
+        a.solver_kind = kind;
+        return 0;
+    });
+}
+int oracle_sc_verbose(void *h, int v)
+{
+    return withAlg(h, [&](auto &a) {
+        a.socp_settings.verbose = v != 0;
+        a.structured_settings.verbose = v != 0;
+        return 0;
+    });
+}
+
+// RocketQuat only: perturb x_init per SURVEY §8(d)
+int oracle_sc_randomize(void *h, unsigned long long seed, unsigned long long instance)
+{
+    SCHandleBase *b = static_cast<SCHandleBase *>(h);
+    if (!b->rq())
+        return -1;
+    b->rq()->model->p.randomizeInitialState(seed, instance);
+    return 0;
+}
+int oracle_sc_get_x_init(void *h, double *x)
+{
+    return withAlg(h, [&](auto &a) {
+        for (int i = 0; i < a.td.nx; i++)
+            x[i] = a.model->p.x_init[i];
+        return 0;
+    });
+}
+int oracle_sc_set_x_init(void *h, const double *x)
+{
+    return withAlg(h, [&](auto &a) {
+        for (int i = 0; i < a.td.nx; i++)
+            a.model->p.x_init[i] = x[i];
+        return 0;
+    });
+}
+int oracle_sc_get_x_final(void *h, double *x)
+{
+    return withAlg(h, [&](auto &a) {
+        for (int i = 0; i < a.td.nx; i++)
+            x[i] = a.model->p.x_final[i];
+        return 0;
+    });
+}
+int oracle_sc_solve(void *h, int warm_start)
+{
+    try
+    {
+        return static_cast<SCHandleBase *>(h)->solve(warm_start);
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_sc_solve: %s\n", e.what());
+        return -2;
+    }
+}
+// meta: [K, nU, nx, nu, iterations, converged, n_all_td, n, p, l, ncones, m]
+int oracle_sc_meta(void *h, int *meta)
+{
+    return withAlg(h, [&](auto &a) {
+        meta[0] = a.td.K;
+        meta[1] = a.td.nU;
+        meta[2] = a.td.nx;
+        meta[3] = a.td.nu;
+        meta[4] = a.iterations;
+        meta[5] = a.converged ? 1 : 0;
+        meta[6] = int(a.all_td.size());
+        for (int i = 0; i < 5; i++)
+            meta[7 + i] = a.last_dims[i];
+        return 0;
+    });
+}
+int oracle_sc_get_solution(void *h, double *X, double *U, double *t)
+{
+    return withAlg(h, [&](auto &a) {
+        std::memcpy(X, a.td.X.data(), a.td.X.size() * sizeof(double));
+        std::memcpy(U, a.td.U.data(), a.td.U.size() * sizeof(double));
+        *t = a.td.t;
+        return 0;
+    });
+}
+// all iterates, NON-dimensional as stored (index 0 = initial guess of the first solve)
+int oracle_sc_get_iterate(void *h, int idx, double *X, double *U, double *t)
+{
+    return withAlg(h, [&](auto &a) {
+        if (idx < 0 || idx >= int(a.all_td.size()))
+            return -1;
+        const TrajectoryData &td = a.all_td[idx];
+        std::memcpy(X, td.X.data(), td.X.size() * sizeof(double));
+        std::memcpy(U, td.U.data(), td.U.size() * sizeof(double));
+        *t = td.t;
+        return 0;
+    });
+}
+// per-iteration info rows: [norm1_nu, sum_delta, delta_sigma, sigma, ipm_iters, exitflag, pres, dres, gap]
+int oracle_sc_get_info(void *h, double *rows, int max_rows)
+{
+    return withAlg(h, [&](auto &a) {
+        int n = std::min<int>(max_rows, int(a.info.size()));
+        for (int i = 0; i < n; i++)
+        {
+            const SCIterationInfo &f = a.info[i];
+            double *r = rows + i * 9;
+            r[0] = f.norm1_nu;
+            r[1] = f.sum_delta;
+            r[2] = f.delta_sigma;
+            r[3] = f.sigma;
+            r[4] = f.ipm_iters;
+            r[5] = f.exitflag;
+            r[6] = f.pres;
+            r[7] = f.dres;
+            r[8] = f.gap;
+        }
+        return n;
+    });
+}
+// last sub-problem primal vector and variable offsets [X,U,nu,nu_bound,norm1_nu,delta,sigma,delta_sigma]
+int oracle_sc_get_last_socp_x(void *h, double *x, int *offsets)
+{
+    return withAlg(h, [&](auto &a) {
+        for (size_t i = 0; i < a.last_result.x.size(); i++)
+            x[i] = a.last_result.x[i];
+        const SCVarIndex &ix = a.last_ix;
+        const int o[8] = {ix.X, ix.U, ix.nu, ix.nu_bound, ix.norm1_nu, ix.delta, ix.sigma, ix.delta_sigma};
+        for (int i = 0; i < 8; i++)
+            offsets[i] = o[i];
+        return int(a.last_result.x.size());
+    });
+}
+// scales [m_scale, r_scale] and current weight_trust_region_trajectory
+int oracle_sc_get_scales(void *h, double *out)
+{
+    return withAlg(h, [&](auto &a) {
+        out[0] = a.model->p.m_scale;
+        out[1] = a.model->p.r_scale;
+        out[2] = a.weight_trust_region_trajectory;
+        return 0;
+    });
+}
+
+// ---- batched RocketQuat SC_oneshot over randomised instances (cpu_baseline leg) ----
+// outputs per instance: X[K][14], U[K][4] (dimensional), t, iters, converged, final norm1_nu, total ipm iters
+int oracle_sc_batch(const char *config_root, int K, unsigned long long seed, long first, long count, int nthreads,
+                    int solver_kind, double *X, double *U, double *t, int *iters, int *conv, double *nu, int *ipm_iters)
+{
+    if (nthreads < 1)
+        nthreads = 1;
+    std::vector<std::thread> pool;
+    std::vector<int> rc(nthreads, 0);
+    for (int th = 0; th < nthreads; th++)
+    {
+        pool.emplace_back([&, th]() {
+            for (long i = th; i < count; i += nthreads)
+            {
+                try
+                {
+                    SCHandle<RocketQuat> hnd(config_root, K);
+                    hnd.model.p.randomizeInitialState(seed, (unsigned long long)(first + i));
+                    hnd.alg->solver_kind = solver_kind;
+                    hnd.solve(0);
+                    auto &a = *hnd.alg;
+                    std::memcpy(X + size_t(i) * K * 14, a.td.X.data(), sizeof(double) * K * 14);
+                    std::memcpy(U + size_t(i) * K * 4, a.td.U.data(), sizeof(double) * K * 4);
+                    t[i] = a.td.t;
+                    iters[i] = a.iterations;
+                    conv[i] = a.converged ? 1 : 0;
+                    nu[i] = a.info.empty() ? 0. : a.info.back().norm1_nu;
+                    int tot = 0;
+                    for (auto &f : a.info)
+                        tot += f.ipm_iters;
+                    ipm_iters[i] = tot;
+                }
+                catch (const std::exception &e)
+                {
+                    rc[th] = -1;
+                }
+            }
+        });
+    }
+    for (auto &th : pool)
+        th.join();
+    for (int r : rc)
+        if (r)
+            return r;
+    return 0;
+}
+
+} // extern "C"

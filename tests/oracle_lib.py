@@ -1,0 +1,238 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE, never imported by the product).
+
+The oracle is the CPU restatement of the reference algorithm (see oracle/*.hpp headers for the
+reference file:line each function follows).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+CONFIG_ROOT = os.path.join(ROOT, "scpp_amd", "config")
+
+ROCKETQUAT, ROCKET2D = 0, 1
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(path)
+            for f in os.listdir(ORACLE_DIR)
+            if f.endswith((".hpp", ".cpp"))
+        ):
+            build()
+        _lib = C.CDLL(path)
+        _lib.oracle_sc_create.restype = C.c_void_p
+        _lib.oracle_sc_create.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        for name in (
+            "oracle_sc_destroy oracle_sc_solve oracle_sc_meta oracle_sc_get_solution oracle_sc_get_iterate "
+            "oracle_sc_get_info oracle_sc_get_scales oracle_sc_randomize oracle_sc_get_x_init oracle_sc_set_x_init "
+            "oracle_sc_get_x_final oracle_sc_set_tolerances oracle_sc_verbose"
+        ).split():
+            getattr(_lib, name).argtypes = None
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dims(model):
+    d = np.zeros(3, dtype=np.int32)
+    lib().oracle_model_dims(model, _p(d))
+    return int(d[0]), int(d[1]), int(d[2])
+
+
+def flow(model, x, u, par):
+    nx, nu, _ = dims(model)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    f = np.zeros(nx)
+    A = np.zeros((nx, nx))
+    B = np.zeros((nx, nu))
+    lib().oracle_flow(model, _p(x), _p(u), _p(par), _p(f), _p(A), _p(B))
+    return f, A, B
+
+
+def rkf78_tableau():
+    c = np.zeros(13)
+    a = np.zeros((13, 13))
+    b = np.zeros(13)
+    lib().oracle_rkf78_tableau(_p(c), _p(a), _p(b))
+    return c, a, b
+
+
+def rkf78_harmonic(omega, dt, n):
+    y = np.zeros(2)
+    lib().oracle_rkf78_harmonic(C.c_double(omega), C.c_double(dt), int(n), _p(y))
+    return y
+
+
+def discretize(model, par, X, U, t, foh=True, vt=True):
+    nx, nu, _ = dims(model)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    K = X.shape[0]
+    A = np.zeros((K - 1, nx, nx))
+    B = np.zeros((K - 1, nx, nu))
+    Cm = np.zeros((K - 1, nx, nu))
+    s = np.zeros((K - 1, nx))
+    z = np.zeros((K - 1, nx))
+    lib().oracle_discretize(model, K, int(foh), int(vt), _p(par), _p(X), _p(U), C.c_double(t), _p(A), _p(B), _p(Cm), _p(s), _p(z))
+    return A, B, Cm, s, z
+
+
+def simulate(model, par, dt, u0, u1, x):
+    x = np.array(x, dtype=np.float64)
+    u0 = np.ascontiguousarray(u0, dtype=np.float64)
+    u1 = np.ascontiguousarray(u1, dtype=np.float64)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    lib().oracle_simulate(model, _p(par), C.c_double(dt), _p(u0), _p(u1), _p(x))
+    return x
+
+
+def socp_solve(c, A, b, G, h, l, q):
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    n = c.size
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, n) if np.size(A) else np.zeros((0, n))
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    G = np.ascontiguousarray(G, dtype=np.float64).reshape(-1, n)
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.int32)
+    p, m = A.shape[0], G.shape[0]
+    x = np.zeros(n)
+    y = np.zeros(max(p, 1))
+    z = np.zeros(m)
+    s = np.zeros(m)
+    info = np.zeros(8)
+    lib().oracle_socp_solve(n, p, int(l), int(q.size), _p(q), _p(c), _p(A), _p(b), _p(G), _p(h), _p(x), _p(y), _p(z), _p(s), _p(info))
+    return dict(x=x, y=y[:p], z=z, s=s, exitflag=int(info[0]), iter=int(info[1]), pcost=info[2], dcost=info[3],
+                pres=info[4], dres=info[5], gap=info[6])
+
+
+class SC:
+    """Oracle SCAlgorithm handle (SCAlgorithm.cpp:14-210 restated)."""
+
+    def __init__(self, model, K=0, config_root=CONFIG_ROOT):
+        self.model = model
+        self.h = lib().oracle_sc_create(model, config_root.encode(), int(K))
+        if not self.h:
+            raise RuntimeError("oracle_sc_create failed")
+        self.h = C.c_void_p(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_sc_destroy(self.h)
+            self.h = None
+
+    def set_tolerances(self, feastol=1e-8, abstol=1e-8, reltol=1e-8, maxit=100):
+        lib().oracle_sc_set_tolerances(self.h, C.c_double(feastol), C.c_double(abstol), C.c_double(reltol), int(maxit))
+
+    def set_solver(self, kind):
+        """0 = literal standard form + ECOS-style solver, 1 = structured IPM twin (RocketQuat only)."""
+        lib().oracle_sc_set_solver(self.h, int(kind))
+
+    def verbose(self, v=True):
+        lib().oracle_sc_verbose(self.h, int(v))
+
+    def randomize(self, seed, instance):
+        return lib().oracle_sc_randomize(self.h, C.c_ulonglong(seed), C.c_ulonglong(instance))
+
+    def x_init(self):
+        nx = dims(self.model)[0]
+        x = np.zeros(nx)
+        lib().oracle_sc_get_x_init(self.h, _p(x))
+        return x
+
+    def set_x_init(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().oracle_sc_set_x_init(self.h, _p(x))
+
+    def x_final(self):
+        nx = dims(self.model)[0]
+        x = np.zeros(nx)
+        lib().oracle_sc_get_x_final(self.h, _p(x))
+        return x
+
+    def solve(self, warm_start=False):
+        return lib().oracle_sc_solve(self.h, int(warm_start))
+
+    def meta(self):
+        m = np.zeros(12, dtype=np.int32)
+        lib().oracle_sc_meta(self.h, _p(m))
+        keys = "K nU nx nu iterations converged n_all_td n p l ncones m".split()
+        return dict(zip(keys, [int(v) for v in m]))
+
+    def solution(self):
+        m = self.meta()
+        X = np.zeros((m["K"], m["nx"]))
+        U = np.zeros((m["nU"], m["nu"]))
+        t = C.c_double(0)
+        lib().oracle_sc_get_solution(self.h, _p(X), _p(U), C.byref(t))
+        return X, U, t.value
+
+    def iterate(self, idx):
+        m = self.meta()
+        X = np.zeros((m["K"], m["nx"]))
+        U = np.zeros((m["nU"], m["nu"]))
+        t = C.c_double(0)
+        rc = lib().oracle_sc_get_iterate(self.h, int(idx), _p(X), _p(U), C.byref(t))
+        assert rc == 0
+        return X, U, t.value
+
+    def info(self):
+        rows = np.zeros((64, 9))
+        n = lib().oracle_sc_get_info(self.h, _p(rows), 64)
+        return rows[:n]
+
+    def last_socp(self):
+        m = self.meta()
+        x = np.zeros(m["n"])
+        off = np.zeros(8, dtype=np.int32)
+        lib().oracle_sc_get_last_socp_x(self.h, _p(x), _p(off))
+        K, nx, nu, nU = m["K"], m["nx"], m["nu"], m["nU"]
+        o = dict(zip("X U nu nu_bound norm1_nu delta sigma delta_sigma".split(), [int(v) for v in off]))
+        return dict(
+            x=x,
+            X=x[o["X"]:o["X"] + K * nx].reshape(K, nx),
+            U=x[o["U"]:o["U"] + nU * nu].reshape(nU, nu),
+            nu=x[o["nu"]:o["nu"] + (K - 1) * nx].reshape(K - 1, nx),
+            nu_bound=x[o["nu_bound"]:o["nu_bound"] + (K - 1) * nx].reshape(K - 1, nx),
+            norm1_nu=x[o["norm1_nu"]],
+            delta=x[o["delta"]:o["delta"] + K],
+            sigma=x[o["sigma"]] if o["sigma"] >= 0 else None,
+            delta_sigma=x[o["delta_sigma"]] if o["delta_sigma"] >= 0 else None,
+        )
+
+    def scales(self):
+        out = np.zeros(3)
+        lib().oracle_sc_get_scales(self.h, _p(out))
+        return out
+
+
+def sc_batch(K, seed, first, count, nthreads=1, solver=1, config_root=CONFIG_ROOT):
+    X = np.zeros((count, K, 14))
+    U = np.zeros((count, K, 4))
+    t = np.zeros(count)
+    iters = np.zeros(count, dtype=np.int32)
+    conv = np.zeros(count, dtype=np.int32)
+    nu = np.zeros(count)
+    ipm = np.zeros(count, dtype=np.int32)
+    rc = lib().oracle_sc_batch(config_root.encode(), int(K), C.c_ulonglong(seed), C.c_long(first), C.c_long(count),
+                               int(nthreads), int(solver), _p(X), _p(U), _p(t), _p(iters), _p(conv), _p(nu), _p(ipm))
+    if rc != 0:
+        raise RuntimeError("oracle_sc_batch failed")
+    return dict(X=X, U=U, t=t, iters=iters, converged=conv, nu=nu, ipm_iters=ipm)
