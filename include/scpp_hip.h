@@ -1,0 +1,121 @@
+/* scpp_hip.h -- C ABI of the MI355X (gfx950) batched Successive-Convexification engine.
+ *
+ * Drop-in boundary for the ONE hot path of EmbersArc/SCpp that this library replaces:
+ *
+ *   reference interface (file:line in the reference tree)                      entry point(s) here
+ *   -------------------------------------------------------------------------  ----------------------------
+ *   scpp::discretization::multipleShooting(model, td, dd)                      scpp_hip_upload_traj
+ *       scpp_core/include/discretization.hpp:16-19                             scpp_hip_set_flow_params
+ *       scpp_core/src/discretization.cpp:42-55                                 scpp_hip_discretize
+ *       (td: trajectoryData.hpp:8-32, dd: discretizationData.hpp:8-53)         scpp_hip_download_dd
+ *   scpp::simulate(model, dt, u0, u1, x)  scpp_core/src/simulation.cpp:25-42   scpp_hip_simulate
+ *   SystemModel::updateModelParameters    scpp_core/include/systemModel.hpp:90 scpp_hip_set_flow_params
+ *   cvx::ecos::ECOSSolver::solve(false)   scpp_core/src/SCAlgorithm.cpp:78     scpp_hip_socp_solve
+ *       on buildSCProblem (SCProblem.cpp:6-138) + RocketQuat::addApplicationConstraints
+ *       (scpp_models/src/rocketQuat.cpp:70-144)
+ *   SCAlgorithm::initialize/solve/iterate scpp_core/src/SCAlgorithm.cpp:48-189 scpp_hip_sc_setup, scpp_hip_sc_iterate,
+ *   (incl. RocketQuat (non|re)dimensionalize*, getInitializedTrajectory,       scpp_hip_sc_solve
+ *    getNewModelParameters: rocketQuat.cpp:39-68,156-201,291-332)
+ *   SCAlgorithm::getSolution              scpp_core/include/SCAlgorithm.hpp:37 scpp_hip_download
+ *
+ * Conventions: every function returns 0 on success or a negative SCPP_E_* code; nothing throws or
+ * exits.  One context per GPU, one host thread per context.  All host buffers are caller-owned,
+ * float64, C-contiguous.  Trajectories are [B][K][nx] / [B][K][nu]; discretization blocks are
+ * ROW-major [B][K-1][nx][nx] etc. (the reference stores Eigen column-major blocks per segment).
+ * Batch entries are independent problem instances ("B" below).
+ */
+#ifndef SCPP_HIP_H
+#define SCPP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define SCPP_MODEL_ROCKETQUAT 0
+#define SCPP_MODEL_ROCKET2D 1
+
+#define SCPP_MODE_FOH 1 /* interpolate_input   (discretizationData.hpp:56-59) */
+#define SCPP_MODE_VT 2  /* free_final_time     (discretizationData.hpp:62-65) */
+
+#define SCPP_OK 0
+#define SCPP_E_ARG -1
+#define SCPP_E_HIP -2
+#define SCPP_E_UNSUPPORTED -3
+#define SCPP_E_STATE -4
+
+    typedef struct scpp_hip_ctx scpp_hip_ctx;
+
+    /* RocketQuat::Parameters after loadFromFile (rocketQuat.cpp:234-289): SI units, angles in radians */
+    typedef struct
+    {
+        double g_I[3], J_B[3], r_T_B[3];
+        double alpha_m, T_min, T_max, t_max;
+        double gimbal_max, theta_max, gamma_gs, w_B_max;
+        double x_final[14];
+        double final_time;
+        int exact_minimum_thrust;
+        int enable_roll_control;
+    } scpp_rocketquat_params;
+
+    /* SC.info (SCAlgorithm.cpp:22-46) */
+    typedef struct
+    {
+        int K;
+        int free_final_time, interpolate_input, nondimensionalize, max_iterations;
+        double weight_time, weight_trust_region_time, weight_trust_region_trajectory, weight_virtual_control;
+        double nu_tol, delta_tol;
+    } scpp_sc_opts;
+
+    /* interior-point settings (ECOS-style tolerances) */
+    typedef struct
+    {
+        double feastol, abstol, reltol;
+        int maxit;
+        int use_mfma; /* 1: v_mfma_f64_16x16x4_f64 tile products, 0: plain FMA (same results to round-off) */
+    } scpp_socp_opts;
+
+    /* accumulated device time per kernel family, measured with hipEvents on the context stream */
+    typedef struct
+    {
+        double ms_discretize, ms_socp, ms_other;
+        long long n_discretize, n_socp;          /* kernel launches */
+        long long inst_discretize, inst_socp;    /* sum over launches of ACTIVE instances processed */
+    } scpp_timing;
+
+    int scpp_hip_create(scpp_hip_ctx **ctx, int device_id, int model_id, int K, int batch_max, unsigned flags);
+    int scpp_hip_destroy(scpp_hip_ctx *ctx);
+    const char *scpp_hip_version(void);
+
+    /* ---- multipleShooting / simulate boundary (any model) ---- */
+    int scpp_hip_set_flow_params(scpp_hip_ctx *ctx, const double *par /* [B][np] */, int B);
+    int scpp_hip_upload_traj(scpp_hip_ctx *ctx, const double *X, const double *U, const double *sigma, int B);
+    int scpp_hip_discretize(scpp_hip_ctx *ctx, int mode);
+    int scpp_hip_download_dd(scpp_hip_ctx *ctx, double *A, double *B, double *C, double *S, double *Z);
+    int scpp_hip_simulate(scpp_hip_ctx *ctx, const double *dt /* [B] */, const double *u0, const double *u1,
+                          double *x /* [B][nx] in/out */, int B);
+
+    /* ---- SCAlgorithm boundary (RocketQuat) ---- */
+    int scpp_hip_set_socp_opts(scpp_hip_ctx *ctx, const scpp_socp_opts *opts);
+    int scpp_hip_sc_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_sc_opts *opts,
+                          const double *x_init /* [B][14] dimensional */, int B, int warm_start);
+    int scpp_hip_sc_iterate(scpp_hip_ctx *ctx, int *n_active);  /* one SCAlgorithm::iterate on every active instance */
+    int scpp_hip_sc_solve(scpp_hip_ctx *ctx, int *n_converged); /* whole SCAlgorithm::solve loop on the device */
+    int scpp_hip_socp_solve(scpp_hip_ctx *ctx);                 /* sub-problem only, on the current td/dd */
+    /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
+    int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
+                          int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);
+    int scpp_hip_download_socp_info(scpp_hip_ctx *ctx, double *info /* [B][8]: pcost,gap,pres,dres,iters,status,norm1_nu,sum_delta */);
+
+    /* ---- plumbing ---- */
+    int scpp_hip_get_timing(scpp_hip_ctx *ctx, scpp_timing *out, int reset);
+    /* device pointers of the result buffers (for zero-copy wrapping, e.g. the RCCL all-gather of
+       converged trajectories): X [B][K][14], U [B][K][4], sigma [B] */
+    int scpp_hip_device_ptrs(scpp_hip_ctx *ctx, void **X, void **U, void **sigma);
+    int scpp_hip_synchronize(scpp_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

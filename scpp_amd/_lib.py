@@ -1,0 +1,231 @@
+"""ctypes binding of the C ABI declared in include/scpp_hip.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+MODEL_ROCKETQUAT, MODEL_ROCKET2D = 0, 1
+MODE_FOH, MODE_VT = 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class ScppHipError(RuntimeError):
+    pass
+
+
+class RocketQuatParams(C.Structure):
+    """scpp_rocketquat_params (RocketQuat::Parameters after loadFromFile, rocketQuat.cpp:234-289)."""
+
+    _fields_ = [
+        ("g_I", C.c_double * 3),
+        ("J_B", C.c_double * 3),
+        ("r_T_B", C.c_double * 3),
+        ("alpha_m", C.c_double),
+        ("T_min", C.c_double),
+        ("T_max", C.c_double),
+        ("t_max", C.c_double),
+        ("gimbal_max", C.c_double),
+        ("theta_max", C.c_double),
+        ("gamma_gs", C.c_double),
+        ("w_B_max", C.c_double),
+        ("x_final", C.c_double * 14),
+        ("final_time", C.c_double),
+        ("exact_minimum_thrust", C.c_int),
+        ("enable_roll_control", C.c_int),
+    ]
+
+
+class SCOpts(C.Structure):
+    """scpp_sc_opts (SC.info, SCAlgorithm.cpp:22-46)."""
+
+    _fields_ = [
+        ("K", C.c_int),
+        ("free_final_time", C.c_int),
+        ("interpolate_input", C.c_int),
+        ("nondimensionalize", C.c_int),
+        ("max_iterations", C.c_int),
+        ("weight_time", C.c_double),
+        ("weight_trust_region_time", C.c_double),
+        ("weight_trust_region_trajectory", C.c_double),
+        ("weight_virtual_control", C.c_double),
+        ("nu_tol", C.c_double),
+        ("delta_tol", C.c_double),
+    ]
+
+
+class SocpOpts(C.Structure):
+    _fields_ = [
+        ("feastol", C.c_double),
+        ("abstol", C.c_double),
+        ("reltol", C.c_double),
+        ("maxit", C.c_int),
+        ("use_mfma", C.c_int),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("ms_discretize", C.c_double),
+        ("ms_socp", C.c_double),
+        ("ms_other", C.c_double),
+        ("n_discretize", C.c_longlong),
+        ("n_socp", C.c_longlong),
+        ("inst_discretize", C.c_longlong),
+        ("inst_socp", C.c_longlong),
+    ]
+
+
+_lib = None
+_lib_path = None
+
+SYMBOLS = [
+    "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
+    "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
+    "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
+    "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
+]
+
+
+def load_library(path=None):
+    """Load libscpp_hip.so (built by `python -c 'import __graft_entry__ as g; g.build()'`).
+
+    Raises ScppHipError if the HIP library is missing: the product has no CPU fallback.  Tests of the kernel
+    logic on GPU-less machines pass the path of the emulation build (tests/emu/libscpp_emu.so) explicitly.
+    """
+    global _lib, _lib_path
+    if path is None:
+        path = os.environ.get("SCPP_HIP_LIBRARY", os.path.join(_HERE, "libscpp_hip.so"))
+    if _lib is not None and _lib_path == path:
+        return _lib
+    if not os.path.exists(path):
+        raise ScppHipError(
+            f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "scpp_amd has no CPU fallback."
+        )
+    lib = C.CDLL(path)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise ScppHipError(f"{path} does not export {s}")
+    lib.scpp_hip_version.restype = C.c_char_p
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ScppHipError(f"{what} failed with code {rc}")
+
+
+class Context:
+    """One scpp_hip_ctx (one GPU, one stream)."""
+
+    def __init__(self, model=MODEL_ROCKETQUAT, K=50, batch_max=256, device=0, library=None):
+        self.lib = load_library(library)
+        self.model, self.K, self.batch_max = model, K, batch_max
+        self.nx, self.nu, self.np_ = (14, 4, 10) if model == MODEL_ROCKETQUAT else (6, 2, 6)
+        h = C.c_void_p()
+        _chk(self.lib.scpp_hip_create(C.byref(h), int(device), int(model), int(K), int(batch_max), C.c_uint(0)), "scpp_hip_create")
+        self.h = h
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.scpp_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- multipleShooting boundary ----
+    def set_flow_params(self, par):
+        par = np.ascontiguousarray(par, dtype=np.float64).reshape(-1, self.np_)
+        _chk(self.lib.scpp_hip_set_flow_params(self.h, _p(par), int(par.shape[0])), "set_flow_params")
+
+    def upload_traj(self, X, U, sigma):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.K, self.nx)
+        U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, self.K, self.nu)
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(-1)
+        self.B = X.shape[0]
+        _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
+
+    def discretize(self, mode=MODE_FOH | MODE_VT):
+        _chk(self.lib.scpp_hip_discretize(self.h, int(mode)), "discretize")
+
+    def download_dd(self):
+        B, K, nx, nu = self.B, self.K, self.nx, self.nu
+        A = np.zeros((B, K - 1, nx, nx))
+        Bm = np.zeros((B, K - 1, nx, nu))
+        Cm = np.zeros((B, K - 1, nx, nu))
+        S = np.zeros((B, K - 1, nx))
+        Z = np.zeros((B, K - 1, nx))
+        _chk(self.lib.scpp_hip_download_dd(self.h, _p(A), _p(Bm), _p(Cm), _p(S), _p(Z)), "download_dd")
+        return A, Bm, Cm, S, Z
+
+    def simulate(self, dt, u0, u1, x):
+        x = np.array(x, dtype=np.float64).reshape(-1, self.nx)
+        B = x.shape[0]
+        dt = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, dtype=np.float64), (B,)))
+        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(B, self.nu)
+        u1 = np.ascontiguousarray(u1, dtype=np.float64).reshape(B, self.nu)
+        _chk(self.lib.scpp_hip_simulate(self.h, _p(dt), _p(u0), _p(u1), _p(x), int(B)), "simulate")
+        return x
+
+    # ---- SC boundary ----
+    def set_socp_opts(self, feastol=1e-8, abstol=1e-7, reltol=1e-7, maxit=60, use_mfma=1):
+        o = SocpOpts(feastol, abstol, reltol, maxit, use_mfma)
+        _chk(self.lib.scpp_hip_set_socp_opts(self.h, C.byref(o)), "set_socp_opts")
+
+    def sc_setup(self, model_params, sc_opts, x_init, warm_start=False):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        self.B = x_init.shape[0]
+        _chk(self.lib.scpp_hip_sc_setup(self.h, C.byref(model_params), C.byref(sc_opts), _p(x_init), int(self.B), int(warm_start)), "sc_setup")
+
+    def sc_iterate(self):
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_sc_iterate(self.h, C.byref(n)), "sc_iterate")
+        return n.value
+
+    def sc_solve(self):
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_sc_solve(self.h, C.byref(n)), "sc_solve")
+        return n.value
+
+    def socp_solve(self):
+        _chk(self.lib.scpp_hip_socp_solve(self.h), "socp_solve")
+
+    def download(self):
+        B, K = self.B, self.K
+        out = dict(
+            X=np.zeros((B, K, self.nx)), U=np.zeros((B, K, self.nu)), sigma=np.zeros(B), sc_iters=np.zeros(B, dtype=np.int32),
+            nu_norm=np.zeros(B), converged=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32),
+            ipm_iters=np.zeros(B, dtype=np.int32), sum_delta=np.zeros(B),
+        )
+        _chk(self.lib.scpp_hip_download(self.h, _p(out["X"]), _p(out["U"]), _p(out["sigma"]), _p(out["sc_iters"]), _p(out["nu_norm"]),
+                                        _p(out["converged"]), _p(out["status"]), _p(out["ipm_iters"]), _p(out["sum_delta"])), "download")
+        return out
+
+    def socp_info(self):
+        info = np.zeros((self.B, 8))
+        _chk(self.lib.scpp_hip_download_socp_info(self.h, _p(info)), "download_socp_info")
+        return info
+
+    def timing(self, reset=False):
+        t = Timing()
+        _chk(self.lib.scpp_hip_get_timing(self.h, C.byref(t), int(reset)), "get_timing")
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+    def device_ptrs(self):
+        X, U, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(self.lib.scpp_hip_device_ptrs(self.h, C.byref(X), C.byref(U), C.byref(s)), "device_ptrs")
+        return X.value, U.value, s.value
+
+    def synchronize(self):
+        _chk(self.lib.scpp_hip_synchronize(self.h), "synchronize")

@@ -1,0 +1,103 @@
+// Shared device/host definitions for the HIP kernels (gfx950 only).
+// With -DSCPP_HIP_EMU the same sources build against tests/emu/hip_emu.h (CPU wave emulator used
+// ONLY by the CPU-side unit tests; the product library is always built by hipcc without it).
+#pragma once
+#ifdef SCPP_HIP_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+typedef double d4_t __attribute__((ext_vector_type(4)));
+#endif
+#include <cmath>
+#include <cstdint>
+
+namespace scpp
+{
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        const double o = __shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_or(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1)
+        v |= __shfl_xor(v, m);
+    return v;
+}
+
+// single-tangent forward dual: device-side stand-in for the reference's CppAD tape
+// (scpp_core/include/systemDynamics.hpp:109-168,206-235). One lane = one seed direction.
+struct Dual1
+{
+    double v, d;
+    __host__ __device__ Dual1() : v(0.), d(0.) {}
+    __host__ __device__ Dual1(double c) : v(c), d(0.) {}
+    __host__ __device__ Dual1(double v_, double d_) : v(v_), d(d_) {}
+};
+__host__ __device__ inline Dual1 operator+(Dual1 a, Dual1 b) { return Dual1(a.v + b.v, a.d + b.d); }
+__host__ __device__ inline Dual1 operator-(Dual1 a, Dual1 b) { return Dual1(a.v - b.v, a.d - b.d); }
+__host__ __device__ inline Dual1 operator-(Dual1 a) { return Dual1(-a.v, -a.d); }
+__host__ __device__ inline Dual1 operator*(Dual1 a, Dual1 b) { return Dual1(a.v * b.v, a.d * b.v + a.v * b.d); }
+__host__ __device__ inline Dual1 operator/(Dual1 a, Dual1 b)
+{
+    const double inv = 1. / b.v;
+    const double q = a.v * inv;
+    return Dual1(q, (a.d - q * b.d) * inv);
+}
+__host__ __device__ inline Dual1 operator+(Dual1 a, double b) { return Dual1(a.v + b, a.d); }
+__host__ __device__ inline Dual1 operator+(double a, Dual1 b) { return Dual1(a + b.v, b.d); }
+__host__ __device__ inline Dual1 operator-(Dual1 a, double b) { return Dual1(a.v - b, a.d); }
+__host__ __device__ inline Dual1 operator-(double a, Dual1 b) { return Dual1(a - b.v, -b.d); }
+__host__ __device__ inline Dual1 operator*(Dual1 a, double b) { return Dual1(a.v * b, a.d * b); }
+__host__ __device__ inline Dual1 operator*(double a, Dual1 b) { return Dual1(a * b.v, a * b.d); }
+__host__ __device__ inline Dual1 operator/(Dual1 a, double b) { return Dual1(a.v / b, a.d / b); }
+__host__ __device__ inline Dual1 operator/(double a, Dual1 b) { return Dual1(a) / b; }
+__host__ __device__ inline Dual1 dsqrt(Dual1 a)
+{
+    const double r = sqrt(a.v);
+    return Dual1(r, a.d * 0.5 / r);
+}
+__host__ __device__ inline Dual1 dsin(Dual1 a) { return Dual1(sin(a.v), a.d * cos(a.v)); }
+__host__ __device__ inline Dual1 dcos(Dual1 a) { return Dual1(cos(a.v), -a.d * sin(a.v)); }
+__host__ __device__ inline double dsqrt(double a) { return sqrt(a); }
+__host__ __device__ inline double dsin(double a) { return sin(a); }
+__host__ __device__ inline double dcos(double a) { return cos(a); }
+__host__ __device__ inline double valueOf(double a) { return a; }
+__host__ __device__ inline double valueOf(Dual1 a) { return a.v; }
+__host__ __device__ inline double tangentOf(double) { return 0.; }
+__host__ __device__ inline double tangentOf(Dual1 a) { return a.d; }
+
+// Runge-Kutta-Fehlberg 7(8), propagated with the 8th-order weights: the scheme of the reference's
+// boost::numeric::odeint::runge_kutta_fehlberg78 (discretizationImplementation.hpp:141).
+constexpr int RK_S = 13;
+constexpr double RK_C[RK_S] = {0., 2. / 27., 1. / 9., 1. / 6., 5. / 12., 1. / 2., 5. / 6., 1. / 6., 2. / 3., 1. / 3., 1., 0., 1.};
+constexpr double RK_A[RK_S][RK_S] = {
+    {0},
+    {2. / 27.},
+    {1. / 36., 1. / 12.},
+    {1. / 24., 0., 1. / 8.},
+    {5. / 12., 0., -25. / 16., 25. / 16.},
+    {1. / 20., 0., 0., 1. / 4., 1. / 5.},
+    {-25. / 108., 0., 0., 125. / 108., -65. / 27., 125. / 54.},
+    {31. / 300., 0., 0., 0., 61. / 225., -2. / 9., 13. / 900.},
+    {2., 0., 0., -53. / 6., 704. / 45., -107. / 9., 67. / 90., 3.},
+    {-91. / 108., 0., 0., 23. / 108., -976. / 135., 311. / 54., -19. / 60., 17. / 6., -1. / 12.},
+    {2383. / 4100., 0., 0., -341. / 164., 4496. / 1025., -301. / 82., 2133. / 4100., 45. / 82., 45. / 164., 18. / 41.},
+    {3. / 205., 0., 0., 0., 0., -6. / 41., -3. / 205., -3. / 41., 3. / 41., 6. / 41., 0.},
+    {-1777. / 4100., 0., 0., -341. / 164., 4496. / 1025., -289. / 82., 2193. / 4100., 51. / 82., 33. / 164., 12. / 41., 0., 1.}};
+constexpr double RK_B[RK_S] = {0., 0., 0., 0., 0., 34. / 105., 9. / 35., 9. / 35., 9. / 280., 9. / 280., 0., 41. / 840., 41. / 840.};
+
+} // namespace scpp

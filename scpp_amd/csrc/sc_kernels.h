@@ -1,0 +1,211 @@
+// Element-wise kernels around the two hot kernels: per-instance problem setup, trajectory
+// initialisation and (re)dimensionalisation -- batched counterparts of
+//   RocketQuat::Parameters::nondimensionalize / redimensionalize   scpp_models/src/rocketQuat.cpp:291-332
+//   RocketQuat::getInitializedTrajectory                           scpp_models/src/rocketQuat.cpp:39-68
+//   RocketQuat::getNewModelParameters / updateProblemParameters    scpp_models/src/rocketQuat.cpp:156-173
+//   RocketQuat::(non|re)dimensionalizeTrajectory                    scpp_models/src/rocketQuat.cpp:175-201
+//   SCAlgorithm::solve (cold / warm start bookkeeping)              scpp_core/src/SCAlgorithm.cpp:134-160,182-187
+// One thread per instance (K <= 64 nodes each; negligible next to the solver).
+#pragma once
+#include "ipm_kernel.h"
+#include "../../include/scpp_hip.h"
+
+namespace scpp
+{
+
+struct SCBuffers
+{
+    int B, K;
+    const double *x_init_dim; // [B][14] dimensional initial states
+    double *X, *U, *sigma;    // trajectory (nondimensional while solving)
+    double *ip;               // [B][IP_N]
+    double *uhat;             // [B][K][3]
+    double *wtrx;
+    int *active, *converged, *sc_iters, *ipm_iters, *status;
+    double *norm1_nu, *sum_delta, *delta_sigma;
+};
+
+// cold (warm=0) or warm (warm=1) start of SCAlgorithm::solve for every instance
+__global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_opts so, int warm)
+{
+    using namespace ipm;
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    const int K = b.K;
+    const double *xi = b.x_init_dim + i * 14;
+    double *ip = b.ip + i * IP_N;
+    double m_scale = 1., r_scale = 1.;
+    if (so.nondimensionalize)
+    {
+        m_scale = xi[0];
+        r_scale = sqrt(xi[1] * xi[1] + xi[2] * xi[2] + xi[3] * xi[3]);
+    }
+    double x0[14], xf[14];
+    for (int j = 0; j < 14; j++)
+    {
+        x0[j] = xi[j];
+        xf[j] = mp.x_final[j];
+    }
+    x0[0] /= m_scale;
+    xf[0] /= m_scale;
+    for (int j = 1; j < 7; j++)
+    {
+        x0[j] /= r_scale;
+        xf[j] /= r_scale;
+    }
+    for (int j = 0; j < 14; j++)
+    {
+        ip[IP_XINIT + j] = x0[j];
+        ip[IP_XFINAL + j] = xf[j];
+    }
+    const double T_min = mp.T_min / (m_scale * r_scale), T_max = mp.T_max / (m_scale * r_scale);
+    ip[IP_GS] = tan(mp.gamma_gs);
+    ip[IP_TILT] = sqrt((1. - cos(mp.theta_max)) / 2.);
+    ip[IP_WMAX] = mp.w_B_max;
+    ip[IP_TMIN] = T_min;
+    ip[IP_TMAX] = T_max;
+    ip[IP_GIM] = tan(mp.gimbal_max);
+    ip[IP_MDRY] = xf[0];
+    ip[IP_WT] = so.weight_time;
+    ip[IP_WTRT] = so.weight_trust_region_time;
+    ip[IP_WTRX] = so.weight_trust_region_trajectory;
+    ip[IP_WVC] = so.weight_virtual_control;
+    ip[IP_PAR + 0] = mp.alpha_m * r_scale;
+    for (int j = 0; j < 3; j++)
+    {
+        ip[IP_PAR + 1 + j] = mp.g_I[j] / r_scale;
+        ip[IP_PAR + 4 + j] = mp.J_B[j] / (m_scale * r_scale * r_scale);
+        ip[IP_PAR + 7 + j] = mp.r_T_B[j] / r_scale;
+    }
+    ip[IP_MSCALE] = m_scale;
+    ip[IP_RSCALE] = r_scale;
+    ip[IP_FINALTIME] = mp.final_time;
+
+    double *X = b.X + i * K * 14, *U = b.U + i * K * 4;
+    if (!warm)
+    {
+        // getInitializedTrajectory (k/K interpolation quirk kept)
+        for (int k = 0; k < K; k++)
+        {
+            const double a1 = double(K - k) / K, a2 = double(k) / K;
+            double *x = X + k * 14;
+            for (int j = 0; j < 7; j++)
+                x[j] = a1 * x0[j] + a2 * xf[j];
+            const double *q0 = x0 + 7, *q1 = xf + 7;
+            const double one = 1. - 2.220446049250313e-16;
+            const double d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+            const double absD = fabs(d);
+            double s0, s1;
+            if (absD >= one)
+            {
+                s0 = 1. - a2;
+                s1 = a2;
+            }
+            else
+            {
+                const double th = acos(absD), st = sin(th);
+                s0 = sin((1. - a2) * th) / st;
+                s1 = sin(a2 * th) / st;
+            }
+            if (d < 0.)
+                s1 = -s1;
+            for (int j = 0; j < 4; j++)
+                x[7 + j] = s0 * q0[j] + s1 * q1[j];
+            for (int j = 11; j < 14; j++)
+                x[j] = a1 * x0[j] + a2 * xf[j];
+            double *u = U + k * 4;
+            u[0] = 0.;
+            u[1] = 0.;
+            u[2] = (T_max - T_min) / 2.;
+            u[3] = 0.;
+        }
+        b.sigma[i] = mp.final_time;
+        b.wtrx[i] = so.weight_trust_region_trajectory; // loadParameters() on cold start
+    }
+    else
+    {
+        // warm start: stored trajectory is dimensional -> nondimensionalizeTrajectory
+        for (int k = 0; k < K; k++)
+        {
+            double *x = X + k * 14, *u = U + k * 4;
+            x[0] /= m_scale;
+            for (int j = 1; j < 7; j++)
+                x[j] /= r_scale;
+            for (int j = 0; j < 3; j++)
+                u[j] /= m_scale * r_scale;
+            u[3] /= m_scale * r_scale * r_scale;
+        }
+        // weight_trust_region_trajectory keeps its (doubled) value: loadParameters() is skipped
+    }
+    // updateProblemParameters: thrust_const from the trajectory bound at solve() start
+    for (int k = 0; k < K; k++)
+    {
+        double *uh = b.uhat + (i * K + k) * 3;
+        if (mp.exact_minimum_thrust)
+        {
+            const double *u = U + k * 4;
+            const double z = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+            const double s = z > 0. ? 1. / sqrt(z) : 1.;
+            for (int j = 0; j < 3; j++)
+                uh[j] = u[j] * s;
+        }
+        else
+        {
+            uh[0] = 0.;
+            uh[1] = 0.;
+            uh[2] = 1.;
+        }
+    }
+    b.active[i] = 1;
+    b.converged[i] = 0;
+    b.sc_iters[i] = 0;
+    b.ipm_iters[i] = 0;
+    b.status[i] = 0;
+    b.norm1_nu[i] = 0.;
+    b.sum_delta[i] = 0.;
+    b.delta_sigma[i] = 0.;
+}
+
+// redimensionalizeTrajectory, in place
+__global__ void sc_redim_kernel(SCBuffers b)
+{
+    using namespace ipm;
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    const double m_scale = b.ip[i * IP_N + IP_MSCALE], r_scale = b.ip[i * IP_N + IP_RSCALE];
+    for (int k = 0; k < b.K; k++)
+    {
+        double *x = b.X + (i * b.K + k) * 14, *u = b.U + (i * b.K + k) * 4;
+        x[0] *= m_scale;
+        for (int j = 1; j < 7; j++)
+            x[j] *= r_scale;
+        for (int j = 0; j < 3; j++)
+            u[j] *= m_scale * r_scale;
+        u[3] *= m_scale * r_scale * r_scale;
+    }
+}
+
+// counts active instances (one block)
+__global__ void count_active_kernel(int B, const int *active, int *out)
+{
+    int acc = 0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x)
+        acc += active[i] != 0;
+    acc = int(wave_sum(double(acc)) + 0.5);
+    __shared__ int part[16];
+    const int wave = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+        part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int tot = 0;
+        for (int w = 0; w < int(blockDim.x) / WAVE; w++)
+            tot += part[w];
+        *out = tot;
+    }
+}
+
+} // namespace scpp

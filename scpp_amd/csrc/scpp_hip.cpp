@@ -1,0 +1,574 @@
+// C-ABI implementation (see include/scpp_hip.h). Compiled by hipcc for gfx950 (product) or, with
+// -DSCPP_HIP_EMU, by g++ against tests/emu/hip_emu.h (CPU-side kernel unit tests only).
+#include "../../include/scpp_hip.h"
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "discretize_kernel.h"
+#include "ipm_solve.h"
+#include "model_rocketquat.h"
+#include "sc_kernels.h"
+
+using namespace scpp;
+
+#define CHECK_HIP(expr)                  \
+    do                                   \
+    {                                    \
+        hipError_t e_ = (expr);          \
+        if (e_ != hipSuccess)            \
+            return SCPP_E_HIP;           \
+    } while (0)
+
+struct scpp_hip_ctx
+{
+    int device = 0, model = 0, K = 0, Bmax = 0, B = 0;
+    int nx = 0, nu = 0, np = 0;
+    hipStream_t stream = nullptr;
+    // trajectory + discretization
+    double *X = nullptr, *U = nullptr, *sigma = nullptr, *par = nullptr;
+    double *A = nullptr, *Bm = nullptr, *C = nullptr, *S = nullptr, *Z = nullptr;
+    // SC state
+    double *x_init = nullptr, *ip = nullptr, *uhat = nullptr, *wtrx = nullptr, *ws = nullptr, *dbg = nullptr;
+    int *active = nullptr, *converged = nullptr, *sc_iters = nullptr, *ipm_iters = nullptr, *status = nullptr, *counter = nullptr;
+    double *norm1_nu = nullptr, *sum_delta = nullptr, *delta_sigma = nullptr;
+    // simulate scratch
+    double *sim_dt = nullptr, *sim_u0 = nullptr, *sim_u1 = nullptr, *sim_x = nullptr;
+    scpp_sc_opts sc{};
+    scpp_rocketquat_params mp{};
+    scpp_socp_opts socp{1e-8, 1e-7, 1e-7, 60, 1};
+    bool sc_ready = false, par_from_ip = false;
+    int mode = SCPP_MODE_FOH | SCPP_MODE_VT;
+    // timing
+    struct Span
+    {
+        hipEvent_t a, b;
+        int kind;
+        long long inst;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    scpp_timing timing{};
+    int last_active = 0;
+};
+
+namespace
+{
+
+template <class T>
+int devAlloc(T **p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)) == hipSuccess ? 0 : -1;
+}
+
+hipEvent_t getEvent(scpp_hip_ctx *c)
+{
+    if (!c->pool.empty())
+    {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;
+    return e;
+}
+void spanBegin(scpp_hip_ctx *c, int kind, long long inst)
+{
+    scpp_hip_ctx::Span s;
+    s.a = getEvent(c);
+    s.b = getEvent(c);
+    s.kind = kind;
+    s.inst = inst;
+    (void)hipEventRecord(s.a, c->stream);
+    c->spans.push_back(s);
+}
+void spanEnd(scpp_hip_ctx *c) { (void)hipEventRecord(c->spans.back().b, c->stream); }
+void collectTiming(scpp_hip_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->spans)
+    {
+        float ms = 0.f;
+        (void)hipEventSynchronize(s.b);
+        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        if (s.kind == 0)
+        {
+            c->timing.ms_discretize += ms;
+            c->timing.n_discretize++;
+            c->timing.inst_discretize += s.inst;
+        }
+        else if (s.kind == 1)
+        {
+            c->timing.ms_socp += ms;
+            c->timing.n_socp++;
+            c->timing.inst_socp += s.inst;
+        }
+        else
+            c->timing.ms_other += ms;
+        c->pool.push_back(s.a);
+        c->pool.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+template <class Model>
+int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
+{
+    const int B = c->B, K = c->K;
+    const long groups = ((long(B) + 7) / 8) * (K - 1);
+    const unsigned grid = unsigned(groups * 8);
+    spanBegin(c, 0, ninst);
+    if (mode == (SCPP_MODE_FOH | SCPP_MODE_VT))
+        hipLaunchKernelGGL((discretize_kernel<Model, true, true>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
+                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+    else if (mode == SCPP_MODE_FOH)
+        hipLaunchKernelGGL((discretize_kernel<Model, true, false>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
+                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+    else if (mode == SCPP_MODE_VT)
+        hipLaunchKernelGGL((discretize_kernel<Model, false, true>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
+                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+    else
+        hipLaunchKernelGGL((discretize_kernel<Model, false, false>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
+                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+    spanEnd(c);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+
+int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
+{
+    if (c->model == SCPP_MODEL_ROCKETQUAT)
+        return launchDiscretize<RocketQuatModel>(c, mode, par, stride, active, ninst);
+    return launchDiscretize<Rocket2dModel>(c, mode, par, stride, active, ninst);
+}
+
+SCBuffers scBuffers(scpp_hip_ctx *c)
+{
+    SCBuffers b;
+    b.B = c->B;
+    b.K = c->K;
+    b.x_init_dim = c->x_init;
+    b.X = c->X;
+    b.U = c->U;
+    b.sigma = c->sigma;
+    b.ip = c->ip;
+    b.uhat = c->uhat;
+    b.wtrx = c->wtrx;
+    b.active = c->active;
+    b.converged = c->converged;
+    b.sc_iters = c->sc_iters;
+    b.ipm_iters = c->ipm_iters;
+    b.status = c->status;
+    b.norm1_nu = c->norm1_nu;
+    b.sum_delta = c->sum_delta;
+    b.delta_sigma = c->delta_sigma;
+    return b;
+}
+
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst)
+{
+    ipm::KernelArgs a;
+    a.B = c->B;
+    a.K = c->K;
+    a.X = c->X;
+    a.U = c->U;
+    a.sigma = c->sigma;
+    a.A = c->A;
+    a.Bm = c->Bm;
+    a.C = c->C;
+    a.S = c->S;
+    a.Z = c->Z;
+    a.ip = c->ip;
+    a.uhat = c->uhat;
+    a.ws = c->ws;
+    a.wtrx = c->wtrx;
+    a.active = do_sc_update ? c->active : nullptr;
+    a.converged = c->converged;
+    a.sc_iters = c->sc_iters;
+    a.ipm_iters = c->ipm_iters;
+    a.status = c->status;
+    a.norm1_nu = c->norm1_nu;
+    a.sum_delta = c->sum_delta;
+    a.delta_sigma = c->delta_sigma;
+    a.nu_tol = c->sc.nu_tol;
+    a.delta_tol = c->sc.delta_tol;
+    a.max_sc_iterations = c->sc.max_iterations;
+    a.do_sc_update = do_sc_update;
+    a.opt.feastol = c->socp.feastol;
+    a.opt.abstol = c->socp.abstol;
+    a.opt.reltol = c->socp.reltol;
+    a.opt.gamma = 0.99;
+    a.opt.maxit = c->socp.maxit;
+    a.opt.use_mfma = c->socp.use_mfma;
+    a.dbg = c->dbg;
+    spanBegin(c, 1, ninst);
+    hipLaunchKernelGGL(ipm::ipm_kernel, dim3(unsigned(c->B)), dim3(WAVE), 0, c->stream, a);
+    spanEnd(c);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+
+int countActive(scpp_hip_ctx *c, int *n)
+{
+    hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, c->stream, c->B, (const int *)c->active, c->counter);
+    CHECK_HIP(hipMemcpyAsync(n, c->counter, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} // namespace
+
+extern "C"
+{
+
+const char *scpp_hip_version(void)
+{
+#ifdef SCPP_HIP_EMU
+    return "scpp_hip 0.1 (CPU emulation build: TEST ONLY)";
+#else
+    return "scpp_hip 0.1 (gfx950)";
+#endif
+}
+
+int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int batch_max, unsigned)
+{
+    if (!out || K < 3 || K > WAVE || batch_max < 1)
+        return SCPP_E_ARG;
+    if (model_id != SCPP_MODEL_ROCKETQUAT && model_id != SCPP_MODEL_ROCKET2D)
+        return SCPP_E_ARG;
+    CHECK_HIP(hipSetDevice(device_id));
+    scpp_hip_ctx *c = new (std::nothrow) scpp_hip_ctx;
+    if (!c)
+        return SCPP_E_HIP;
+    c->device = device_id;
+    c->model = model_id;
+    c->K = K;
+    c->Bmax = batch_max;
+    c->B = 0;
+    if (model_id == SCPP_MODEL_ROCKETQUAT)
+    {
+        c->nx = RocketQuatModel::NX;
+        c->nu = RocketQuatModel::NU;
+        c->np = RocketQuatModel::NP;
+    }
+    else
+    {
+        c->nx = Rocket2dModel::NX;
+        c->nu = Rocket2dModel::NU;
+        c->np = Rocket2dModel::NP;
+    }
+    if (hipStreamCreate(&c->stream) != hipSuccess)
+    {
+        delete c;
+        return SCPP_E_HIP;
+    }
+    const size_t B = size_t(batch_max), nx = c->nx, nu = c->nu;
+    int rc = 0;
+    rc |= devAlloc(&c->X, B * K * nx);
+    rc |= devAlloc(&c->U, B * K * nu);
+    rc |= devAlloc(&c->sigma, B);
+    rc |= devAlloc(&c->par, B * c->np);
+    rc |= devAlloc(&c->A, B * (K - 1) * nx * nx);
+    rc |= devAlloc(&c->Bm, B * (K - 1) * nx * nu);
+    rc |= devAlloc(&c->C, B * (K - 1) * nx * nu);
+    rc |= devAlloc(&c->S, B * (K - 1) * nx);
+    rc |= devAlloc(&c->Z, B * (K - 1) * nx);
+    rc |= devAlloc(&c->sim_dt, B);
+    rc |= devAlloc(&c->sim_u0, B * nu);
+    rc |= devAlloc(&c->sim_u1, B * nu);
+    rc |= devAlloc(&c->sim_x, B * nx);
+    rc |= devAlloc(&c->active, B);
+    rc |= devAlloc(&c->converged, B);
+    rc |= devAlloc(&c->sc_iters, B);
+    rc |= devAlloc(&c->ipm_iters, B);
+    rc |= devAlloc(&c->status, B);
+    rc |= devAlloc(&c->counter, 4);
+    rc |= devAlloc(&c->norm1_nu, B);
+    rc |= devAlloc(&c->sum_delta, B);
+    rc |= devAlloc(&c->delta_sigma, B);
+    if (model_id == SCPP_MODEL_ROCKETQUAT)
+    {
+        rc |= devAlloc(&c->x_init, B * 14);
+        rc |= devAlloc(&c->ip, B * ipm::IP_N);
+        rc |= devAlloc(&c->uhat, B * K * 3);
+        rc |= devAlloc(&c->wtrx, B);
+        rc |= devAlloc(&c->ws, B * ipm::workspaceDoubles(K));
+        rc |= devAlloc(&c->dbg, B * 8);
+    }
+    if (rc)
+    {
+        scpp_hip_destroy(c);
+        return SCPP_E_HIP;
+    }
+    (void)hipMemset(c->active, 0, B * sizeof(int));
+    *out = c;
+    return SCPP_OK;
+}
+
+int scpp_hip_destroy(scpp_hip_ctx *c)
+{
+    if (!c)
+        return SCPP_OK;
+    (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->X, c->U, c->sigma, c->par, c->A, c->Bm, c->C, c->S, c->Z, c->x_init, c->ip, c->uhat, c->wtrx, c->ws,
+                    c->dbg, c->active, c->converged, c->sc_iters, c->ipm_iters, c->status, c->counter, c->norm1_nu,
+                    c->sum_delta, c->delta_sigma, c->sim_dt, c->sim_u0, c->sim_u1, c->sim_x};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    for (auto &s : c->spans)
+    {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : c->pool)
+        (void)hipEventDestroy(e);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SCPP_OK;
+}
+
+int scpp_hip_set_flow_params(scpp_hip_ctx *c, const double *par, int B)
+{
+    if (!c || !par || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    CHECK_HIP(hipMemcpyAsync(c->par, par, size_t(B) * c->np * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->par_from_ip = false;
+    return SCPP_OK;
+}
+
+int scpp_hip_upload_traj(scpp_hip_ctx *c, const double *X, const double *U, const double *sigma, int B)
+{
+    if (!c || !X || !U || !sigma || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    c->B = B;
+    CHECK_HIP(hipMemcpyAsync(c->X, X, size_t(B) * c->K * c->nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->U, U, size_t(B) * c->K * c->nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->sigma, sigma, size_t(B) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return SCPP_OK;
+}
+
+int scpp_hip_discretize(scpp_hip_ctx *c, int mode)
+{
+    if (!c || c->B < 1 || mode < 0 || mode > 3)
+        return SCPP_E_ARG;
+    if (!(mode & SCPP_MODE_FOH))
+        return SCPP_E_UNSUPPORTED; /* U is stored [B][K][nu]; zero-order hold needs K-1 inputs: not wired yet */
+    const double *par = c->par_from_ip ? c->ip + ipm::IP_PAR : c->par;
+    const int stride = c->par_from_ip ? ipm::IP_N : c->np;
+    int rc = discretizeDispatch(c, mode, par, stride, nullptr, c->B);
+    if (rc)
+        return rc;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    return SCPP_OK;
+}
+
+int scpp_hip_download_dd(scpp_hip_ctx *c, double *A, double *B, double *C, double *S, double *Z)
+{
+    if (!c || c->B < 1)
+        return SCPP_E_ARG;
+    const size_t n = size_t(c->B) * (c->K - 1), nx = c->nx, nu = c->nu;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (A)
+        CHECK_HIP(hipMemcpy(A, c->A, n * nx * nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (B)
+        CHECK_HIP(hipMemcpy(B, c->Bm, n * nx * nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (C)
+        CHECK_HIP(hipMemcpy(C, c->C, n * nx * nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (S)
+        CHECK_HIP(hipMemcpy(S, c->S, n * nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (Z)
+        CHECK_HIP(hipMemcpy(Z, c->Z, n * nx * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
+int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const double *u1, double *x, int B)
+{
+    if (!c || !dt || !u0 || !u1 || !x || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    CHECK_HIP(hipMemcpyAsync(c->sim_dt, dt, size_t(B) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->sim_u0, u0, size_t(B) * c->nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->sim_u1, u1, size_t(B) * c->nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->sim_x, x, size_t(B) * c->nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const double *par = c->par_from_ip ? c->ip + ipm::IP_PAR : c->par;
+    const int stride = c->par_from_ip ? ipm::IP_N : c->np;
+    const unsigned grid = unsigned((B + 63) / 64);
+    if (c->model == SCPP_MODEL_ROCKETQUAT)
+        hipLaunchKernelGGL((simulate_kernel<RocketQuatModel>), dim3(grid), dim3(64), 0, c->stream, B, par, stride,
+                           (const double *)c->sim_dt, (const double *)c->sim_u0, (const double *)c->sim_u1, c->sim_x,
+                           (const int *)nullptr);
+    else
+        hipLaunchKernelGGL((simulate_kernel<Rocket2dModel>), dim3(grid), dim3(64), 0, c->stream, B, par, stride,
+                           (const double *)c->sim_dt, (const double *)c->sim_u0, (const double *)c->sim_u1, c->sim_x,
+                           (const int *)nullptr);
+    CHECK_HIP(hipMemcpyAsync(x, c->sim_x, size_t(B) * c->nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    return SCPP_OK;
+}
+
+int scpp_hip_set_socp_opts(scpp_hip_ctx *c, const scpp_socp_opts *o)
+{
+    if (!c || !o)
+        return SCPP_E_ARG;
+    c->socp = *o;
+    return SCPP_OK;
+}
+
+int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_sc_opts *so, const double *x_init,
+                      int B, int warm_start)
+{
+    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKETQUAT)
+        return SCPP_E_UNSUPPORTED;
+    /* the device solver implements the configuration SC_oneshot/SC_sim run for RocketQuat */
+    if (so->K != c->K || !so->free_final_time || !so->interpolate_input || mp->enable_roll_control)
+        return SCPP_E_UNSUPPORTED;
+    if (warm_start && (!c->sc_ready || B != c->B))
+        return SCPP_E_STATE;
+    c->B = B;
+    c->mp = *mp;
+    c->sc = *so;
+    c->mode = SCPP_MODE_FOH | SCPP_MODE_VT;
+    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SCBuffers b = scBuffers(c);
+    hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
+    c->sc_ready = true;
+    c->par_from_ip = true;
+    c->last_active = B;
+    return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
+}
+
+int scpp_hip_sc_iterate(scpp_hip_ctx *c, int *n_active)
+{
+    if (!c || !c->sc_ready)
+        return SCPP_E_STATE;
+    int rc = discretizeDispatch(c, c->mode, c->ip + ipm::IP_PAR, ipm::IP_N, c->active, c->last_active);
+    if (rc)
+        return rc;
+    rc = launchIpm(c, 1, c->last_active);
+    if (rc)
+        return rc;
+    int n = 0;
+    rc = countActive(c, &n);
+    if (rc)
+        return rc;
+    c->last_active = n;
+    if (n_active)
+        *n_active = n;
+    return SCPP_OK;
+}
+
+int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
+{
+    if (!c || !c->sc_ready)
+        return SCPP_E_STATE;
+    int n_active = c->B;
+    for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
+    {
+        int rc = scpp_hip_sc_iterate(c, &n_active);
+        if (rc)
+            return rc;
+    }
+    if (c->sc.nondimensionalize)
+    {
+        SCBuffers b = scBuffers(c);
+        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
+    }
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (n_converged)
+    {
+        std::vector<int> conv(c->B);
+        CHECK_HIP(hipMemcpy(conv.data(), c->converged, size_t(c->B) * sizeof(int), hipMemcpyDeviceToHost));
+        int n = 0;
+        for (int v : conv)
+            n += v;
+        *n_converged = n;
+    }
+    return SCPP_OK;
+}
+
+int scpp_hip_socp_solve(scpp_hip_ctx *c)
+{
+    if (!c || !c->sc_ready)
+        return SCPP_E_STATE;
+    int rc = launchIpm(c, 0, c->B);
+    if (rc)
+        return rc;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    return SCPP_OK;
+}
+
+int scpp_hip_download(scpp_hip_ctx *c, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
+                      int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta)
+{
+    if (!c || c->B < 1)
+        return SCPP_E_ARG;
+    const size_t B = size_t(c->B);
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (X)
+        CHECK_HIP(hipMemcpy(X, c->X, B * c->K * c->nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (U)
+        CHECK_HIP(hipMemcpy(U, c->U, B * c->K * c->nu * sizeof(double), hipMemcpyDeviceToHost));
+    if (sigma)
+        CHECK_HIP(hipMemcpy(sigma, c->sigma, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (sc_iters)
+        CHECK_HIP(hipMemcpy(sc_iters, c->sc_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (nu_norm)
+        CHECK_HIP(hipMemcpy(nu_norm, c->norm1_nu, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (converged)
+        CHECK_HIP(hipMemcpy(converged, c->converged, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (status)
+        CHECK_HIP(hipMemcpy(status, c->status, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (ipm_iters)
+        CHECK_HIP(hipMemcpy(ipm_iters, c->ipm_iters, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (sum_delta)
+        CHECK_HIP(hipMemcpy(sum_delta, c->sum_delta, B * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
+int scpp_hip_download_socp_info(scpp_hip_ctx *c, double *info)
+{
+    if (!c || !info || !c->dbg || c->B < 1)
+        return SCPP_E_ARG;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    CHECK_HIP(hipMemcpy(info, c->dbg, size_t(c->B) * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
+int scpp_hip_get_timing(scpp_hip_ctx *c, scpp_timing *out, int reset)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    collectTiming(c);
+    if (out)
+        *out = c->timing;
+    if (reset)
+        c->timing = scpp_timing{};
+    return SCPP_OK;
+}
+
+int scpp_hip_device_ptrs(scpp_hip_ctx *c, void **X, void **U, void **sigma)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    if (X)
+        *X = c->X;
+    if (U)
+        *U = c->U;
+    if (sigma)
+        *sigma = c->sigma;
+    return SCPP_OK;
+}
+
+int scpp_hip_synchronize(scpp_hip_ctx *c)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    return SCPP_OK;
+}
+
+} // extern "C"

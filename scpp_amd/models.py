@@ -1,0 +1,109 @@
+"""Host-side mirror of the RocketQuat model plugin's configuration half
+(scpp_models/src/rocketQuat.cpp:203-289, scpp_models/include/common.hpp:30-38).  The flow map itself is
+device code (scpp_amd/csrc/model_rocketquat.h)."""
+import math
+import os
+
+import numpy as np
+
+from ._lib import RocketQuatParams
+from .parameter_server import ParameterServer
+
+CONFIG_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
+
+_MASK = (1 << 64) - 1
+
+
+def counter_uniform(seed, instance, draw):
+    """Counter-based uniform in [-1,1): SplitMix64 keyed by (seed, instance, draw)."""
+    z = (seed + (instance * 8 + draw + 1) * 0x9E3779B97F4A7C15) & _MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    z = z ^ (z >> 31)
+    return 2.0 * ((z >> 11) * (1.0 / 9007199254740992.0)) - 1.0
+
+
+def euler_to_quaternion_xyz(eta):
+    """q = Rx(phi) Ry(theta) Rz(psi) as (w,x,y,z)  (common.hpp:30-38)."""
+    cx, sx = math.cos(0.5 * eta[0]), math.sin(0.5 * eta[0])
+    cy, sy = math.cos(0.5 * eta[1]), math.sin(0.5 * eta[1])
+    cz, sz = math.cos(0.5 * eta[2]), math.sin(0.5 * eta[2])
+    aw, ax, ay, az = cx * cy, sx * cy, cx * sy, sx * sy
+    return [aw * cz - az * sz, ax * cz + ay * sz, ay * cz - ax * sz, aw * sz + az * cz]
+
+
+class RocketQuat:
+    modelName = "RocketQuat"
+    state_dim, input_dim, param_dim = 14, 4, 10
+
+    def __init__(self, param_folder=CONFIG_ROOT):
+        self.param_folder = param_folder
+        self.p = None
+        self.x_init = None
+        self.rpy_init = None
+
+    def getParameterFolder(self):
+        return os.path.join(self.param_folder, self.modelName)
+
+    def loadParameters(self):
+        """rocketQuat.cpp:229-289"""
+        ps = ParameterServer(os.path.join(self.getParameterFolder(), "model.info"))
+        d2r = math.pi / 180.0
+        p = RocketQuatParams()
+        g_I = ps.load_vector("g_I", 3)
+        p.g_I[:] = g_I
+        p.J_B[:] = ps.load_vector("J_B", 3)
+        p.r_T_B[:] = ps.load_vector("r_T_B", 3)
+        m_init = ps.load_scalar("m_init")
+        r_init = ps.load_vector("r_init", 3)
+        v_init = ps.load_vector("v_init", 3)
+        rpy_init = [a * d2r for a in ps.load_vector("rpy_init", 3)]
+        w_init = [a * d2r for a in ps.load_vector("w_init", 3)]
+        w_final = [a * d2r for a in ps.load_vector("w_final", 3)]
+        m_dry = ps.load_scalar("m_dry")
+        r_final = ps.load_vector("r_final", 3)
+        v_final = ps.load_vector("v_final", 3)
+        rpy_final = [a * d2r for a in ps.load_vector("rpy_final", 3)]
+        p.T_min = ps.load_scalar("T_min")
+        p.T_max = ps.load_scalar("T_max")
+        p.t_max = ps.load_scalar("t_max")
+        I_sp = ps.load_scalar("I_sp")
+        p.gimbal_max = ps.load_scalar("gimbal_max") * d2r
+        p.theta_max = ps.load_scalar("theta_max") * d2r
+        p.gamma_gs = ps.load_scalar("gamma_gs") * d2r
+        p.w_B_max = ps.load_scalar("w_B_max") * d2r
+        self.random_initial_state = ps.load_scalar("random_initial_state", bool)
+        p.final_time = ps.load_scalar("final_time")
+        p.exact_minimum_thrust = int(ps.load_scalar("exact_minimum_thrust", bool))
+        p.enable_roll_control = int(ps.load_scalar("enable_roll_control", bool))
+        p.alpha_m = 1.0 / (I_sp * abs(g_I[2]))
+        q_init = euler_to_quaternion_xyz(rpy_init)
+        q_final = euler_to_quaternion_xyz(rpy_final)
+        self.x_init = np.array([m_init] + r_init + v_init + q_init + w_init, dtype=np.float64)
+        p.x_final[:] = [m_dry] + r_final + v_final + q_final + w_final
+        self.rpy_init = rpy_init
+        self.p = p
+        return self
+
+    def randomized_initial_states(self, batch, seed=20260927, first=0):
+        """The reference's (commented-out) randomizeInitialState recipe (rocketQuat.cpp:203-227), made
+        deterministic and batched per SURVEY.md §8(d): 7 counter-based uniforms per instance."""
+        X = np.tile(self.x_init, (batch, 1))
+        for b in range(batch):
+            i = first + b
+            X[b, 1] *= counter_uniform(seed, i, 0)
+            X[b, 2] *= counter_uniform(seed, i, 1)
+            X[b, 4] *= counter_uniform(seed, i, 2)
+            X[b, 5] *= counter_uniform(seed, i, 3)
+            X[b, 6] *= 1.0 + 0.2 * counter_uniform(seed, i, 4)
+            euler = [counter_uniform(seed, i, 5) * self.rpy_init[0], counter_uniform(seed, i, 6) * self.rpy_init[1], self.rpy_init[2]]
+            X[b, 7:11] = euler_to_quaternion_xyz(euler)
+        return X
+
+    def flow_params(self, x_init=None, nondimensionalize=True):
+        """getNewModelParameters (rocketQuat.cpp:168-173) after Parameters::nondimensionalize (:291-312)."""
+        x = self.x_init if x_init is None else np.asarray(x_init)
+        m_s = x[0] if nondimensionalize else 1.0
+        r_s = float(np.linalg.norm(x[1:4])) if nondimensionalize else 1.0
+        p = self.p
+        return np.array([p.alpha_m * r_s] + [g / r_s for g in p.g_I] + [j / (m_s * r_s * r_s) for j in p.J_B] + [r / r_s for r in p.r_T_B])

@@ -1,0 +1,328 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product build.
+//
+// Minimal CPU emulation of the HIP constructs the kernels in scpp_amd/csrc use, so that the SAME
+// kernel sources can be compiled with g++ and executed lane-accurately in this GPU-less dev
+// container (and under pytest -m "not gpu") to debug kernel logic before spending GPU minutes:
+//   * each workgroup runs as `blockDim.x` cooperative fibers (hand-rolled x86-64 context switch);
+//   * __syncthreads() = round-robin yield; blocks execute sequentially;
+//   * wave shuffles / ballot-free reductions and the f64 MFMA builtin are emulated through an
+//     exchange buffer with the gfx950 lane->element maps of cdna_hip_programming.md §3;
+//   * a tiny hipMalloc/hipMemcpy/hipStream/hipEvent shim lets the C-ABI layer run unchanged.
+// The product library (libscpp_hip.so) is built by hipcc from the same sources WITHOUT this header.
+#pragma once
+#ifndef SCPP_HIP_EMU
+#error "hip_emu.h is only for the emulation build (-DSCPP_HIP_EMU)"
+#endif
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3
+{
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hipemu
+{
+struct Fiber
+{
+    void *sp = nullptr;
+    void *stack = nullptr;
+    bool done = false;
+    dim3 tid;
+};
+struct State
+{
+    std::vector<Fiber> fibers;
+    void *main_sp = nullptr;
+    int cur = -1;
+    dim3 bid, bdim, gdim;
+    std::function<void()> body;
+    double xchg[1024][4];
+    long xchg_i[1024];
+};
+inline State &st()
+{
+    static State s;
+    return s;
+}
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+__asm__(".text\n"
+        ".globl hipemu_switch\n"
+        ".type hipemu_switch,@function\n"
+        "hipemu_switch:\n"
+        "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+        "  movq %rsp, (%rdi)\n"
+        "  movq %rsi, %rsp\n"
+        "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+        "  ret\n"
+        ".size hipemu_switch,.-hipemu_switch\n");
+
+inline void yield_to_main()
+{
+    State &s = st();
+    Fiber &f = s.fibers[s.cur];
+    hipemu_switch(&f.sp, s.main_sp);
+}
+inline void fiber_entry()
+{
+    State &s = st();
+    s.body();
+    s.fibers[s.cur].done = true;
+    for (;;)
+        yield_to_main();
+}
+constexpr size_t STACK_BYTES = 512 * 1024;
+inline void run_block(unsigned nthreads)
+{
+    State &s = st();
+    if (s.fibers.size() < nthreads)
+    {
+        size_t old = s.fibers.size();
+        s.fibers.resize(nthreads);
+        for (size_t i = old; i < nthreads; i++)
+            s.fibers[i].stack = std::aligned_alloc(64, STACK_BYTES);
+    }
+    for (unsigned i = 0; i < nthreads; i++)
+    {
+        Fiber &f = s.fibers[i];
+        f.done = false;
+        f.tid = dim3(i, 0, 0);
+        uintptr_t top = (uintptr_t(f.stack) + STACK_BYTES) & ~uintptr_t(15);
+        void **p = reinterpret_cast<void **>(top);
+        *--p = nullptr;                                     // fake return address of fiber_entry
+        *--p = reinterpret_cast<void *>(&fiber_entry);      // popped by `ret`
+        for (int r = 0; r < 6; r++)
+            *--p = nullptr;                                 // r15..rbp
+        f.sp = p;
+    }
+    for (;;)
+    {
+        bool any = false;
+        for (unsigned i = 0; i < nthreads; i++)
+        {
+            if (s.fibers[i].done)
+                continue;
+            any = true;
+            s.cur = int(i);
+            hipemu_switch(&s.main_sp, s.fibers[i].sp);
+        }
+        if (!any)
+            break;
+    }
+    s.cur = -1;
+}
+template <class K, class... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args)
+{
+    State &s = st();
+    s.gdim = grid;
+    s.bdim = block;
+    for (unsigned b = 0; b < grid.x; b++)
+    {
+        s.bid = dim3(b, 0, 0);
+        s.body = [=]() { kernel(args...); };
+        run_block(block.x);
+    }
+}
+struct TidProxy
+{
+    operator dim3() const { return st().fibers[st().cur].tid; }
+    unsigned get_x() const { return st().fibers[st().cur].tid.x; }
+};
+} // namespace hipemu
+
+struct hipemu_tid_t
+{
+    struct X
+    {
+        operator unsigned() const { return hipemu::st().fibers[hipemu::st().cur].tid.x; }
+    } x;
+};
+struct hipemu_bid_t
+{
+    struct X
+    {
+        operator unsigned() const { return hipemu::st().bid.x; }
+    } x;
+};
+struct hipemu_bdim_t
+{
+    struct X
+    {
+        operator unsigned() const { return hipemu::st().bdim.x; }
+    } x;
+};
+struct hipemu_gdim_t
+{
+    struct X
+    {
+        operator unsigned() const { return hipemu::st().gdim.x; }
+    } x;
+};
+static hipemu_tid_t threadIdx;
+static hipemu_bid_t blockIdx;
+static hipemu_bdim_t blockDim;
+static hipemu_gdim_t gridDim;
+
+inline void __syncthreads() { hipemu::yield_to_main(); }
+
+// ---- wave-level exchange (64-lane waves) ----
+inline double __shfl(double v, int srcLane)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x;
+    s.xchg[t][0] = v;
+    __syncthreads();
+    const double r = s.xchg[(t & ~63u) | (unsigned(srcLane) & 63u)][0];
+    __syncthreads();
+    return r;
+}
+inline double __shfl_xor(double v, int mask)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x;
+    s.xchg[t][0] = v;
+    __syncthreads();
+    const double r = s.xchg[t ^ (unsigned(mask) & 63u)][0];
+    __syncthreads();
+    return r;
+}
+inline int __shfl_xor(int v, int mask)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x;
+    s.xchg_i[t] = v;
+    __syncthreads();
+    const int r = int(s.xchg_i[t ^ (unsigned(mask) & 63u)]);
+    __syncthreads();
+    return r;
+}
+inline int __shfl(int v, int srcLane)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x;
+    s.xchg_i[t] = v;
+    __syncthreads();
+    const int r = int(s.xchg_i[(t & ~63u) | (unsigned(srcLane) & 63u)]);
+    __syncthreads();
+    return r;
+}
+
+typedef double d4_t __attribute__((vector_size(32)));
+// v_mfma_f64_16x16x4_f64:  D(16x16) = A(16x4) B(4x16) + C
+//   A operand lane l: A[i = l&15][k = l>>4] ; B operand lane l: B[k = l>>4][j = l&15]
+//   C/D lane l, reg r: row = (l>>4) + 4r, col = l&15        (cdna_hip_programming.md §3)
+inline d4_t __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, d4_t c, int, int, int)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    s.xchg[t][0] = a;
+    s.xchg[t][1] = b;
+    __syncthreads();
+    d4_t d = c;
+    const unsigned col = l & 15u;
+    for (int r = 0; r < 4; r++)
+    {
+        const unsigned row = (l >> 4) + 4u * unsigned(r);
+        double acc = d[r];
+        for (unsigned k = 0; k < 4; k++)
+            acc += s.xchg[base + k * 16u + row][0] * s.xchg[base + k * 16u + col][1];
+        d[r] = acc;
+    }
+    __syncthreads();
+    return d;
+}
+
+// ---- host runtime shim ----
+typedef int hipError_t;
+typedef void *hipStream_t;
+struct hipemu_event
+{
+    std::chrono::steady_clock::time_point t;
+};
+typedef hipemu_event *hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyDefault 4
+inline hipError_t hipMalloc(void **p, size_t n)
+{
+    *p = std::malloc(n ? n : 1);
+    return *p ? 0 : 2;
+}
+template <class T>
+hipError_t hipMalloc(T **p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void **>(p), n);
+}
+inline hipError_t hipFree(void *p)
+{
+    std::free(p);
+    return 0;
+}
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int)
+{
+    std::memcpy(d, s, n);
+    return 0;
+}
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { return hipMemcpy(d, s, n, 0); }
+inline hipError_t hipMemset(void *d, int v, size_t n)
+{
+    std::memset(d, v, n);
+    return 0;
+}
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+inline hipError_t hipStreamCreate(hipStream_t *s)
+{
+    *s = nullptr;
+    return 0;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDeviceCount(int *n)
+{
+    *n = 1;
+    return 0;
+}
+inline hipError_t hipGetLastError() { return 0; }
+inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipEventCreate(hipEvent_t *e)
+{
+    *e = new hipemu_event;
+    return 0;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e)
+{
+    delete e;
+    return 0;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t)
+{
+    e->t = std::chrono::steady_clock::now();
+    return 0;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return 0;
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
