@@ -356,6 +356,14 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
 
     // ---- stage setup: trust-region centre, fixed values, zero start ----
     int Dcount = 0;
+    // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
+    // never written afterwards but are swept by the vector updates)
+    if (vst)
+        for (int i = 0; i < STREC; i++)
+            st[i] = 0.;
+    if (vsg)
+        for (int i = 0; i < SEGREC; i++)
+            sg[i] = 0.;
     if (vst)
     {
         const double *Xb = a.X + (size_t(inst) * K + k) * NX, *Ub = a.U + (size_t(inst) * K + k) * NU;

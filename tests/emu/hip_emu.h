@@ -264,6 +264,8 @@ typedef hipemu_event *hipEvent_t;
 inline hipError_t hipMalloc(void **p, size_t n)
 {
     *p = std::malloc(n ? n : 1);
+    if (*p)
+        std::memset(*p, 0xFF, n); // poison: any read-before-write of device memory shows up as NaN
     return *p ? 0 : 2;
 }
 template <class T>

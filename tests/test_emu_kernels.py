@@ -1,0 +1,70 @@
+"""The HIP kernel SOURCES, compiled for the CPU wave emulator (tests/emu/hip_emu.h), against the oracle.
+This is how kernel logic is debugged in the GPU-less dev container; the same checks run on the real GPU in
+test_gpu_parity.py.  (The emulation build is test infrastructure and is never loaded by the product.)"""
+import numpy as np
+import pytest
+
+import scpp_amd
+
+
+def _setup(model, emu_lib, K, B):
+    alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, library=emu_lib).initialize()
+    x0 = model.randomized_initial_states(B)
+    return alg, x0
+
+
+def test_emu_discretize_matches_oracle(oracle, model, emu_lib):
+    K, B = 8, 3
+    alg, x0 = _setup(model, emu_lib, K, B)
+    alg.ctx.sc_setup(model.p, alg.opts, x0)
+    alg.ctx.discretize()
+    A, Bm, C, S, Z = alg.ctx.download_dd()
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.randomize(20260927, b); sc.set_solver(1); sc.solve()
+        X, U, t = sc.iterate(0)
+        ref = oracle.discretize(0, model.flow_params(x0[b]), X, U, t)
+        for a, o in zip((A[b], Bm[b], C[b], S[b], Z[b]), ref):
+            assert np.abs(a - o).max() <= 1e-11 * max(1.0, np.abs(o).max())
+
+
+@pytest.mark.parametrize("use_mfma", [0, 1])
+def test_emu_socp_matches_structured_twin(oracle, model, emu_lib, use_mfma):
+    K, B = 8, 2
+    alg, x0 = _setup(model, emu_lib, K, B)
+    alg.ctx.set_socp_opts(use_mfma=use_mfma)
+    alg.ctx.sc_setup(model.p, alg.opts, x0)
+    alg.ctx.sc_iterate()
+    out = alg.ctx.download()
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.randomize(20260927, b); sc.set_solver(1); sc.solve()
+        X1, U1, t1 = sc.iterate(1)
+        inf = sc.info()[0]
+        assert out["ipm_iters"][b] == int(inf[4])
+        assert abs(out["nu_norm"][b] - inf[0]) < 1e-9
+        assert np.abs(out["X"][b] - X1).max() < 1e-9 and np.abs(out["U"][b] - U1).max() < 1e-9
+        assert abs(out["sigma"][b] - t1) < 1e-9
+
+
+def test_emu_full_sc_solve_matches_oracle(oracle, model, emu_lib):
+    K, B = 8, 2
+    alg, x0 = _setup(model, emu_lib, K, B)
+    alg.solve(x0)
+    out = alg.getSolution()
+    ref = oracle.sc_batch(K, 20260927, 0, B, nthreads=2, solver=1)
+    assert (out["sc_iters"] == ref["iters"]).all() and (out["converged"] == ref["converged"]).all()
+    sx = np.abs(ref["X"]).max(axis=1, keepdims=True); su = np.abs(ref["U"]).max(axis=1, keepdims=True)
+    assert (np.abs(out["X"] - ref["X"]) / np.maximum(sx, 1e-9)).max() < 1e-7
+    assert (np.abs(out["U"] - ref["U"]) / np.maximum(su, 1e-9)).max() < 1e-7
+    assert np.abs(out["sigma"] - ref["t"]).max() < 1e-8
+
+
+def test_emu_simulate_matches_oracle(oracle, model, emu_lib):
+    ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, 8, 4, library=emu_lib)
+    par = model.flow_params()
+    ctx.set_flow_params(np.tile(par, (4, 1)))
+    rng = np.random.default_rng(3)
+    x = np.tile([1.0, 0.2, 0.2, 0.9, -0.05, -0.05, -0.09, 0.97, -0.17, 0.17, -0.03, 0.01, -0.02, 0.0], (4, 1)) + 0.01 * rng.normal(size=(4, 14))
+    u0 = np.tile([0.001, -0.002, 0.015, 0.0], (4, 1)); u1 = np.tile([0.0, 0.001, 0.018, 0.0], (4, 1))
+    out = ctx.simulate(0.05, u0, u1, x)
+    for b in range(4):
+        assert np.abs(out[b] - oracle.simulate(0, par, 0.05, u0[b], u1[b], x[b])).max() < 1e-14

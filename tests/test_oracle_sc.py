@@ -1,0 +1,48 @@
+"""End-to-end oracle SC runs (G5: self-generated regression baseline) + reference-semantics checks."""
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def test_rocket2d_sc_oneshot_converges(oracle):
+    """BASELINE configs[0]: Rocket2D SC_oneshot, K=30, single trajectory on the CPU path."""
+    rec = json.load(open(os.path.join(GOLDEN, "sc_regression.json")))["rocket2d_K30_literal"]
+    sc = oracle.SC(oracle.ROCKET2D)
+    assert sc.solve() == 0
+    m = sc.meta()
+    assert m["K"] == 30 and m["converged"] == 1 and m["iterations"] == rec["iterations"]
+    X, U, t = sc.solution()
+    assert abs(t - rec["sigma"]) < 1e-5 * t
+    xf = sc.x_final()
+    assert np.abs(X[-1] - xf).max() < 1e-6 * 800  # final state reached
+    inf = sc.info()
+    assert inf[-1, 0] < 1e-5 and inf[-1, 1] < 1e-3  # nu_tol, delta_tol (SC.info)
+
+
+def test_rocketquat_regression_and_initial_guess_quirks(oracle):
+    rec = json.load(open(os.path.join(GOLDEN, "sc_regression.json")))["rocketquat_K50_structured"]
+    sc = oracle.SC(oracle.ROCKETQUAT, K=50)
+    sc.set_solver(1)
+    assert sc.solve() == 0
+    inf = sc.info()
+    assert sc.meta()["iterations"] == rec["iterations"]
+    assert np.allclose(inf[:, 0], rec["norm1_nu"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(inf[:, 3], rec["sigma"], rtol=1e-7)
+    # initial guess quirks (SURVEY F9 b,c): k/K interpolation -> last node != x_final; thrust (Tmax - Tmin)/2
+    X0, U0, t0 = sc.iterate(0)
+    s = sc.scales()
+    assert t0 == 12.0
+    assert abs(X0[-1, 3] * s[1] - 800.0 / 50) < 1e-9       # r_z at the last node = x_init/K, not 0
+    assert np.allclose(U0[:, 2] * s[0] * s[1], (420000.0 - 200000.0) / 2)
+
+
+def test_weight_doubling_rule(oracle):
+    """weight_trust_region_trajectory doubles exactly when norm1_nu < nu_tol (SCAlgorithm.cpp:112-115)."""
+    sc = oracle.SC(oracle.ROCKET2D)
+    sc.solve()
+    inf = sc.info()
+    n_double = int((inf[:, 0] < 1e-5).sum())
+    assert abs(sc.scales()[2] - 1.0 * 2.0 ** n_double) < 1e-12
