@@ -106,7 +106,7 @@ extern "C"
     /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                           int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);
-    int scpp_hip_download_socp_info(scpp_hip_ctx *ctx, double *info /* [B][8]: pcost,gap,pres,dres,iters,status,norm1_nu,sum_delta */);
+    int scpp_hip_download_socp_info(scpp_hip_ctx *ctx, double *info /* [B][32]: pcost,gap,pres,dres,iters,status,norm1_nu,sum_delta, then 24 profiling slots */);
 
     /* ---- plumbing ---- */
     int scpp_hip_get_timing(scpp_hip_ctx *ctx, scpp_timing *out, int reset);

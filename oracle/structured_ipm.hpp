@@ -175,30 +175,51 @@ inline double stepInv(int d, const double *lam, const double *v)
     return std::sqrt(r1) - rho0;
 }
 
-// dense Cholesky helpers (n<=16), row-major lower
-inline bool chol(int n, double *Aa, int ld)
+// Inverse Cholesky factor of an SPD n x n matrix by Gaussian elimination on the augmented array [A | I]
+// (no pivoting): A = Lt D Lt', the right half becomes Lt^-1 (unit lower), and Li = D^-1/2 Lt^-1 = L^-1 with
+// A = L L'.  Every elimination step is a rank-1 update of BOTH halves, so the HIP tile engine runs it with all
+// 64 lanes busy; forward error ~ sqrt(cond(A)) eps (triangular factor), unlike an explicit A^-1.
+// Pivot floor 1e-14 * original diagonal (multiplier block of segment 0 is tiny-diagonal + rank 3 near convergence).
+// Li: row-major n x n (ld), lower triangular.  Returns false on non-finite input.
+inline bool invCholFactor(int n, const double *Ain, int ld, double *Li)
 {
+    double A[16 * 16], R[16 * 16], orig[16];
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < n; c++)
+        {
+            A[r * 16 + c] = Ain[r * ld + c];
+            R[r * 16 + c] = (r == c) ? 1. : 0.;
+        }
     for (int j = 0; j < n; j++)
     {
-        const double orig = Aa[j * ld + j];
-        double d = orig;
-        for (int q = 0; q < j; q++)
-            d -= Aa[j * ld + q] * Aa[j * ld + q];
-        if (!std::isfinite(d) || !(orig > 0.))
+        orig[j] = A[j * 16 + j];
+        if (!(orig[j] > 0.) || !std::isfinite(orig[j]))
             return false;
-        // relative pivot floor: the multiplier block of segment 0 is (tiny diagonal + rank-3) near
-        // convergence; round-off must not turn a pivot negative
-        if (!(d > 1e-14 * orig))
-            d = 1e-14 * orig;
-        d = std::sqrt(d);
-        Aa[j * ld + j] = d;
-        for (int i = j + 1; i < n; i++)
+    }
+    double piv[16];
+    for (int j = 0; j < n; j++)
+    {
+        double d = A[j * 16 + j];
+        if (!std::isfinite(d))
+            return false;
+        if (!(d > 1e-14 * orig[j]))
+            d = 1e-14 * orig[j];
+        piv[j] = d;
+        const double p = 1. / d;
+        for (int r = j + 1; r < n; r++)
         {
-            double v = Aa[i * ld + j];
-            for (int q = 0; q < j; q++)
-                v -= Aa[i * ld + q] * Aa[j * ld + q];
-            Aa[i * ld + j] = v / d;
+            const double m = A[r * 16 + j] * p; // multiplier (column j of A == row j by symmetry of the trailing part)
+            for (int c = j + 1; c < n; c++)
+                A[r * 16 + c] -= m * A[j * 16 + c];
+            for (int c = 0; c <= j; c++)
+                R[r * 16 + c] -= m * R[j * 16 + c];
         }
+    }
+    for (int r = 0; r < n; r++)
+    {
+        const double sc = 1. / std::sqrt(piv[r]);
+        for (int c = 0; c < n; c++)
+            Li[r * ld + c] = (c <= r) ? R[r * 16 + c] * sc : 0.;
     }
     return true;
 }
@@ -265,7 +286,7 @@ class RQStructuredSocp
     std::vector<double> dw, ddl, dnu, dnub, dlam, ds, dz, ds1, dz1, ds2, dz2;
     double dsig = 0, ddsg = 0, dn1 = 0, dss = 0, dzs = 0, ds3 = 0, dz3 = 0, dsc3[3], dzc3[3];
     // factor storage
-    std::vector<double> Lf, Yf, Tf, Zf; // [K][16*16] each (row-major), Y/Z are 14x16, T 14x14
+    std::vector<double> Lif, Ytf, Tif, Zf; // [K][256]: Li = chol(Phi)^-1 (16x16), Yt = Li M' (16x14, ld 16), Ti = chol(Theta)^-1 (14x14, ld 14), Z = Ti N (14x16)
     std::vector<double> Einv;            // [K-1][14]
     std::vector<double> qv;              // [K-1][14]  (d2-d1)/(d1+d2)
     std::vector<double> hdd, hdw;        // [K], [K][16]: delta_k elimination
@@ -298,8 +319,8 @@ class RQStructuredSocp
         ds = s;
         dz = z;
         ds1 = dz1 = ds2 = dz2 = s1;
-        Lf.assign(size_t(K) * 256, 0.);
-        Yf = Tf = Zf = Lf;
+        Lif.assign(size_t(K) * 256, 0.);
+        Ytf = Tif = Zf = Lif;
         Einv.assign(size_t(K - 1) * NL, 0.);
         qv = Einv;
         hdd.assign(K, 0.);
@@ -670,6 +691,10 @@ class RQStructuredSocp
             Hdd = Hdd_;
             hsig = Hss - Hsd * Hsd / Hdd;
         }
+        // block-tridiagonal elimination; every stage operation is an X'Y product of 16x16 tiles (what the FP64
+        // matrix cores of the GPU twin execute) except the two inverse-Cholesky factors:
+        //   Phi_k = H_k + Z_{k-1}'Z_{k-1},  Li_k = chol(Phi_k)^-1,  Yt_k = Li_k M_k'   (= Y_k', Y_k = M_k L_k^-T)
+        //   Theta_k = E_k^-1 + Yt_k'Yt_k,   Ti_k = chol(Theta_k)^-1, Z_k = Ti_k N_k
         double Phi[256], M[NL * NV], N[NL * NV], Th[256];
         for (int k = 0; k < K; k++)
         {
@@ -686,51 +711,51 @@ class RQStructuredSocp
                         Phi[i * NV + j] += acc;
                     }
             }
-            if (!chol(NV, Phi, NV))
+            double *Li = &Lif[size_t(k) * 256];
+            if (!invCholFactor(NV, Phi, NV, Li))
             {
                 last_fail = 100 + k;
                 return false;
             }
-            double *Lk = &Lf[size_t(k) * 256];
-            std::memcpy(Lk, Phi, sizeof(double) * 256);
             if (k == K - 1)
                 break;
             buildM(k, M);
-            // Y = M L^-T : solve Y L' = M  row by row (forward substitution over columns)
-            double *Y = &Yf[size_t(k) * 256];
-            for (int r = 0; r < NL; r++)
-                for (int j = 0; j < NV; j++)
+            // Yt = Li M'  (16 x 14), stored [var j][dyn row i]
+            double *Yt = &Ytf[size_t(k) * 256];
+            for (int j = 0; j < NV; j++)
+                for (int i = 0; i < NL; i++)
                 {
-                    double v = M[r * NV + j];
-                    for (int q = 0; q < j; q++)
-                        v -= Y[r * NV + q] * Lk[j * NV + q];
-                    Y[r * NV + j] = v / Lk[j * NV + j];
+                    double acc = 0.;
+                    for (int q = 0; q < NV; q++)
+                        acc += Li[j * NV + q] * M[i * NV + q];
+                    Yt[j * NV + i] = acc;
                 }
             for (int i = 0; i < NL; i++)
                 for (int j = 0; j < NL; j++)
                 {
-                    double acc = (i == j) ? Einv[size_t(k) * NL + i] : 0.;
+                    double acc = 0.;
                     for (int q = 0; q < NV; q++)
-                        acc += Y[i * NV + q] * Y[j * NV + q];
+                        acc += Yt[q * NV + i] * Yt[q * NV + j];
+                    if (i == j)
+                        acc += Einv[size_t(k) * NL + i];
                     Th[i * NL + j] = acc;
                 }
-            if (!chol(NL, Th, NL))
+            double *Ti = &Tif[size_t(k) * 256];
+            if (!invCholFactor(NL, Th, NL, Ti))
             {
                 last_fail = 200 + k;
                 return false;
             }
-            double *T = &Tf[size_t(k) * 256];
-            std::memcpy(T, Th, sizeof(double) * NL * NL);
             buildN(k, N);
-            // Z = T^-1 N
+            // Z = Ti N  (14 x 16)
             double *Zk = &Zf[size_t(k) * 256];
-            for (int j = 0; j < NV; j++)
-                for (int i = 0; i < NL; i++)
+            for (int i = 0; i < NL; i++)
+                for (int j = 0; j < NV; j++)
                 {
-                    double v = N[i * NV + j];
-                    for (int q = 0; q < i; q++)
-                        v -= T[i * NL + q] * Zk[q * NV + j];
-                    Zk[i * NV + j] = v / T[i * NL + i];
+                    double acc = 0.;
+                    for (int q = 0; q < NL; q++)
+                        acc += Ti[i * NL + q] * N[q * NV + j];
+                    Zk[i * NV + j] = acc;
                 }
         }
         // border column: T_mat v = c_sigma, c_sigma = (0 in w rows, -S_k in lambda rows)
@@ -754,104 +779,100 @@ class RQStructuredSocp
         return true;
     }
 
-    // solve block-tridiagonal T_mat [dw; dlam] = [beta; rho]
+    // solve block-tridiagonal T_mat [dw; dlam] = [beta; rho] with the stored tiles Li, Yt, Ti, Z
     void blockSolve(const std::vector<double> &beta, const std::vector<double> &rho, std::vector<double> &ow,
                     std::vector<double> &ol) const
     {
         using namespace sipm;
-        std::vector<double> a(size_t(K) * NV), c(size_t(K - 1) * NL);
+        std::vector<double> av(size_t(K) * NV), cv(size_t(K - 1) * NL);
         double g[NV];
         for (int j = 0; j < NV; j++)
             g[j] = beta[j];
         for (int k = 0; k < K; k++)
         {
-            const double *Lk = &Lf[size_t(k) * 256];
-            double *ak = &a[size_t(k) * NV];
+            const double *Li = &Lif[size_t(k) * 256];
+            double *a = &av[size_t(k) * NV];
             for (int i = 0; i < NV; i++)
             {
-                double v = g[i];
-                for (int q = 0; q < i; q++)
-                    v -= Lk[i * NV + q] * ak[q];
-                ak[i] = v / Lk[i * NV + i];
+                double acc = 0.;
+                for (int q = 0; q < NV; q++)
+                    acc += Li[i * NV + q] * g[q];
+                a[i] = acc;
             }
             if (k == K - 1)
                 break;
-            const double *Y = &Yf[size_t(k) * 256], *T = &Tf[size_t(k) * 256], *Zk = &Zf[size_t(k) * 256];
+            const double *Yt = &Ytf[size_t(k) * 256], *Ti = &Tif[size_t(k) * 256], *Zk = &Zf[size_t(k) * 256];
             double gl[NL];
             for (int i = 0; i < NL; i++)
             {
-                double v = rho[size_t(k) * NL + i];
+                double acc = 0.;
                 for (int q = 0; q < NV; q++)
-                    v -= Y[i * NV + q] * ak[q];
-                gl[i] = v;
+                    acc += Yt[q * NV + i] * a[q];
+                gl[i] = rho[size_t(k) * NL + i] - acc;
             }
-            double *ck = &c[size_t(k) * NL];
+            double *c = &cv[size_t(k) * NL];
             for (int i = 0; i < NL; i++)
             {
-                double v = gl[i];
-                for (int q = 0; q < i; q++)
-                    v -= T[i * NL + q] * ck[q];
-                ck[i] = v / T[i * NL + i];
+                double acc = 0.;
+                for (int q = 0; q < NL; q++)
+                    acc += Ti[i * NL + q] * gl[q];
+                c[i] = acc;
             }
             for (int j = 0; j < NV; j++)
             {
-                double v = beta[size_t(k + 1) * NV + j];
-                for (int r = 0; r < NL; r++)
-                    v += Zk[r * NV + j] * ck[r];
-                g[j] = v;
+                double acc = 0.;
+                for (int q = 0; q < NL; q++)
+                    acc += Zk[q * NV + j] * c[q];
+                g[j] = beta[size_t(k + 1) * NV + j] + acc;
             }
         }
-        // backward
         ow.assign(size_t(K) * NV, 0.);
         ol.assign(size_t(K - 1) * NL, 0.);
         {
-            const double *Lk = &Lf[size_t(K - 1) * 256];
-            double *x = &ow[size_t(K - 1) * NV];
-            const double *ak = &a[size_t(K - 1) * NV];
-            for (int i = NV - 1; i >= 0; i--)
+            const double *Li = &Lif[size_t(K - 1) * 256];
+            for (int i = 0; i < NV; i++)
             {
-                double v = ak[i];
-                for (int q = i + 1; q < NV; q++)
-                    v -= Lk[q * NV + i] * x[q];
-                x[i] = v / Lk[i * NV + i];
+                double acc = 0.;
+                for (int q = 0; q < NV; q++)
+                    acc += Li[q * NV + i] * av[size_t(K - 1) * NV + q];
+                ow[size_t(K - 1) * NV + i] = acc;
             }
         }
         for (int k = K - 2; k >= 0; k--)
         {
-            const double *Lk = &Lf[size_t(k) * 256], *Y = &Yf[size_t(k) * 256], *T = &Tf[size_t(k) * 256],
+            const double *Li = &Lif[size_t(k) * 256], *Yt = &Ytf[size_t(k) * 256], *Ti = &Tif[size_t(k) * 256],
                          *Zk = &Zf[size_t(k) * 256];
             const double *xn = &ow[size_t(k + 1) * NV];
-            double t[NL];
+            double t[NL], sv[NV];
             for (int i = 0; i < NL; i++)
             {
-                double v = -c[size_t(k) * NL + i];
-                for (int j = 0; j < NV; j++)
-                    v += Zk[i * NV + j] * xn[j];
-                t[i] = v;
+                double acc = 0.;
+                for (int q = 0; q < NV; q++)
+                    acc += Zk[i * NV + q] * xn[q];
+                t[i] = acc - cv[size_t(k) * NL + i];
             }
             double *lk = &ol[size_t(k) * NL];
-            for (int i = NL - 1; i >= 0; i--)
+            for (int i = 0; i < NL; i++)
             {
-                double v = t[i];
-                for (int q = i + 1; q < NL; q++)
-                    v -= T[q * NL + i] * lk[q];
-                lk[i] = v / T[i * NL + i];
+                double acc = 0.;
+                for (int q = 0; q < NL; q++)
+                    acc += Ti[q * NL + i] * t[q];
+                lk[i] = acc;
             }
-            double r[NV];
             for (int j = 0; j < NV; j++)
             {
-                double v = a[size_t(k) * NV + j];
-                for (int i = 0; i < NL; i++)
-                    v -= Y[i * NV + j] * lk[i];
-                r[j] = v;
+                double acc = 0.;
+                for (int q = 0; q < NL; q++)
+                    acc += Yt[j * NV + q] * lk[q];
+                sv[j] = av[size_t(k) * NV + j] - acc;
             }
             double *x = &ow[size_t(k) * NV];
-            for (int i = NV - 1; i >= 0; i--)
+            for (int i = 0; i < NV; i++)
             {
-                double v = r[i];
-                for (int q = i + 1; q < NV; q++)
-                    v -= Lk[q * NV + i] * x[q];
-                x[i] = v / Lk[i * NV + i];
+                double acc = 0.;
+                for (int q = 0; q < NV; q++)
+                    acc += Li[q * NV + i] * sv[q];
+                x[i] = acc;
             }
         }
     }

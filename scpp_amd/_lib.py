@@ -213,7 +213,7 @@ class Context:
         return out
 
     def socp_info(self):
-        info = np.zeros((self.B, 8))
+        info = np.zeros((self.B, 32))
         _chk(self.lib.scpp_hip_download_socp_info(self.h, _p(info)), "download_socp_info")
         return info
 

@@ -16,6 +16,21 @@ namespace scpp
 
 constexpr int WAVE = 64;
 
+// Every hot kernel here runs ONE 64-lane wavefront per workgroup.  Lanes of a wavefront execute in lockstep and
+// the LDS / vector-memory pipelines process a wavefront's instructions in order, so exchanging data between
+// lanes through LDS or global memory needs only a wavefront-scope fence (no instruction emitted) instead of
+// __syncthreads() (s_waitcnt vmcnt(0) + s_barrier, which exposes every outstanding store's latency).
+#ifdef SCPP_HIP_EMU
+#define WAVE_SYNC() __syncthreads()
+#else
+#define WAVE_SYNC()                                            \
+    do                                                         \
+    {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+#endif
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1)

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(WAVE)
                 if (e < NENT)
                     Ys[e] = ys;
             }
-            __syncthreads();
+            WAVE_SYNC();
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
             {
                 const double frac = FOH ? ts / dt : 0.;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(WAVE)
                     }
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
             // ---- derivative of the owned entries ----
             {
                 const double frac = FOH ? ts / dt : 0.;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(WAVE)
                     kk[s][m] = d;
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
         // ---- y += h * sum_s b_s k_s ----
 #pragma unroll

@@ -88,7 +88,9 @@ enum StageField
     F_WB = 472,   // [33] wbar of the 6 cones, same offsets as the slack layout
     F_BXW = 505,  // [16] right-hand side (w part)
     F_BXD = 521,
-    STREC = 528
+    F_HS = 522,   // [27] small Hessian blocks of the non-trust-region cones
+    F_HC = 549,   // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
+    STREC = 552
 };
 // ---- segment record: 33 fields of 14 doubles ----
 enum SegField
@@ -129,9 +131,22 @@ enum SegField
     G_NFIELDS
 };
 constexpr int SEGREC = G_NFIELDS * NL; // 462
-constexpr int FACREC = 4 * 256;        // L, Y, T, Z tiles (16x16 row-major each)
+constexpr int FACREC = 4 * 256;        // Li, Yt, Ti, Z tiles (16x16 row-major each)
+constexpr int NRHS_MAX = 3;            // right-hand-side columns carried by one sweep
+constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) per stage
 
-__host__ __device__ inline size_t workspaceDoubles(int K) { return size_t(K) * STREC + size_t(K) * SEGREC + size_t(K) * FACREC; }
+// Stage / segment records are stored FIELD-major: element f of stage k lives at st[f*64 + k], so that the
+// lane == stage phases read and write fully coalesced 512-byte rows (one lane per stage).
+constexpr int LANES = 64;
+__host__ __device__ inline size_t workspaceDoubles(int K) { return size_t(LANES) * STREC + size_t(LANES) * SEGREC + size_t(K) * (FACREC + SVREC); }
+
+// strided view of one lane's record
+struct SV
+{
+    double *p;
+    __device__ double &operator[](int i) const { return p[size_t(i) * LANES]; }
+    __device__ SV operator+(int o) const { return SV{p + size_t(o) * LANES}; }
+};
 
 struct Settings
 {
@@ -144,9 +159,10 @@ struct Settings
 struct Ctx
 {
     int K, lane;
-    double *st;  // [K][STREC]
-    double *sg;  // [K][SEGREC]
+    double *st;  // [STREC][64]   field-major
+    double *sg;  // [SEGREC][64]  field-major
     double *fac; // [K][FACREC]
+    double *sv;  // [K][SVREC]
     const double *A, *B, *C, *S, *Z; // dd of this instance
     const double *ip;                // instance parameters
 };
@@ -170,7 +186,8 @@ __device__ inline unsigned activeMask(int k, int K)
     return 0xFFu;
 }
 
-__device__ inline void maskInactive(unsigned act, double *v)
+template <class AV>
+__device__ inline void maskInactive(unsigned act, AV v)
 {
     for (int c = 0; c < NCONE; c++)
         if (!(act & (1u << c)))
@@ -182,8 +199,8 @@ __device__ inline void maskInactive(unsigned act, double *v)
         v[L2] = 0.;
 }
 // affine slack h - Gx of one stage
-__device__ inline void saff(const double *ip, unsigned act, const double *wk, double dlk, const double *wb, const double *uh,
-                            double *out)
+template <class AW, class AB, class AU, class AO>
+__device__ inline void saff(const double *ip, unsigned act, AW wk, double dlk, AB wb, AU uh, AO out)
 {
     out[0] = dlk;
     for (int j = 0; j < NV; j++)
@@ -209,7 +226,8 @@ __device__ inline void saff(const double *ip, unsigned act, const double *wk, do
     maskInactive(act, out);
 }
 // linear part of saff
-__device__ inline void Lmul(const double *ip, unsigned act, const double *dwk, double ddlk, const double *uh, double *out)
+template <class AW, class AU, class AO>
+__device__ inline void Lmul(const double *ip, unsigned act, AW dwk, double ddlk, AU uh, AO out)
 {
     out[0] = ddlk;
     for (int j = 0; j < NV; j++)
@@ -235,7 +253,8 @@ __device__ inline void Lmul(const double *ip, unsigned act, const double *dwk, d
     maskInactive(act, out);
 }
 // L' v (entries of inactive cones must be zero)
-__device__ inline void LTmul(const double *ip, unsigned fm, const double *v, const double *uh, double *gw, double *gdl)
+template <class AV, class AU>
+__device__ inline void LTmul(const double *ip, unsigned fm, AV v, AU uh, double *gw, double *gdl)
 {
     *gdl = v[0];
     for (int j = 0; j < NV; j++)
@@ -256,12 +275,12 @@ __device__ inline void LTmul(const double *ip, unsigned fm, const double *v, con
             gw[j] = 0.;
 }
 
-__device__ inline double stageX(const double *wk, int j) { return j < 13 ? wk[j] : 0.; }
-__device__ inline double stageU(const double *wk, int j) { return j < 3 ? wk[13 + j] : 0.; }
+template <class AW>
+__device__ inline double stageX(AW wk, int j) { return j < 13 ? wk[j] : 0.; }
 
 // dynamics residual of segment k: x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu_k - Z_k
-__device__ inline void dynRes(const Ctx &c, int k, const double *w0, const double *w1, const double *nuv, double sig,
-                              double *out)
+template <class A0, class A1, class AN>
+__device__ inline void dynRes(const Ctx &c, int k, A0 w0, A1 w1, AN nuv, double sig, double *out)
 {
     const double *A = c.A + size_t(k) * NX * NX, *B = c.B + size_t(k) * NX * NU, *C = c.C + size_t(k) * NX * NU;
     for (int i = 0; i < NX; i++)
@@ -289,7 +308,8 @@ __device__ inline double Nent(const Ctx &c, int k, unsigned fmNext, int i, int j
 }
 
 // H += sum_ab c_a c_b W^-2_ab e_va e_vb'
-__device__ inline void addConeH(double *H, double eta, const double *w, int d, const int *vars, const double *coef)
+template <class AW>
+__device__ inline void addConeH(double *H, double eta, AW w, int d, const int *vars, const double *coef)
 {
     const double e2 = 1. / (eta * eta);
     for (int a = 0; a < d; a++)
@@ -310,432 +330,102 @@ __device__ inline void addConeH(double *H, double eta, const double *w, int d, c
     }
 }
 
-// stage Hessian (delta_k eliminated), written row-major 16x16 to H (global); also hdd, hdw
-__device__ inline void buildH(const Ctx &c, int k, bool identity, double *H)
+// Per-stage Hessian data (delta_k eliminated) for the in-sweep tile build: F_HDD, F_HDW (delta elimination),
+// F_HC = {1/eta1^2, 2/den} of the trust-region cone and F_HS = the small dense blocks contributed by the other
+// cones / LP rows (layout: hsIndex in tile_engine.h).
+__device__ inline int hsIndexK(int a, int b)
+{
+    if (a >= 1 && a <= 3 && b >= 1 && b <= 3)
+        return (a - 1) * 3 + (b - 1);
+    if (a >= 8 && a <= 9 && b >= 8 && b <= 9)
+        return 9 + (a - 8) * 2 + (b - 8);
+    if (a >= 11 && a <= 12 && b >= 11 && b <= 12)
+        return 13 + (a - 11) * 2 + (b - 11);
+    if (a >= 13 && b >= 13)
+        return 17 + (a - 13) * 3 + (b - 13);
+    if (a == 0 && b == 0)
+        return 26;
+    return -1;
+}
+template <class AW>
+__device__ inline void addConeHs(double *Hs, double eta, AW w, int d, const int *vars, const double *coef)
+{
+    const double e2 = 1. / (eta * eta);
+    for (int a = 0; a < d; a++)
+    {
+        if (vars[a] < 0)
+            continue;
+        const double va = (a == 0) ? w[0] : -w[a];
+        for (int b = 0; b < d; b++)
+        {
+            if (vars[b] < 0)
+                continue;
+            const double vb = (b == 0) ? w[0] : -w[b];
+            double Wab = 2. * va * vb;
+            if (a == b)
+                Wab += (a == 0) ? -1. : 1.;
+            Hs[hsIndexK(vars[a], vars[b])] += coef[a] * coef[b] * Wab * e2;
+        }
+    }
+}
+__device__ inline void buildHs(const Ctx &c, int k, bool identity)
 {
     const unsigned fm = fixedMask(k, c.K), act = activeMask(k, c.K);
-    double *st = c.st + size_t(k) * STREC;
-    const double *eta = st + F_ETA, *wb = st + F_WB, *uh = st + F_UHAT;
-    for (int i = 0; i < NV * NV; i++)
-        H[i] = 0.;
+    const SV st{c.st + k};
+    const SV eta = st + F_ETA, wb = st + F_WB, uh = st + F_UHAT;
+    double Hs[27];
+    for (int i = 0; i < 27; i++)
+        Hs[i] = 0.;
     {
         const double e2 = 1. / (eta[0] * eta[0]);
         const double den = 2. * wb[0] * wb[0] - 1.;
         st[F_HDD] = den * e2;
         for (int j = 0; j < NV; j++)
             st[F_HDW + j] = (fm & (1u << j)) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
-        for (int i = 0; i < NV; i++)
-            for (int j = 0; j < NV; j++)
-                H[i * NV + j] = e2 * ((i == j ? 1. : 0.) - (2. / den) * wb[1 + i] * wb[1 + j]);
+        st[F_HC] = e2;
+        st[F_HC + 1] = 2. / den;
     }
     if (act & 2u)
     {
         const int v[3] = {3, 1, 2};
         const double cf[3] = {c.ip[IP_GS], 1., 1.};
-        addConeH(H, eta[1], wb + C2, 3, v, cf);
+        addConeHs(Hs, eta[1], wb + C2, 3, v, cf);
     }
     if (act & 4u)
     {
         const int v[3] = {-1, 8, 9};
         const double cf[3] = {0., 1., 1.};
-        addConeH(H, eta[2], wb + C3, 3, v, cf);
+        addConeHs(Hs, eta[2], wb + C3, 3, v, cf);
     }
     if (act & 8u)
     {
         const int v[3] = {-1, 11, 12};
         const double cf[3] = {0., 1., 1.};
-        addConeH(H, eta[3], wb + C4, 3, v, cf);
+        addConeHs(Hs, eta[3], wb + C4, 3, v, cf);
     }
     if (act & 16u)
     {
         const int v[4] = {-1, 13, 14, 15};
         const double cf[4] = {0., 1., 1., 1.};
-        addConeH(H, eta[4], wb + C5, 4, v, cf);
+        addConeHs(Hs, eta[4], wb + C5, 4, v, cf);
     }
     if (act & 32u)
     {
         const int v[3] = {15, 13, 14};
         const double cf[3] = {c.ip[IP_GIM], 1., 1.};
-        addConeH(H, eta[5], wb + C6, 3, v, cf);
+        addConeHs(Hs, eta[5], wb + C6, 3, v, cf);
     }
     if (act & 64u)
-        H[0] += identity ? 1. : st[F_Z + L1] / st[F_S + L1];
+        Hs[26] += identity ? 1. : st[F_Z + L1] / st[F_S + L1];
     if (act & 128u)
     {
         const double d = identity ? 1. : st[F_Z + L2] / st[F_S + L2];
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++)
-                H[(13 + a) * NV + 13 + b] += d * uh[a] * uh[b];
+                Hs[17 + a * 3 + b] += d * uh[a] * uh[b];
     }
-    for (int j = 0; j < NV; j++)
-        if (fm & (1u << j))
-        {
-            for (int i = 0; i < NV; i++)
-                H[i * NV + j] = H[j * NV + i] = 0.;
-            H[j * NV + j] = 1.;
-        }
-}
-
-// ---- cooperative tile helpers (LDS tiles, leading dimension 17) ----
-constexpr int LD = 17;
-
-// in-place lower Cholesky of the n x n tile in LDS; relative pivot floor 1e-14 (see structured_ipm.hpp)
-__device__ inline void cholTile(double *Am, double *od, int n, int lane)
-{
-    if (lane < n)
-        od[lane] = Am[lane * LD + lane];
-    __syncthreads();
-    for (int j = 0; j < n; j++)
-    {
-        if (lane == 0)
-        {
-            double d = Am[j * LD + j];
-            const double orig = od[j];
-            if (!(d > 1e-14 * orig))
-                d = 1e-14 * orig;
-            Am[j * LD + j] = sqrt(d);
-        }
-        __syncthreads();
-        if (lane > j && lane < n)
-            Am[lane * LD + j] /= Am[j * LD + j];
-        __syncthreads();
-        for (int e = lane; e < 256; e += WAVE)
-        {
-            const int i = e >> 4, cidx = e & 15;
-            if (i < n && cidx > j && i >= cidx)
-                Am[i * LD + cidx] -= Am[i * LD + j] * Am[cidx * LD + j];
-        }
-        __syncthreads();
-    }
-}
-
-// D(16x16) += X' Y with X, Y 16x16 tiles in LDS (rows >= nrows treated as zero by the caller), on the
-// FP64 matrix core: 4 x v_mfma_f64_16x16x4_f64.  Operand maps (cdna_hip_programming.md §3):
-//   A-operand lane l: A[i=l&15][k=l>>4] ; B-operand: B[k=l>>4][j=l&15] ; D lane l reg r: (row (l>>4)+4r, col l&15)
-__device__ inline d4_t mfmaXtY(const double *Xm, const double *Ym, int lane, d4_t acc)
-{
-    const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++)
-    {
-        const int kr = 4 * kk + hi; // contraction index = row of X and Y
-        const double a = Xm[kr * LD + lo];
-        const double b = Ym[kr * LD + lo];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-// D += X Y' : contraction over columns
-__device__ inline d4_t mfmaXYt(const double *Xm, const double *Ym, int lane, d4_t acc)
-{
-    const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++)
-    {
-        const int kc = 4 * kk + hi;
-        const double a = Xm[lo * LD + kc];
-        const double b = Ym[lo * LD + kc];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// forward substitution with a lower-triangular n x n matrix whose ROW `lane` is in Lrow (lanes < n);
-// g = right-hand side element of this lane; returns solution element (valid in lanes < n)
-template <int n>
-__device__ inline double trsvLower(const double *Lrow, double g, int lane)
-{
-    double x = 0.;
-#pragma unroll
-    for (int j = 0; j < n; j++)
-    {
-        const double xj_local = (lane == j) ? g / Lrow[j] : 0.;
-        const double xj = __shfl(xj_local, j);
-        if (lane == j)
-            x = xj;
-        if (lane > j && lane < n)
-            g -= Lrow[j] * xj;
-    }
-    return x;
-}
-// backward substitution with L' where COLUMN `lane` of L is in Lcol (Lcol[q] = L[q][lane])
-template <int n>
-__device__ inline double trsvUpperT(const double *Lcol, double g, int lane)
-{
-    double x = 0.;
-#pragma unroll
-    for (int j = n - 1; j >= 0; j--)
-    {
-        const double xj_local = (lane == j) ? g / Lcol[j] : 0.;
-        const double xj = __shfl(xj_local, j);
-        if (lane == j)
-            x = xj;
-        if (lane < j)
-            g -= Lcol[j] * xj; // L'[lane][j] = L[j][lane]
-    }
-    return x;
-}
-
-struct Shared
-{
-    double Pm[16 * LD]; // Phi / L
-    double Ym[16 * LD];
-    double Tm[16 * LD];
-    double Zm[16 * LD];
-    double Mm[16 * LD]; // M or N
-    double od[16];
-    double va[16];
-    double vc[16];
-};
-
-// ---- block-tridiagonal factorisation (stage sweep) ----
-// in: fac[k][0] = H_k (from buildH), seg EINV.  out: fac[k] = {L, Y, T, Z}.
-__device__ inline void factorSweep(const Ctx &c, Shared &sh, int use_mfma)
-{
-    const int lane = c.lane, K = c.K;
-    for (int k = 0; k < K; k++)
-    {
-        double *fk = c.fac + size_t(k) * FACREC;
-        // Phi = H_k (+ Z_{k-1}' Z_{k-1})
-        if (k > 0 && use_mfma)
-        {
-            d4_t acc = {0., 0., 0., 0.};
-            acc = mfmaXtY(sh.Zm, sh.Zm, lane, acc);
-            __syncthreads();
-            const int col = lane & 15;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-            {
-                const int row = (lane >> 4) + 4 * r;
-                sh.Pm[row * LD + col] = fk[row * 16 + col] + acc[r];
-            }
-        }
-        else
-        {
-            double tmp[4];
-            for (int r = 0; r < 4; r++)
-            {
-                const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-                double acc = fk[e];
-                if (k > 0)
-                    for (int q = 0; q < NL; q++)
-                        acc += sh.Zm[q * LD + i] * sh.Zm[q * LD + j];
-                tmp[r] = acc;
-            }
-            __syncthreads();
-            for (int r = 0; r < 4; r++)
-            {
-                const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-                sh.Pm[i * LD + j] = tmp[r];
-            }
-        }
-        __syncthreads();
-        cholTile(sh.Pm, sh.od, NV, lane);
-        for (int r = 0; r < 4; r++)
-        {
-            const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-            fk[e] = (j <= i) ? sh.Pm[i * LD + j] : 0.;
-        }
-        if (k == K - 1)
-            break;
-        // M tile (rows 14,15 zero)
-        const unsigned fm = fixedMask(k, K), fmn = fixedMask(k + 1, K);
-        for (int r = 0; r < 4; r++)
-        {
-            const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-            sh.Mm[i * LD + j] = (i < NL) ? Ment(c, k, fm, i, j) : 0.;
-        }
-        __syncthreads();
-        // Y = M L^-T : lane r < 14 does row r by forward substitution over columns
-        if (lane < 16)
-        {
-            for (int j = 0; j < NV; j++)
-            {
-                double v = sh.Mm[lane * LD + j];
-                for (int q = 0; q < j; q++)
-                    v -= sh.Ym[lane * LD + q] * sh.Pm[j * LD + q];
-                sh.Ym[lane * LD + j] = (lane < NL) ? v / sh.Pm[j * LD + j] : 0.;
-            }
-        }
-        __syncthreads();
-        // Theta = diag(Einv) + Y Y'   (rows/cols 14,15: identity padding)
-        {
-            const double *einv = c.sg + size_t(k) * SEGREC + G_EINV * NL;
-            if (use_mfma)
-            {
-                d4_t acc = {0., 0., 0., 0.};
-                acc = mfmaXYt(sh.Ym, sh.Ym, lane, acc);
-                const int col = lane & 15;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                {
-                    const int row = (lane >> 4) + 4 * r;
-                    double v = acc[r];
-                    if (row == col)
-                        v += (row < NL) ? einv[row] : 1.;
-                    sh.Tm[row * LD + col] = v;
-                }
-            }
-            else
-            {
-                for (int r = 0; r < 4; r++)
-                {
-                    const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-                    double acc = 0.;
-                    for (int q = 0; q < NV; q++)
-                        acc += sh.Ym[i * LD + q] * sh.Ym[j * LD + q];
-                    if (i == j)
-                        acc += (i < NL) ? einv[i] : 1.;
-                    sh.Tm[i * LD + j] = acc;
-                }
-            }
-        }
-        __syncthreads();
-        cholTile(sh.Tm, sh.od, NL, lane);
-        // N tile
-        for (int r = 0; r < 4; r++)
-        {
-            const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-            sh.Mm[i * LD + j] = (i < NL) ? Nent(c, k, fmn, i, j) : 0.;
-        }
-        __syncthreads();
-        // Z = T^-1 N : lane j < 16 does column j
-        if (lane < 16)
-        {
-            for (int i = 0; i < NL; i++)
-            {
-                double v = sh.Mm[i * LD + lane];
-                for (int q = 0; q < i; q++)
-                    v -= sh.Tm[i * LD + q] * sh.Zm[q * LD + lane];
-                sh.Zm[i * LD + lane] = v / sh.Tm[i * LD + i];
-            }
-            sh.Zm[14 * LD + lane] = 0.;
-            sh.Zm[15 * LD + lane] = 0.;
-        }
-        __syncthreads();
-        for (int r = 0; r < 4; r++)
-        {
-            const int e = lane + WAVE * r, i = e >> 4, j = e & 15;
-            fk[256 + e] = sh.Ym[i * LD + j];
-            fk[512 + e] = (i < NL && j < NL && j <= i) ? sh.Tm[i * LD + j] : (i == j ? 1. : 0.);
-            fk[768 + e] = sh.Zm[i * LD + j];
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-}
-
-// ---- block-tridiagonal solve: [dw; dlam] = T_mat^-1 [beta; rho] ----
-// beta from stage field fBeta, rho from segment field gRho; result to stage field fOut, segment field gOut.
-__device__ inline void blockSolve(const Ctx &c, Shared &sh, int fBeta, int gRho, int fOut, int gOut)
-{
-    const int lane = c.lane, K = c.K;
-    double g = (lane < NV) ? c.st[F_BETA * 0 + fBeta + lane] : 0.; // stage 0
-    for (int k = 0; k < K; k++)
-    {
-        const double *fk = c.fac + size_t(k) * FACREC;
-        double row[16];
-#pragma unroll
-        for (int q = 0; q < NV; q++)
-            row[q] = (lane < NV) ? fk[lane * 16 + q] : 1.;
-        const double a = trsvLower<NV>(row, g, lane);
-        if (lane < NV)
-        {
-            c.st[size_t(k) * STREC + F_AV + lane] = a;
-            sh.va[lane] = a;
-        }
-        __syncthreads();
-        if (k == K - 1)
-            break;
-        // gl = rho - Y a
-        double gl = 0.;
-        if (lane < NL)
-        {
-            gl = c.sg[size_t(k) * SEGREC + gRho * NL + lane];
-            for (int q = 0; q < NV; q++)
-                gl -= fk[256 + lane * 16 + q] * sh.va[q];
-#pragma unroll
-            for (int q = 0; q < NL; q++)
-                row[q] = fk[512 + lane * 16 + q];
-        }
-        const double cc = trsvLower<NL>(row, gl, lane);
-        if (lane < NL)
-        {
-            c.sg[size_t(k) * SEGREC + G_CV * NL + lane] = cc;
-            sh.vc[lane] = cc;
-        }
-        __syncthreads();
-        // g_next = beta_{k+1} + Z' c
-        if (lane < NV)
-        {
-            double v = c.st[size_t(k + 1) * STREC + fBeta + lane];
-            for (int r = 0; r < NL; r++)
-                v += fk[768 + r * 16 + lane] * sh.vc[r];
-            g = v;
-        }
-        __syncthreads();
-    }
-    // backward
-    {
-        const double *fk = c.fac + size_t(K - 1) * FACREC;
-        double col[16];
-#pragma unroll
-        for (int q = 0; q < NV; q++)
-            col[q] = (lane < NV) ? fk[q * 16 + lane] : 1.;
-        const double a = (lane < NV) ? c.st[size_t(K - 1) * STREC + F_AV + lane] : 0.;
-        const double x = trsvUpperT<NV>(col, a, lane);
-        if (lane < NV)
-        {
-            c.st[size_t(K - 1) * STREC + fOut + lane] = x;
-            sh.va[lane] = x;
-        }
-        __syncthreads();
-    }
-    for (int k = K - 2; k >= 0; k--)
-    {
-        const double *fk = c.fac + size_t(k) * FACREC;
-        double col[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-            col[q] = 1.;
-        // t = Z x_{k+1} - c
-        double t = 0.;
-        if (lane < NL)
-        {
-            t = -c.sg[size_t(k) * SEGREC + G_CV * NL + lane];
-            for (int j = 0; j < NV; j++)
-                t += fk[768 + lane * 16 + j] * sh.va[j];
-#pragma unroll
-            for (int q = 0; q < NL; q++)
-                col[q] = fk[512 + q * 16 + lane];
-        }
-        const double lk = trsvUpperT<NL>(col, t, lane);
-        __syncthreads();
-        if (lane < NL)
-        {
-            c.sg[size_t(k) * SEGREC + gOut * NL + lane] = lk;
-            sh.vc[lane] = lk;
-        }
-        __syncthreads();
-        double r = 0.;
-        if (lane < NV)
-        {
-            r = c.st[size_t(k) * STREC + F_AV + lane];
-            for (int i = 0; i < NL; i++)
-                r -= fk[256 + i * 16 + lane] * sh.vc[i];
-#pragma unroll
-            for (int q = 0; q < NV; q++)
-                col[q] = fk[q * 16 + lane];
-        }
-        const double x = trsvUpperT<NV>(col, r, lane);
-        __syncthreads();
-        if (lane < NV)
-        {
-            c.st[size_t(k) * STREC + fOut + lane] = x;
-            sh.va[lane] = x;
-        }
-        __syncthreads();
-    }
+    for (int i = 0; i < 27; i++)
+        st[F_HS + i] = Hs[i];
 }
 
 } // namespace ipm

@@ -3,6 +3,7 @@
 // twin carries the derivation); see ipm_kernel.h for layout and tile helpers.
 #pragma once
 #include "ipm_kernel.h"
+#include "sweeps.h"
 
 namespace scpp
 {
@@ -53,7 +54,7 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     const int k = c.lane, K = c.K;
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             if (identity)
@@ -70,7 +71,7 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
         }
     }
     if (k < K)
-        buildH(c, k, identity, c.fac + size_t(k) * FACREC);
+        buildHs(c, k, identity);
     {
         const double e2 = 1. / (g.seta * g.seta);
         const double vt[3] = {g.sw[0], -g.sw[1], -g.sw[2]};
@@ -91,38 +92,15 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     }
 }
 
-// factorisation + border column
-__device__ inline void factorAll(const Ctx &c, Shared &sh, bool identity, Glob &g, int use_mfma)
-{
-    const int k = c.lane, K = c.K;
-    prepareFactor(c, identity, g);
-    __syncthreads();
-    factorSweep(c, sh, use_mfma);
-    // border column: T_mat v = c_sigma = (0 ; -S_k)
-    if (k < K)
-        for (int j = 0; j < NV; j++)
-            c.st[size_t(k) * STREC + F_BETA + j] = 0.;
-    if (k < K - 1)
-        for (int i = 0; i < NL; i++)
-            c.sg[size_t(k) * SEGREC + G_RHO * NL + i] = -c.S[k * NX + i];
-    __syncthreads();
-    blockSolve(c, sh, F_BETA, G_RHO, F_BCW, G_BCL);
-    double acc = 0.;
-    if (k < K - 1)
-        for (int i = 0; i < NL; i++)
-            acc += -c.S[k * NX + i] * c.sg[size_t(k) * SEGREC + G_BCL * NL + i];
-    acc = wave_sum(acc);
-    g.schur = g.hsig - acc;
-}
-
-// reduced KKT solve with right-hand side in F_BXW/F_BXD, G_BXNU/G_BXNUB/G_BY and b; fills all d* quantities
-__device__ inline void kktSolve(const Ctx &c, Shared &sh, bool identity, Glob &g, const Rhs &b)
+// Reduced KKT solve, part 1: condensed right-hand side.  Input: F_BXW/F_BXD, G_BXNU/G_BXNUB/G_BY and b.
+// Output: stage field fBeta (16) and segment field gRho (14) for the sweeps; returns the sigma-row rhs.
+__device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs &b, int fBeta, int gRho)
 {
     const int k = c.lane, K = c.K;
     g.dz3 = -b.n1;
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             const double d1 = dLP(identity, sg[G_S1 * NL + i], sg[G_Z1 * NL + i]);
@@ -132,34 +110,51 @@ __device__ inline void kktSolve(const Ctx &c, Shared &sh, bool identity, Glob &g
             const double btn = sg[G_BXNU * NL + i] - sg[G_QV * NL + i] * bnb;
             sg[G_BNB * NL + i] = bnb;
             sg[G_BTN * NL + i] = btn;
-            sg[G_RHO * NL + i] = sg[G_BY * NL + i] + sg[G_EINV * NL + i] * btn;
+            sg[gRho * NL + i] = sg[G_BY * NL + i] + sg[G_EINV * NL + i] * btn;
         }
     }
     if (k < K)
     {
-        double *st = c.st + size_t(k) * STREC;
+        const SV st{c.st + k};
         const unsigned fm = fixedMask(k, K);
         for (int j = 0; j < NV; j++)
-            st[F_BETA + j] = (fm & (1u << j)) ? 0. : st[F_BXW + j] - st[F_HDW + j] * st[F_BXD] / st[F_HDD];
+            st[fBeta + j] = (fm & (1u << j)) ? 0. : st[F_BXW + j] - st[F_HDW + j] * st[F_BXD] / st[F_HDD];
     }
-    const double bts = b.s - g.Hsd * b.ds / g.Hdd;
-    __syncthreads();
-    blockSolve(c, sh, F_BETA, G_RHO, F_VW, G_VL);
+    return b.s - g.Hsd * b.ds / g.Hdd;
+}
+
+// border column products: schur complement of sigma (after the border column has been solved)
+__device__ inline void borderSchur(const Ctx &c, Glob &g)
+{
+    const int k = c.lane, K = c.K;
+    double acc = 0.;
+    if (k < K - 1)
+        for (int i = 0; i < NL; i++)
+            acc += -c.S[k * NX + i] * c.sg[size_t(G_BCL * NL + i) * LANES + k];
+    acc = wave_sum(acc);
+    g.schur = g.hsig - acc;
+}
+
+// part 2: after the sweeps left T_mat^-1 [beta;rho] in fVW / gVL: border correction and recovery of the
+// eliminated variables.
+__device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs &b, double bts, int fVW, int gVL)
+{
+    const int k = c.lane, K = c.K;
     double cv = 0.;
     if (k < K - 1)
         for (int i = 0; i < NL; i++)
-            cv += -c.S[k * NX + i] * c.sg[size_t(k) * SEGREC + G_VL * NL + i];
+            cv += -c.S[k * NX + i] * c.sg[size_t(gVL * NL + i) * LANES + k];
     cv = wave_sum(cv);
     g.dsig = (bts - cv) / g.schur;
     g.ddsg = (b.ds - g.Hsd * g.dsig) / g.Hdd;
     double sumnb = 0.;
     if (k < K)
     {
-        double *st = c.st + size_t(k) * STREC;
+        const SV st{c.st + k};
         double acc = 0.;
         for (int j = 0; j < NV; j++)
         {
-            const double d = st[F_VW + j] - st[F_BCW + j] * g.dsig;
+            const double d = st[fVW + j] - st[F_BCW + j] * g.dsig;
             st[F_DW + j] = d;
             acc += st[F_HDW + j] * d;
         }
@@ -167,10 +162,10 @@ __device__ inline void kktSolve(const Ctx &c, Shared &sh, bool identity, Glob &g
     }
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
-            const double dl = sg[G_VL * NL + i] - sg[G_BCL * NL + i] * g.dsig;
+            const double dl = sg[gVL * NL + i] - sg[G_BCL * NL + i] * g.dsig;
             sg[G_DLAM * NL + i] = dl;
             const double dnu = sg[G_EINV * NL + i] * (dl + sg[G_BTN * NL + i]);
             const double dnub = sg[G_BNB * NL + i] * sg[G_DINV * NL + i] - sg[G_QV * NL + i] * dnu;
@@ -184,12 +179,33 @@ __device__ inline void kktSolve(const Ctx &c, Shared &sh, bool identity, Glob &g
     g.dn1 = sumnb - w3sq * g.dz3 - b.rhs3;
 }
 
+__device__ inline RhsSpec specBorderPlus(int fBeta, int gRho, int fOut, int gOut)
+{
+    RhsSpec sp;
+    sp.n = 2;
+    sp.fBeta = fBeta;
+    sp.gRho = gRho;
+    sp.fOut = fOut;
+    sp.gOut = gOut;
+    return sp;
+}
+__device__ inline RhsSpec specSingle(int fBeta, int gRho, int fOut, int gOut)
+{
+    RhsSpec sp;
+    sp.n = 1;
+    sp.fBeta = fBeta;
+    sp.gRho = gRho;
+    sp.fOut = fOut;
+    sp.gOut = gOut;
+    return sp;
+}
+
 __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
 {
     const int k = c.lane, K = c.K;
     if (k < K)
     {
-        double *st = c.st + size_t(k) * STREC;
+        const SV st{c.st + k};
         const unsigned fm = fixedMask(k, K);
         for (int j = 0; j < NV; j++)
             if (!(fm & (1u << j)))
@@ -198,7 +214,7 @@ __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
     }
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             sg[G_NU * NL + i] += alpha * sg[G_DNU * NL + i];
@@ -217,12 +233,12 @@ __device__ inline void evalAllSaff(const Ctx &c, const Glob &g, int fOut, int g1
     double sumnb = 0.;
     if (k < K)
     {
-        double *st = c.st + size_t(k) * STREC;
+        const SV st{c.st + k};
         saff(c.ip, activeMask(k, K), st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, st + fOut);
     }
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
@@ -247,11 +263,11 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        const double *v = c.st + size_t(k) * STREC + f;
+        const SV v = SV{c.st + k} + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
             {
-                const double *r = v + coneOff(cix);
+                const SV r = v + coneOff(cix);
                 double nrm = 0.;
                 for (int i = 1; i < coneDim(cix); i++)
                     nrm += r[i] * r[i];
@@ -266,7 +282,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        const double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
@@ -289,7 +305,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        double *v = c.st + size_t(k) * STREC + f;
+        const SV v = SV{c.st + k} + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
                 v[coneOff(cix)] += alpha;
@@ -300,7 +316,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        double *sg = c.sg + size_t(k) * SEGREC;
+        const SV sg{c.sg + k};
         for (int i = 0; i < NL; i++)
         {
             sg[g1 * NL + i] += alpha;
@@ -312,22 +328,147 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     vc[0] += alpha;
 }
 
-__global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
+
+// ---- per-cone work on register arrays (compile-time offset / dimension) ----
+template <int OFF, int D>
+__device__ inline void ldv(const SV &st, int f, double (&v)[D])
 {
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        v[i] = st[f + OFF + i];
+}
+template <int OFF, int D>
+__device__ inline void stv(const SV &st, int f, const double (&v)[D])
+{
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        st[f + OFF + i] = v[i];
+}
+// NT scaling of one cone + lambda = W z ; returns 1 if the iterate left the cone
+template <int OFF, int D>
+__device__ inline int coneScaling(const SV &st, int cix)
+{
+    double s[D], z[D], w[D], ls[D], eta;
+    ldv<OFF, D>(st, F_S, s);
+    ldv<OFF, D>(st, F_Z, z);
+    if (!cone::nt_scalingS<D>(s, z, eta, w))
+        return 1;
+    cone::applyWS<D>(eta, w, z, ls);
+    st[F_ETA + cix] = eta;
+    stv<OFF, D>(st, F_WB, w);
+    stv<OFF, D>(st, F_LS, ls);
+    return 0;
+}
+// t = W^-2 rz' + W^-1(lambda \ ds) of one cone
+template <int OFF, int D>
+__device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu)
+{
+    double w[D], rz[D], b2[D], t[D];
+    const double eta = st[F_ETA + cix];
+    ldv<OFF, D>(st, F_WB, w);
+    ldv<OFF, D>(st, F_RZ, rz);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        rz[i] *= om;
+    cone::applyWinv2S<D>(eta, w, rz, b2);
+    if (pass == 0)
+    {
+        double z[D];
+        ldv<OFF, D>(st, F_Z, z);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            t[i] = b2[i] - z[i];
+    }
+    else
+    {
+        double dss[D], dzs[D], ls[D], dsv[D], aa[D];
+        ldv<OFF, D>(st, F_DSS, dss);
+        ldv<OFF, D>(st, F_DZS, dzs);
+        ldv<OFF, D>(st, F_LS, ls);
+        cone::conicProductS<D>(dss, dzs, dsv);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            dsv[i] = -dsv[i];
+        dsv[0] += sigmu;
+        cone::conicDivisionS<D>(ls, dsv);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            dsv[i] -= ls[i];
+        cone::applyWinvS<D>(eta, w, dsv, aa);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            t[i] = b2[i] + aa[i];
+    }
+    stv<OFF, D>(st, F_TZ, t);
+}
+// dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
+template <int OFF, int D>
+__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall)
+{
+    double w[D], Ld[D], aa[D], t[D], rz[D], dz[D], ds[D], dss[D], dzs[D], ls[D];
+    const double eta = st[F_ETA + cix];
+    ldv<OFF, D>(st, F_WB, w);
+    ldv<OFF, D>(st, F_TZ, t);
+    ldv<OFF, D>(st, F_RZ, rz);
+    ldv<OFF, D>(st, F_LS, ls);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        Ld[i] = Ldall[OFF + i];
+    cone::applyWinv2S<D>(eta, w, Ld, aa);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+    {
+        dz[i] = -aa[i] + t[i];
+        ds[i] = -om * rz[i] + Ld[i];
+    }
+    cone::applyWinvS<D>(eta, w, ds, dss);
+    cone::applyWS<D>(eta, w, dz, dzs);
+    stv<OFF, D>(st, F_DZ, dz);
+    stv<OFF, D>(st, F_DS, ds);
+    stv<OFF, D>(st, F_DSS, dss);
+    stv<OFF, D>(st, F_DZS, dzs);
+    const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
+    return a1 > a2 ? a1 : a2;
+}
+template <int OFF, int D>
+__device__ inline void zeroT(const SV &st)
+{
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        st[F_TZ + OFF + i] = 0.;
+}
+
+#ifndef IPM_WAVES_PER_SIMD
+#define IPM_WAVES_PER_SIMD 2
+#endif
+#ifdef IPM_PROFILE
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) prof[slot] += double((t1) - (t0))
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArgs a)
+{
+#ifdef IPM_PROFILE
+    double prof[12] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    const long long t_kernel0 = clock64();
+#endif
     const int inst = blockIdx.x;
     if (inst >= a.B)
         return;
     if (a.active && a.active[inst] == 0)
         return;
-    __shared__ Shared sh;
+    __shared__ TileShared sh;
     const int K = a.K, lane = threadIdx.x, k = lane;
     Ctx c;
     c.K = K;
     c.lane = lane;
     double *ws = a.ws + size_t(inst) * workspaceDoubles(K);
     c.st = ws;
-    c.sg = ws + size_t(K) * STREC;
-    c.fac = c.sg + size_t(K) * SEGREC;
+    c.sg = ws + size_t(LANES) * STREC;
+    c.fac = c.sg + size_t(LANES) * SEGREC;
+    c.sv = c.fac + size_t(K) * FACREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
     c.B = a.Bm + size_t(inst) * (K - 1) * NX * NU;
     c.C = a.C + size_t(inst) * (K - 1) * NX * NU;
@@ -340,8 +481,9 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
     const double sigbar = a.sigma[inst];
     const Settings opt = a.opt;
     const unsigned fm = (k < K) ? fixedMask(k, K) : 0u, act = (k < K) ? activeMask(k, K) : 0u;
-    double *st = c.st + size_t(k < K ? k : 0) * STREC;
-    double *sg = c.sg + size_t(k < K - 1 ? k : 0) * SEGREC;
+    const SV st{c.st + (k < K ? k : 0)};
+    const SV stN{c.st + (k < K - 1 ? k + 1 : 0)}; // next stage's record
+    const SV sg{c.sg + (k < K - 1 ? k : 0)};
     const bool vst = k < K, vsg = k < K - 1;
 
     Glob g;
@@ -408,10 +550,11 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         Dcount = int(dsum + 0.5) + 3;
     }
     const int D = Dcount;
-    __syncthreads();
+    WAVE_SYNC();
 
     // =============== initialisation (ECOS init, W = I) ===============
-    factorAll(c, sh, true, g, opt.use_mfma);
+    PROF_T(tp0);
+    prepareFactor(c, true, g);
     {
         // primal: bx = -L' saff(x0), by = -ry(x0), rhs3 = n1
         Rhs b;
@@ -427,7 +570,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         if (vsg)
         {
             double res[NL];
-            dynRes(c, k, st + F_W, st + STREC + F_W, sg + G_NU * NL, g.sig, res);
+            dynRes(c, k, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
             for (int i = 0; i < NL; i++)
             {
                 sg[G_BXNU * NL + i] = 0.;
@@ -439,10 +582,17 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         b.ds = -(0.5 * (0.5 + 0.5 * g.dsg) - 0.5 * (0.5 - 0.5 * g.dsg));
         b.n1 = 0.;
         b.rhs3 = g.n1;
-        __syncthreads();
-        kktSolve(c, sh, true, g, b);
+        const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+        WAVE_SYNC();
+        const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
+        factorSweepFused(c, sh, sp);
+        bwdSweep(c, sp);
+        borderSchur(c, g);
+        kktFinish(c, true, g, b, bts, F_VW, G_VL);
+        PROF_T(tp1);
+        PROF_ADD(0, tp0, tp1);
         applyPrimalStep(c, g, 1.);
-        __syncthreads();
+        WAVE_SYNC();
         evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
         bring2cone(c, opt.gamma, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
     }
@@ -466,8 +616,12 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         b.ds = -w_trt;
         b.n1 = -w_vc;
         b.rhs3 = 0.;
-        __syncthreads();
-        kktSolve(c, sh, true, g, b);
+        const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+        WAVE_SYNC();
+        const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
+        fwdSweep(c, sp);
+        bwdSweep(c, sp);
+        kktFinish(c, true, g, b, bts, F_VW, G_VL);
         if (vst)
         {
             double t[NS];
@@ -490,7 +644,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         g.zc3[2] = -g.dsig;
         bring2cone(c, opt.gamma, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // ---- data norms for the termination test ----
     double resx0, resy0, resz0;
@@ -512,7 +666,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         {
             const unsigned fmn = fixedMask(k + 1, K);
             for (int j = 0; j < NV; j++)
-                w1[j] = (fmn & (1u << j)) ? st[STREC + F_W + j] : 0.;
+                w1[j] = (fmn & (1u << j)) ? stN[F_W + j] : 0.;
             double zero[NL], res[NL];
             for (int i = 0; i < NL; i++)
                 zero[i] = 0.;
@@ -532,6 +686,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
     for (iter = 0;; iter++)
     {
         // ================= residuals =================
+        PROF_T(tr0);
         double sas, sa3, sac[3];
         evalAllSaff(c, g, F_RZ, G_RZ1, G_RZ2, sas, sa3, sac);
         double p_gap = 0., p_rx = 0., p_ry = 0., p_rz = 0., p_xx = 0., p_yy = 0., p_zz = 0., p_ss = 0., p_rxs = 0., p_dl = 0.;
@@ -564,7 +719,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
             if (k > 0)
                 for (int i = 0; i < NL; i++)
                 {
-                    const double l = c.sg[size_t(k - 1) * SEGREC + G_LAM * NL + i];
+                    const double l = SV{c.sg + k - 1}[G_LAM * NL + i];
                     for (int j = 0; j < NV; j++)
                         r[j] += Nent(c, k - 1, fm, i, j) * l;
                 }
@@ -584,7 +739,7 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         if (vsg)
         {
             double res[NL];
-            dynRes(c, k, st + F_W, st + STREC + F_W, sg + G_NU * NL, g.sig, res);
+            dynRes(c, k, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
             for (int i = 0; i < NL; i++)
             {
                 const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
@@ -668,20 +823,22 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
         }
 
         // ================= scalings =================
+        PROF_T(tr1);
+        PROF_ADD(1, tr0, tr1);
         int bad = 0;
         if (vst)
         {
-            for (int cix = 0; cix < NCONE; cix++)
-                if (act & (1u << cix))
-                {
-                    const int o = coneOff(cix), d = coneDim(cix);
-                    if (!cone::nt_scaling(st + F_S + o, st + F_Z + o, d, st + F_ETA + cix, st + F_WB + o))
-                        bad = 1;
-                    else
-                        cone::applyW(st[F_ETA + cix], st + F_WB + o, d, st + F_Z + o, st + F_LS + o);
-                }
+            bad |= coneScaling<C1, 17>(st, 0);
+            if (act & 2u)
+                bad |= coneScaling<C2, 3>(st, 1);
+            if (act & 4u)
+                bad |= coneScaling<C3, 3>(st, 2);
+            if (act & 8u)
+                bad |= coneScaling<C4, 3>(st, 3);
+            bad |= coneScaling<C5, 4>(st, 4);
+            bad |= coneScaling<C6, 3>(st, 5);
         }
-        if (!cone::nt_scaling(g.sc3, g.zc3, 3, &g.seta, g.sw))
+        if (!cone::nt_scaling(g.sc3, g.zc3, 3, g.seta, g.sw))
             bad = 1;
         bad = wave_or(bad);
         if (bad)
@@ -690,56 +847,39 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
             break;
         }
         cone::applyW(g.seta, g.sw, 3, g.zc3, g.lamC);
-        __syncthreads();
-        factorAll(c, sh, false, g, opt.use_mfma);
-        if (!(g.schur > 0.))
-        {
-            status = -2;
-            break;
-        }
+        WAVE_SYNC();
+        PROF_T(tr2);
+        PROF_ADD(2, tr1, tr2);
+        prepareFactor(c, false, g);
+        PROF_T(tr3);
+        PROF_ADD(8, tr2, tr3);
 
         double sigma_c = 0., alpha = 1.;
         double tzs = 0., tzc[3] = {0., 0., 0.};
-        for (int pass = 0; pass < 2; pass++)
+        for (int pass = 0; pass < 2 && !bad; pass++)
         {
             const double om = 1. - sigma_c;
+            PROF_T(tq0);
             // ---------- t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ----------
             if (vst)
             {
-                for (int cix = 0; cix < NCONE; cix++)
                 {
-                    const int o = coneOff(cix), d = coneDim(cix);
-                    if (!(act & (1u << cix)))
-                    {
-                        for (int i = 0; i < d; i++)
-                            st[F_TZ + o + i] = 0.;
-                        continue;
-                    }
-                    const double eta = st[F_ETA + cix];
-                    const double *wb = st + F_WB + o;
-                    double aa[17], b2[17];
-                    for (int i = 0; i < d; i++)
-                        aa[i] = om * st[F_RZ + o + i];
-                    cone::applyWinv2(eta, wb, d, aa, b2);
-                    if (pass == 0)
-                    {
-                        for (int i = 0; i < d; i++)
-                            st[F_TZ + o + i] = b2[i] - st[F_Z + o + i];
-                    }
+                    const double sigmu = sigma_c * mu;
+                    coneT<C1, 17>(st, 0, pass, om, sigmu);
+                    if (act & 2u)
+                        coneT<C2, 3>(st, 1, pass, om, sigmu);
                     else
-                    {
-                        double dsv[17];
-                        cone::conicProduct(d, st + F_DSS + o, st + F_DZS + o, dsv);
-                        for (int i = 0; i < d; i++)
-                            dsv[i] = -dsv[i];
-                        dsv[0] += sigma_c * mu;
-                        cone::conicDivision(d, st + F_LS + o, dsv, dsv);
-                        for (int i = 0; i < d; i++)
-                            dsv[i] -= st[F_LS + o + i];
-                        cone::applyWinv(eta, wb, d, dsv, aa);
-                        for (int i = 0; i < d; i++)
-                            st[F_TZ + o + i] = b2[i] + aa[i];
-                    }
+                        zeroT<C2, 3>(st);
+                    if (act & 4u)
+                        coneT<C3, 3>(st, 2, pass, om, sigmu);
+                    else
+                        zeroT<C3, 3>(st);
+                    if (act & 8u)
+                        coneT<C4, 3>(st, 3, pass, om, sigmu);
+                    else
+                        zeroT<C4, 3>(st);
+                    coneT<C5, 4>(st, 4, pass, om, sigmu);
+                    coneT<C6, 3>(st, 5, pass, om, sigmu);
                 }
                 for (int which = 0; which < 2; which++)
                 {
@@ -803,34 +943,66 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
             b.ds = -om * rxds + 0.5 * tzc[0] - 0.5 * tzc[1];
             b.n1 = -om * rxn1;
             b.rhs3 = -om * rz3 - ds3v / g.z3;
-            __syncthreads();
-            kktSolve(c, sh, false, g, b);
+            const double bts = kktPrep(c, false, g, b, F_BETA, G_RHO);
+            WAVE_SYNC();
+            PROF_T(tq1);
+            PROF_ADD(4, tq0, tq1);
+            if (pass == 0)
+            {
+                // one factorisation per iteration, fused with the forward substitution of the sigma border
+                // column and of the affine right-hand side
+                const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
+                factorSweepFused(c, sh, sp);
+                PROF_T(tf1);
+                PROF_ADD(3, tq1, tf1);
+                bwdSweep(c, sp);
+                borderSchur(c, g);
+                PROF_T(tf2);
+                PROF_ADD(9, tf1, tf2);
+            }
+            else
+            {
+                const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
+                fwdSweep(c, sp);
+                PROF_T(tf1);
+                PROF_ADD(10, tq1, tf1);
+                bwdSweep(c, sp);
+                PROF_T(tf2);
+                PROF_ADD(9, tf1, tf2);
+            }
+            if (!(g.schur > 0.))
+                bad = 1;
+            kktFinish(c, false, g, b, bts, F_VW, G_VL);
+            PROF_T(tq2);
+            PROF_ADD(5, tq1, tq2);
             // ---------- dz = -W^-2 L dx + t ; ds = -rz' + L dx ; step length ----------
             double ainv = 0.;
             if (vst)
             {
                 double Ld[NS];
                 Lmul(ip, act, st + F_DW, st[F_DDL], st + F_UHAT, Ld);
-                for (int cix = 0; cix < NCONE; cix++)
                 {
-                    if (!(act & (1u << cix)))
-                        continue;
-                    const int o = coneOff(cix), d = coneDim(cix);
-                    const double eta = st[F_ETA + cix];
-                    const double *wb = st + F_WB + o;
-                    double aa[17];
-                    cone::applyWinv2(eta, wb, d, Ld + o, aa);
-                    for (int i = 0; i < d; i++)
+                    double a0 = coneDir<C1, 17>(st, 0, om, Ld);
+                    ainv = a0 > ainv ? a0 : ainv;
+                    if (act & 2u)
                     {
-                        st[F_DZ + o + i] = -aa[i] + st[F_TZ + o + i];
-                        st[F_DS + o + i] = -om * st[F_RZ + o + i] + Ld[o + i];
+                        a0 = coneDir<C2, 3>(st, 1, om, Ld);
+                        ainv = a0 > ainv ? a0 : ainv;
                     }
-                    cone::applyWinv(eta, wb, d, st + F_DS + o, st + F_DSS + o);
-                    cone::applyW(eta, wb, d, st + F_DZ + o, st + F_DZS + o);
-                    const double a1 = cone::stepInv(d, st + F_LS + o, st + F_DSS + o);
-                    const double a2 = cone::stepInv(d, st + F_LS + o, st + F_DZS + o);
-                    ainv = a1 > ainv ? a1 : ainv;
-                    ainv = a2 > ainv ? a2 : ainv;
+                    if (act & 4u)
+                    {
+                        a0 = coneDir<C3, 3>(st, 2, om, Ld);
+                        ainv = a0 > ainv ? a0 : ainv;
+                    }
+                    if (act & 8u)
+                    {
+                        a0 = coneDir<C4, 3>(st, 3, om, Ld);
+                        ainv = a0 > ainv ? a0 : ainv;
+                    }
+                    a0 = coneDir<C5, 4>(st, 4, om, Ld);
+                    ainv = a0 > ainv ? a0 : ainv;
+                    a0 = coneDir<C6, 3>(st, 5, om, Ld);
+                    ainv = a0 > ainv ? a0 : ainv;
                 }
                 for (int which = 0; which < 2; which++)
                 {
@@ -912,7 +1084,15 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
                 alpha = alpha < 0.999 ? alpha : 0.999;
                 alpha = alpha > 1e-8 ? alpha : 1e-8;
             }
-            __syncthreads();
+            WAVE_SYNC();
+            PROF_T(tq3);
+            PROF_ADD(6, tq2, tq3);
+        }
+        PROF_T(tu0);
+        if (bad)
+        {
+            status = -2;
+            break;
         }
         // ================= update =================
         applyPrimalStep(c, g, alpha);
@@ -940,7 +1120,9 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
             g.sc3[i] += alpha * g.dsc3[i];
             g.zc3[i] += alpha * g.dzc3[i];
         }
-        __syncthreads();
+        WAVE_SYNC();
+        PROF_T(tu1);
+        PROF_ADD(7, tu0, tu1);
     }
 
     // =============== outputs: readSolution + SC bookkeeping ===============
@@ -948,9 +1130,18 @@ __global__ void __launch_bounds__(WAVE) ipm_kernel(KernelArgs a)
     if (vst)
         sum_delta = st[F_DL];
     sum_delta = wave_sum(sum_delta);
+#ifdef IPM_PROFILE
     if (a.dbg && lane == 0)
     {
-        double *d = a.dbg + size_t(inst) * 8;
+        double *d = a.dbg + size_t(inst) * 32;
+        prof[11] = double(clock64() - t_kernel0);
+        for (int i = 0; i < 12; i++)
+            d[8 + i] = prof[i];
+    }
+#endif
+    if (a.dbg && lane == 0)
+    {
+        double *d = a.dbg + size_t(inst) * 32;
         d[0] = pcost;
         d[1] = gap;
         d[2] = pres;

@@ -294,7 +294,7 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
         rc |= devAlloc(&c->uhat, B * K * 3);
         rc |= devAlloc(&c->wtrx, B);
         rc |= devAlloc(&c->ws, B * ipm::workspaceDoubles(K));
-        rc |= devAlloc(&c->dbg, B * 8);
+        rc |= devAlloc(&c->dbg, B * 32);
     }
     if (rc)
     {
@@ -534,7 +534,7 @@ int scpp_hip_download_socp_info(scpp_hip_ctx *c, double *info)
     if (!c || !info || !c->dbg || c->B < 1)
         return SCPP_E_ARG;
     CHECK_HIP(hipStreamSynchronize(c->stream));
-    CHECK_HIP(hipMemcpy(info, c->dbg, size_t(c->B) * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(info, c->dbg, size_t(c->B) * 32 * sizeof(double), hipMemcpyDeviceToHost));
     return SCPP_OK;
 }
 

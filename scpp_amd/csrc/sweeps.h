@@ -1,0 +1,417 @@
+// Stage sweeps of the block-tridiagonal KKT system on the tile engine (see tile_engine.h for the algebra).
+//   factorSweepFused : factorisation + forward substitution of up to 2 right-hand-side columns
+//   fwdSweep         : forward substitution only (re-uses the stored tiles)
+//   bwdSweep         : backward substitution, writes dw / dlam columns to the field-major records
+// Right-hand sides and solutions live in the field-major stage / segment records.  Column 0 of a 2-column
+// sweep is the sigma BORDER column (beta = 0, rho = -S_k, result to F_BCW / G_BCL); the other column reads
+// beta from stage field fBeta (16 entries) and rho from segment field gRho (14 entries).
+// All sweeps are software-pipelined: the global loads of stage k+1 (k-1) are issued before the dependent
+// MFMA / elimination chain of stage k so that HBM/L2 latency overlaps the chain.
+#pragma once
+#include "tile_engine.h"
+
+namespace scpp
+{
+namespace ipm
+{
+
+struct RhsSpec
+{
+    int n;      // 1: single column ; 2: [border | column]
+    int fBeta;  // stage field of beta
+    int gRho;   // segment field of rho
+    int fOut;   // stage field receiving dw
+    int gOut;   // segment field receiving dlam
+};
+
+// column index of the regular (non-border) column, -1 if this lane's column is unused
+__device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 regular
+{
+    if (sp.n == 2)
+        return i == 0 ? 1 : (i == 1 ? 2 : 0);
+    return i == 0 ? 2 : 0;
+}
+
+__device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+    if (colKind(sp, i) == 2)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            t.v[r] = c.st[size_t(sp.fBeta + g + 4 * r) * LANES + k];
+    }
+    return t;
+}
+__device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+    const int kind = colKind(sp, i);
+    if (kind)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int row = g + 4 * r;
+            if (row < NL)
+                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sg[size_t(sp.gRho * NL + row) * LANES + k];
+        }
+    }
+    return t;
+}
+// border column stores -S: sign applied at use so that the load itself carries no arithmetic
+__device__ inline Tile rhsLSign(const RhsSpec &sp, int lane, const Tile &t)
+{
+    const int i = lane & 15;
+    if (colKind(sp, i) == 1)
+    {
+        Tile o;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            o.v[r] = -t.v[r];
+        return o;
+    }
+    return t;
+}
+__device__ inline void saveCols(double *p, int n, int lane, const Tile &t)
+{
+    const int g = lane >> 4, i = lane & 15;
+    if (i < n)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            p[i * 16 + g + 4 * r] = t.v[r];
+    }
+}
+__device__ inline Tile loadCols(const double *p, int n, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+    if (i < n)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            t.v[r] = p[i * 16 + g + 4 * r];
+    }
+    return t;
+}
+
+__device__ inline Tile tileSub(const Tile &a, const Tile &b)
+{
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = a.v[r] - b.v[r];
+    return t;
+}
+__device__ inline Tile tileAdd(const Tile &a, const Tile &b)
+{
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = a.v[r] + b.v[r];
+    return t;
+}
+
+// ---- raw (arithmetic-free) stage inputs of the factorisation ----
+struct HRaw
+{
+    double e2, cc, wcol, wrow[4], hs[4];
+};
+__device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const SV st{c.st + k};
+    HRaw h;
+    h.e2 = st[F_HC];
+    h.cc = st[F_HC + 1];
+    h.wcol = st[F_WB + 1 + i];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        h.wrow[r] = st[F_WB + 1 + row];
+        const int idx = hsIndex(row, i);
+        h.hs[r] = st[F_HS + (idx >= 0 ? idx : 0)];
+    }
+    return h;
+}
+// H_k (16x16, delta_k eliminated, fixed variables -> identity rows) as a D-layout tile
+__device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned fm = fixedMask(k, K);
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        double v = h.e2 * ((row == i ? 1. : 0.) - h.cc * h.wrow[r] * h.wcol);
+        if (hsIndex(row, i) >= 0)
+            v += h.hs[r];
+        if ((fm & (1u << row)) || (fm & (1u << i)))
+            v = (row == i) ? 1. : 0.;
+        t.v[r] = v;
+    }
+    return t;
+}
+// raw entries of [A|B] / C arranged for the M' and N tiles (mask and sign applied at use)
+__device__ inline Tile loadMtRaw(const Ctx &c, int k, int lane) // entry (var j = g+4r, dyn row i)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+    if (i < NL)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int j = g + 4 * r;
+            t.v[r] = j < 13 ? c.A[size_t(k) * NX * NX + i * NX + j] : c.B[size_t(k) * NX * NU + i * NU + (j - 13)];
+        }
+    }
+    return t;
+}
+__device__ inline Tile finishMt(const Tile &raw, unsigned fm, int lane)
+{
+    const int g = lane >> 4;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = (fm & (1u << (g + 4 * r))) ? 0. : -raw.v[r];
+    return t;
+}
+__device__ inline Tile loadNRaw(const Ctx &c, int k, int lane) // entry (dyn row g+4r, var i): only the C part is loaded
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+    if (i >= 13)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int row = g + 4 * r;
+            if (row < NL)
+                t.v[r] = c.C[size_t(k) * NX * NU + row * NU + (i - 13)];
+        }
+    }
+    return t;
+}
+__device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        double v = 0.;
+        if (row < NL && !(fmn & (1u << i)))
+            v = i < 13 ? (row == i ? 1. : 0.) : -raw.v[r];
+        t.v[r] = v;
+    }
+    return t;
+}
+
+struct FactorIn
+{
+    HRaw h;
+    Tile mt, n, rl, rwn;
+    double einv;
+};
+__device__ inline FactorIn loadFactorIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+{
+    const int i = lane & 15;
+    FactorIn f;
+    f.h = loadHRaw(c, k, lane);
+    if (k < c.K - 1)
+    {
+        f.mt = loadMtRaw(c, k, lane);
+        f.n = loadNRaw(c, k, lane);
+        f.rl = loadRhsL(c, sp, k, lane);
+        f.rwn = loadRhsW(c, sp, k + 1, lane);
+        f.einv = c.sg[size_t(G_EINV * NL + (i < NL ? i : 0)) * LANES + k];
+    }
+    else
+    {
+        f.mt = f.n = f.rl = f.rwn = tileZero();
+        f.einv = 1.;
+    }
+    return f;
+}
+
+__device__ __attribute__((noinline)) void factorSweepFused(const Ctx &c, TileShared &sh, const RhsSpec &sp)
+{
+    const int lane = c.lane, K = c.K;
+    const int g = lane >> 4, i = lane & 15;
+    Tile Z = tileZero(), G = loadRhsW(c, sp, 0, lane);
+    FactorIn cur = loadFactorIn(c, sp, 0, lane);
+    for (int k = 0; k < K; k++)
+    {
+        FactorIn nxt = cur;
+        if (k + 1 < K)
+            nxt = loadFactorIn(c, sp, k + 1, lane); // prefetch: overlaps the elimination chain below
+        double *fk = c.fac + size_t(k) * FACREC;
+        double *svk = c.sv + size_t(k) * SVREC;
+        Tile Phi = buildHTile(cur.h, k, K, lane);
+        if (k > 0)
+            Phi = tileAdd(Phi, mm(Z, Z));
+        const Tile Li = invCholFactor<NV>(Phi, sh, lane);
+        storeTile(fk, lane, Li);
+        const Tile Lit = transposeTile(Li, sh, lane);
+        const Tile a = mm(Lit, G);
+        saveCols(svk, sp.n, lane, a);
+        if (k == K - 1)
+            break;
+        const unsigned fm = fixedMask(k, K), fmn = fixedMask(k + 1, K);
+        const Tile Yt = mm(Lit, finishMt(cur.mt, fm, lane));
+        storeTile(fk + 256, lane, Yt);
+        Tile Th = mm(Yt, Yt);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int row = g + 4 * r;
+            if (row == i)
+                Th.v[r] = (row < NL) ? Th.v[r] + cur.einv : 1.;
+        }
+        const Tile Ti = invCholFactor<NL>(Th, sh, lane);
+        storeTile(fk + 512, lane, Ti);
+        const Tile Tit = transposeTile(Ti, sh, lane);
+        Z = mm(Tit, finishN(cur.n, fmn, lane));
+        storeTile(fk + 768, lane, Z);
+        const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(Yt, a));
+        const Tile cc = mm(Tit, gl);
+        saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
+        G = tileAdd(cur.rwn, mm(Z, cc));
+        cur = nxt;
+    }
+    WAVE_SYNC();
+}
+
+struct FwdIn
+{
+    Tile lit, yt, tit, z, rl, rwn;
+};
+__device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+{
+    const double *fk = c.fac + size_t(k) * FACREC;
+    FwdIn f;
+    f.lit = loadTileT(fk, lane);
+    if (k < c.K - 1)
+    {
+        f.yt = loadTile(fk + 256, lane);
+        f.tit = loadTileT(fk + 512, lane);
+        f.z = loadTile(fk + 768, lane);
+        f.rl = loadRhsL(c, sp, k, lane);
+        f.rwn = loadRhsW(c, sp, k + 1, lane);
+    }
+    else
+        f.yt = f.tit = f.z = f.rl = f.rwn = tileZero();
+    return f;
+}
+__device__ __attribute__((noinline)) void fwdSweep(const Ctx &c, const RhsSpec &sp)
+{
+    const int lane = c.lane, K = c.K;
+    Tile G = loadRhsW(c, sp, 0, lane);
+    FwdIn cur = loadFwdIn(c, sp, 0, lane);
+    for (int k = 0; k < K; k++)
+    {
+        FwdIn nxt = cur;
+        if (k + 1 < K)
+            nxt = loadFwdIn(c, sp, k + 1, lane);
+        double *svk = c.sv + size_t(k) * SVREC;
+        const Tile a = mm(cur.lit, G);
+        saveCols(svk, sp.n, lane, a);
+        if (k == K - 1)
+            break;
+        const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(cur.yt, a));
+        const Tile cc = mm(cur.tit, gl);
+        saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
+        G = tileAdd(cur.rwn, mm(cur.z, cc));
+        cur = nxt;
+    }
+    WAVE_SYNC();
+}
+
+__device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &x)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const int kind = colKind(sp, i);
+    if (kind)
+    {
+        const int f = kind == 1 ? int(F_BCW) : sp.fOut;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            c.st[size_t(f + g + 4 * r) * LANES + k] = x.v[r];
+    }
+}
+__device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &l)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const int kind = colKind(sp, i);
+    if (kind)
+    {
+        const int f = kind == 1 ? int(G_BCL) : sp.gOut;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int row = g + 4 * r;
+            if (row < NL)
+                c.sg[size_t(f * NL + row) * LANES + k] = l.v[r];
+        }
+    }
+}
+
+struct BwdIn
+{
+    Tile zt, ti, y, li, cs, as;
+};
+__device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+{
+    const double *fk = c.fac + size_t(k) * FACREC;
+    const double *svk = c.sv + size_t(k) * SVREC;
+    BwdIn b;
+    b.li = loadTile(fk, lane);
+    b.as = loadCols(svk, sp.n, lane);
+    if (k < c.K - 1)
+    {
+        b.zt = loadTileT(fk + 768, lane);
+        b.ti = loadTile(fk + 512, lane);
+        b.y = loadTileT(fk + 256, lane);
+        b.cs = loadCols(svk + NRHS_MAX * 16, sp.n, lane);
+    }
+    else
+        b.zt = b.ti = b.y = b.cs = tileZero();
+    return b;
+}
+__device__ __attribute__((noinline)) void bwdSweep(const Ctx &c, const RhsSpec &sp)
+{
+    const int lane = c.lane, K = c.K;
+    BwdIn cur = loadBwdIn(c, sp, K - 1, lane);
+    Tile x = tileZero();
+    for (int k = K - 1; k >= 0; k--)
+    {
+        BwdIn nxt = cur;
+        if (k > 0)
+            nxt = loadBwdIn(c, sp, k - 1, lane);
+        if (k == K - 1)
+        {
+            x = mm(cur.li, cur.as); // Li' a = L^-T a
+        }
+        else
+        {
+            const Tile t = tileSub(mm(cur.zt, x), cur.cs); // Z x' - c
+            const Tile lam = mm(cur.ti, t);                 // Ti' t = T^-T t
+            const Tile s = tileSub(cur.as, mm(cur.y, lam)); // a - Y' lam
+            x = mm(cur.li, s);
+            storeSolL(c, sp, k, lane, lam);
+        }
+        storeSolW(c, sp, k, lane, x);
+        cur = nxt;
+    }
+    WAVE_SYNC();
+}
+
+} // namespace ipm
+} // namespace scpp

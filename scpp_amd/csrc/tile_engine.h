@@ -1,0 +1,230 @@
+// Register-resident 16x16 FP64 tile engine for the block-tridiagonal KKT sweeps of ipm_kernel.
+//
+// A tile lives in the MFMA C/D layout of v_mfma_f64_16x16x4_f64 ("D-layout"): lane l = (g = l>>4, i = l&15)
+// holds T[g + 4r][i] in register r = 0..3.  With that layout the product X'Y of two tiles is FOUR matrix-core
+// instructions straight from registers (operand r of both tiles feeds MFMA r; contraction index g + 4r), and
+// the result is again a D-layout tile -- so every stage operation of the factorisation and of the
+// substitution sweeps is expressed as X'Y:
+//   Yt = Li M' = mm(Lit, Mt)     Theta = E^-1 + Yt'Yt = mm(Yt, Yt)     Z = Ti N = mm(Tit, N)     Phi' = H' + mm(Z, Z)
+//   forward :  a = mm(Lit, g)   gl = rho - mm(Yt, a)   c = mm(Tit, gl)   g' = beta' + mm(Z, c)       (multi-RHS columns)
+//   backward:  t = mm(Zt, x') - c   lam = mm(Ti, t)   s = a - mm(Y, lam)   x = mm(Li, s)
+// Only the two inverse Cholesky factors per stage (Li = chol(Phi)^-1, Ti = chol(Theta)^-1) are not MFMA work:
+// they are computed by Gaussian elimination on [A | I] (rank-1 updates of both tiles, all 64 lanes busy, the
+// pivot column / row exchanged through 2 x 16 doubles of LDS).  Scalar twin: oracle/structured_ipm.hpp.
+#pragma once
+#include "ipm_kernel.h"
+
+namespace scpp
+{
+namespace ipm
+{
+
+struct Tile
+{
+    double v[4];
+};
+
+__device__ inline Tile tileZero()
+{
+    Tile t;
+    t.v[0] = t.v[1] = t.v[2] = t.v[3] = 0.;
+    return t;
+}
+
+// X'Y on the FP64 matrix core (4 x v_mfma_f64_16x16x4_f64), optionally accumulating into C
+__device__ inline Tile mm(const Tile &X, const Tile &Y)
+{
+    d4_t acc = {0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X.v[r], Y.v[r], acc, 0, 0, 0);
+    Tile t;
+    t.v[0] = acc[0];
+    t.v[1] = acc[1];
+    t.v[2] = acc[2];
+    t.v[3] = acc[3];
+    return t;
+}
+
+// row-major 16x16 global tile <-> D-layout registers
+__device__ inline Tile loadTile(const double *p, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = p[(g + 4 * r) * 16 + i];
+    return t;
+}
+__device__ inline Tile loadTileT(const double *p, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = p[i * 16 + (g + 4 * r)];
+    return t;
+}
+__device__ inline void storeTile(double *p, int lane, const Tile &t)
+{
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        p[(g + 4 * r) * 16 + i] = t.v[r];
+}
+
+// dynamics coupling tiles of segment k
+__device__ inline Tile loadM(const Ctx &c, int k, unsigned fm, int lane) // M[row][var]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        t.v[r] = row < NL ? Ment(c, k, fm, row, i) : 0.;
+    }
+    return t;
+}
+__device__ inline Tile loadMt(const Ctx &c, int k, unsigned fm, int lane) // M'[var][row]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = i < NL ? Ment(c, k, fm, i, g + 4 * r) : 0.;
+    return t;
+}
+__device__ inline Tile loadN(const Ctx &c, int k, unsigned fmn, int lane) // N[row][var]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        t.v[r] = row < NL ? Nent(c, k, fmn, row, i) : 0.;
+    }
+    return t;
+}
+
+struct TileShared
+{
+    double colA[2][16];
+    double rowR[2][16];
+    double od[16];
+    double pv[16];
+    double tr[16 * 17]; // transpose scratch
+};
+
+// transpose a D-layout tile through LDS
+__device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        sh.tr[(g + 4 * r) * 17 + i] = t.v[r];
+    WAVE_SYNC();
+    Tile o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.v[r] = sh.tr[i * 17 + (g + 4 * r)];
+    return o;
+}
+
+// Li = chol(A)^-1 (lower triangular, D-layout) of the SPD leading n x n block of tile A; rows/cols >= n: identity.
+// Fully unrolled, branch-free elimination: per step ONE LDS turnaround (publish pivot column of A and pivot row
+// of R, read the 7 values this lane needs in one batch), one reciprocal, 8 predicated FMAs.
+template <int n>
+__device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile R;
+    double od = 0.;     // original diagonal entry of MY column (for the pivot floor)
+    double pvr[4];      // pivots of my rows
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        R.v[r] = (g + 4 * r == i) ? 1. : 0.;
+        pvr[r] = 1.;
+        od = (g + 4 * r == i) ? A.v[r] : od;
+    }
+    // every lane of column i learns A[i][i]: lanes (g', i) with g' = i & 3 hold it -> publish once
+    WAVE_SYNC();
+    if (g == (i & 3))
+        sh.od[i] = od;
+    WAVE_SYNC();
+#pragma unroll 1
+    for (int j = 0; j < n; j++)
+    {
+        const int b = j & 1;
+        if (i == j)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                sh.colA[b][g + 4 * r] = A.v[r];
+        }
+        if (g == (j & 3))
+            { const int rj_ = j >> 2; sh.rowR[b][i] = rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3]; }
+        WAVE_SYNC();
+        // one batch of LDS reads (no control flow in between)
+        double d = sh.colA[b][j];
+        const double orig = sh.od[j];
+        const double aj = sh.colA[b][i];
+        const double rj = sh.rowR[b][i];
+        double cr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            cr[r] = sh.colA[b][g + 4 * r];
+        d = (d > 1e-14 * orig) ? d : 1e-14 * orig;
+        const double p = 1. / d;
+        const double ajm = (i > j) ? aj : 0.;
+        const double rjm = (i > j) ? 0. : rj;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int row = g + 4 * r;
+            const double m = (row > j && row < n) ? cr[r] * p : 0.;
+            A.v[r] -= m * ajm;
+            R.v[r] -= m * rjm;
+            pvr[r] = (row == j) ? d : pvr[r];
+        }
+    }
+    Tile Li;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        if (row < n)
+            Li.v[r] = (i <= row) ? R.v[r] / sqrt(pvr[r]) : 0.;
+        else
+            Li.v[r] = (i == row) ? 1. : 0.;
+    }
+    return Li;
+}
+
+// index of H entry (va, vb) inside the stage's small-block record, or -1
+//   block 1: vars {1,2,3} (glide slope)      offset 0  (3x3)
+//   block 2: vars {8,9}   (tilt)             offset 9  (2x2)
+//   block 3: vars {11,12} (angular rate)     offset 13 (2x2)
+//   block 4: vars {13,14,15} (thrust cones + min-thrust row) offset 17 (3x3)
+//   block 5: var {0} (mass row)              offset 26
+constexpr int HS_N = 27;
+__device__ inline int hsIndex(int a, int b)
+{
+    if (a >= 1 && a <= 3 && b >= 1 && b <= 3)
+        return (a - 1) * 3 + (b - 1);
+    if (a >= 8 && a <= 9 && b >= 8 && b <= 9)
+        return 9 + (a - 8) * 2 + (b - 8);
+    if (a >= 11 && a <= 12 && b >= 11 && b <= 12)
+        return 13 + (a - 11) * 2 + (b - 11);
+    if (a >= 13 && b >= 13)
+        return 17 + (a - 13) * 3 + (b - 13);
+    if (a == 0 && b == 0)
+        return 26;
+    return -1;
+}
+
+} // namespace ipm
+} // namespace scpp

@@ -328,3 +328,4 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
     return 0;
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+inline long long clock64() { return 0; }

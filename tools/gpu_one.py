@@ -1,0 +1,16 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, scpp_amd, oracle_lib as O
+lib = os.path.abspath(sys.argv[1]); B = 4
+m = scpp_amd.RocketQuat().loadParameters()
+alg = scpp_amd.SCAlgorithm(m, K=50, batch_max=B, library=lib).initialize()
+x0 = m.randomized_initial_states(B)
+alg.ctx.sc_setup(m.p, alg.opts, x0); alg.ctx.sc_iterate()
+np.set_printoptions(linewidth=200, precision=4)
+print(alg.ctx.socp_info()[:, :8])
+out = alg.ctx.download()
+for b in range(B):
+    sc = O.SC(0, K=50); sc.randomize(20260927, b); sc.set_solver(1); sc.solve()
+    X1, U1, t1 = sc.iterate(1); inf = sc.info()[0]
+    print(b, 'oracle ipm', inf[4], 'gpu ipm', out['ipm_iters'][b], 'dX', np.abs(out['X'][b]-X1).max(), 'status', out['status'][b])

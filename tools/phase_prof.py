@@ -1,0 +1,21 @@
+"""In-kernel phase timing of ipm_kernel (library built with -DIPM_PROFILE): cycles per phase, one SC iteration."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import scpp_amd
+lib = sys.argv[1]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+m = scpp_amd.RocketQuat().loadParameters()
+alg = scpp_amd.SCAlgorithm(m, K=50, batch_max=B, library=os.path.abspath(lib)).initialize()
+x0 = m.randomized_initial_states(B)
+alg.ctx.sc_setup(m.p, alg.opts, x0)
+alg.ctx.sc_iterate()
+info = alg.ctx.socp_info()
+names = ["init", "residuals", "scalings", "  factorFused(in 5)", "rhs(t,bx)+kktPrep", "sweeps+kktFinish", "dz/ds/step", "update", "prepareFactor", "  bwdSweeps(in 5)", "  fwdSweep(in 5)", "kernel_total"]
+it = info[:, 4].mean()
+p = info[:, 8:20].mean(axis=0)
+print(f"B={B} mean ipm iters {it:.1f}; cycles are 100 MHz s_memtime ticks? (raw counts)")
+for n, v in zip(names, p):
+    if n != "-":
+        print(f"  {n:14s} total {v:14.0f}   per-iter {v / it:12.0f}   share {100 * v / p[11]:5.1f}%")
+print(alg.ctx.timing())
