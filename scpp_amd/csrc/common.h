@@ -31,6 +31,25 @@ constexpr int WAVE = 64;
     } while (0)
 #endif
 
+// A pointer that is the same in every lane, re-materialised as an SGPR pair in the GLOBAL address space.
+// Out-of-line device functions receive their arguments in VGPRs / through private memory, where the
+// compiler must assume divergence (waterfall loops around buffer accesses) and generic addressing (flat_*).
+#ifdef SCPP_HIP_EMU
+template <class T>
+inline T *uniformPtr(T *p) { return p; }
+inline int uniformInt(int v) { return v; }
+#else
+template <class T>
+__device__ __forceinline__ T *uniformPtr(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+    typedef __attribute__((address_space(1))) T *gptr_t;
+    return (T *)(gptr_t)((unsigned long long)(hi) << 32 | lo);
+}
+__device__ __forceinline__ int uniformInt(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1)

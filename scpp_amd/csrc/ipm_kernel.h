@@ -140,13 +140,42 @@ constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) p
 constexpr int LANES = 64;
 __host__ __device__ inline size_t workspaceDoubles(int K) { return size_t(LANES) * STREC + size_t(LANES) * SEGREC + size_t(K) * (FACREC + SVREC); }
 
-// strided view of one lane's record
+// Strided view of one lane's record, addressed through a buffer resource: every access is
+//   buffer_load/store_dwordx2 v, v_lane_byte_offset, s[rsrc:rsrc+3], s_field_offset offen
+// i.e. ONE 32-bit VGPR (lane*8) serves all fields and the field offsets live in SGPRs.  (Plain global
+// pointers made the compiler keep ~70 loop-invariant 64-bit VGPR addresses -- one per 4 KB window of the
+// field-major record -- and spill them.)
+typedef unsigned int u32x2_t __attribute__((vector_size(8)));
 struct SV
 {
-    double *p;
-    __device__ double &operator[](int i) const { return p[size_t(i) * LANES]; }
-    __device__ SV operator+(int o) const { return SV{p + size_t(o) * LANES}; }
+    __amdgpu_buffer_rsrc_t rsrc; // wave-uniform: the instance's stage or segment record block
+    int lb;                      // lane offset in bytes
+    int fo;                      // field offset (doubles)
+    struct Ref
+    {
+        __amdgpu_buffer_rsrc_t rsrc;
+        int lb, so;
+        __device__ operator double() const
+        {
+            return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lb, so, 0));
+        }
+        __device__ const Ref &operator=(double x) const
+        {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), rsrc, lb, so, 0);
+            return *this;
+        }
+        __device__ const Ref &operator=(const Ref &o) const { return *this = double(o); }
+        __device__ const Ref &operator+=(double x) const { return *this = double(*this) + x; }
+        __device__ const Ref &operator-=(double x) const { return *this = double(*this) - x; }
+        __device__ const Ref &operator*=(double x) const { return *this = double(*this) * x; }
+    };
+    __device__ Ref operator[](int i) const { return Ref{rsrc, lb, (fo + i) * (LANES * 8)}; }
+    __device__ SV operator+(int o) const { return SV{rsrc, lb, fo + o}; }
 };
+__device__ inline SV makeSV(double *block, int nfields, unsigned lane_index)
+{
+    return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, nfields * LANES * 8, 0x00020000), int(lane_index * 8u), 0};
+}
 
 struct Settings
 {
@@ -371,7 +400,7 @@ __device__ inline void addConeHs(double *Hs, double eta, AW w, int d, const int 
 __device__ inline void buildHs(const Ctx &c, int k, bool identity)
 {
     const unsigned fm = fixedMask(k, c.K), act = activeMask(k, c.K);
-    const SV st{c.st + k};
+    const SV st = makeSV(c.st, STREC, unsigned(k));
     const SV eta = st + F_ETA, wb = st + F_WB, uh = st + F_UHAT;
     double Hs[27];
     for (int i = 0; i < 27; i++)

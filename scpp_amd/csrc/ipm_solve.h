@@ -54,7 +54,7 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     const int k = c.lane, K = c.K;
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             if (identity)
@@ -100,7 +100,7 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
     g.dz3 = -b.n1;
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             const double d1 = dLP(identity, sg[G_S1 * NL + i], sg[G_Z1 * NL + i]);
@@ -115,7 +115,7 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
     }
     if (k < K)
     {
-        const SV st{c.st + k};
+        const SV st = makeSV(c.st, STREC, unsigned(k));
         const unsigned fm = fixedMask(k, K);
         for (int j = 0; j < NV; j++)
             st[fBeta + j] = (fm & (1u << j)) ? 0. : st[F_BXW + j] - st[F_HDW + j] * st[F_BXD] / st[F_HDD];
@@ -150,7 +150,7 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st{c.st + k};
+        const SV st = makeSV(c.st, STREC, unsigned(k));
         double acc = 0.;
         for (int j = 0; j < NV; j++)
         {
@@ -162,7 +162,7 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     }
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             const double dl = sg[gVL * NL + i] - sg[G_BCL * NL + i] * g.dsig;
@@ -205,16 +205,19 @@ __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
     const int k = c.lane, K = c.K;
     if (k < K)
     {
-        const SV st{c.st + k};
+        const SV st = makeSV(c.st, STREC, unsigned(k));
         const unsigned fm = fixedMask(k, K);
+#pragma unroll
         for (int j = 0; j < NV; j++)
-            if (!(fm & (1u << j)))
-                st[F_W + j] += alpha * st[F_DW + j];
+        {
+            const double d = st[F_DW + j];
+            st[F_W + j] += (fm & (1u << j)) ? 0. : alpha * d;
+        }
         st[F_DL] += alpha * st[F_DDL];
     }
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             sg[G_NU * NL + i] += alpha * sg[G_DNU * NL + i];
@@ -233,12 +236,12 @@ __device__ inline void evalAllSaff(const Ctx &c, const Glob &g, int fOut, int g1
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st{c.st + k};
+        const SV st = makeSV(c.st, STREC, unsigned(k));
         saff(c.ip, activeMask(k, K), st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, st + fOut);
     }
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
@@ -263,7 +266,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        const SV v = SV{c.st + k} + f;
+        const SV v = makeSV(c.st, STREC, unsigned(k)) + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
             {
@@ -282,7 +285,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
@@ -305,7 +308,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        const SV v = SV{c.st + k} + f;
+        const SV v = makeSV(c.st, STREC, unsigned(k)) + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
                 v[coneOff(cix)] += alpha;
@@ -316,7 +319,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        const SV sg{c.sg + k};
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
         for (int i = 0; i < NL; i++)
         {
             sg[g1 * NL + i] += alpha;
@@ -475,15 +478,18 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.S = a.S + size_t(inst) * (K - 1) * NX;
     c.Z = a.Z + size_t(inst) * (K - 1) * NX;
     c.ip = a.ip + size_t(inst) * IP_N;
+    // the out-of-line sweeps take the context by reference; give them their own copy so that `c` never
+    // escapes and its pointers stay in SGPRs for the inlined lane=stage phases
+    Ctx cesc = c;
     const double *ip = c.ip;
     const double wtrx = a.wtrx[inst];
     const double w_t = ip[IP_WT], w_trt = ip[IP_WTRT], w_vc = ip[IP_WVC];
     const double sigbar = a.sigma[inst];
     const Settings opt = a.opt;
     const unsigned fm = (k < K) ? fixedMask(k, K) : 0u, act = (k < K) ? activeMask(k, K) : 0u;
-    const SV st{c.st + (k < K ? k : 0)};
-    const SV stN{c.st + (k < K - 1 ? k + 1 : 0)}; // next stage's record
-    const SV sg{c.sg + (k < K - 1 ? k : 0)};
+    const SV st = makeSV(c.st, STREC, unsigned(k < K ? k : 0));
+    const SV stN = makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0)); // next stage's record
+    const SV sg = makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0));
     const bool vst = k < K, vsg = k < K - 1;
 
     Glob g;
@@ -585,8 +591,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
         WAVE_SYNC();
         const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-        factorSweepFused(c, sh, sp);
-        bwdSweep(c, sp);
+        factorSweepFused(cesc, sh, sp);
+        bwdSweep(cesc, sp);
         borderSchur(c, g);
         kktFinish(c, true, g, b, bts, F_VW, G_VL);
         PROF_T(tp1);
@@ -619,8 +625,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
         WAVE_SYNC();
         const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-        fwdSweep(c, sp);
-        bwdSweep(c, sp);
+        fwdSweep(cesc, sp);
+        bwdSweep(cesc, sp);
         kktFinish(c, true, g, b, bts, F_VW, G_VL);
         if (vst)
         {
@@ -719,7 +725,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             if (k > 0)
                 for (int i = 0; i < NL; i++)
                 {
-                    const double l = SV{c.sg + k - 1}[G_LAM * NL + i];
+                    const double l = makeSV(c.sg, SEGREC, unsigned(k - 1))[G_LAM * NL + i];
                     for (int j = 0; j < NV; j++)
                         r[j] += Nent(c, k - 1, fm, i, j) * l;
                 }
@@ -952,10 +958,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
                 // column and of the affine right-hand side
                 const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-                factorSweepFused(c, sh, sp);
+                factorSweepFused(cesc, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
-                bwdSweep(c, sp);
+                bwdSweep(cesc, sp);
                 borderSchur(c, g);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
@@ -963,10 +969,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             else
             {
                 const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-                fwdSweep(c, sp);
+                fwdSweep(cesc, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
-                bwdSweep(c, sp);
+                bwdSweep(cesc, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }

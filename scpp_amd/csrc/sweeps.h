@@ -15,6 +15,30 @@ namespace scpp
 namespace ipm
 {
 
+#ifndef SWEEPS_INLINE
+#define SWEEP_FN __device__ __attribute__((noinline))
+#else
+#define SWEEP_FN __device__ inline __attribute__((always_inline))
+#endif
+
+// re-establish wave-uniformity of the context inside an out-of-line sweep
+__device__ inline Ctx uniformCtx(const Ctx &cin)
+{
+    Ctx c;
+    c.K = uniformInt(cin.K);
+    c.lane = threadIdx.x;
+    c.st = uniformPtr(cin.st);
+    c.sg = uniformPtr(cin.sg);
+    c.fac = uniformPtr(cin.fac);
+    c.sv = uniformPtr(cin.sv);
+    c.A = uniformPtr(cin.A);
+    c.B = uniformPtr(cin.B);
+    c.C = uniformPtr(cin.C);
+    c.S = uniformPtr(cin.S);
+    c.Z = uniformPtr(cin.Z);
+    c.ip = uniformPtr(cin.ip);
+    return c;
+}
 struct RhsSpec
 {
     int n;      // 1: single column ; 2: [border | column]
@@ -23,6 +47,17 @@ struct RhsSpec
     int fOut;   // stage field receiving dw
     int gOut;   // segment field receiving dlam
 };
+
+__device__ inline RhsSpec uniformSpec(const RhsSpec &s)
+{
+    RhsSpec o;
+    o.n = uniformInt(s.n);
+    o.fBeta = uniformInt(s.fBeta);
+    o.gRho = uniformInt(s.gRho);
+    o.fOut = uniformInt(s.fOut);
+    o.gOut = uniformInt(s.gOut);
+    return o;
+}
 
 // column index of the regular (non-border) column, -1 if this lane's column is unused
 __device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 regular
@@ -123,7 +158,7 @@ struct HRaw
 __device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
-    const SV st{c.st + k};
+    const SV st = makeSV(c.st, STREC, unsigned(k));
     HRaw h;
     h.e2 = st[F_HC];
     h.cc = st[F_HC + 1];
@@ -241,8 +276,10 @@ __device__ inline FactorIn loadFactorIn(const Ctx &c, const RhsSpec &sp, int k, 
     return f;
 }
 
-__device__ __attribute__((noinline)) void factorSweepFused(const Ctx &c, TileShared &sh, const RhsSpec &sp)
+SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &spin)
 {
+    const Ctx c = uniformCtx(cin);
+    const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     const int g = lane >> 4, i = lane & 15;
     Tile Z = tileZero(), G = loadRhsW(c, sp, 0, lane);
@@ -310,8 +347,10 @@ __device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
         f.yt = f.tit = f.z = f.rl = f.rwn = tileZero();
     return f;
 }
-__device__ __attribute__((noinline)) void fwdSweep(const Ctx &c, const RhsSpec &sp)
+SWEEP_FN void fwdSweep(const Ctx &cin, const RhsSpec &spin)
 {
+    const Ctx c = uniformCtx(cin);
+    const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     Tile G = loadRhsW(c, sp, 0, lane);
     FwdIn cur = loadFwdIn(c, sp, 0, lane);
@@ -385,8 +424,10 @@ __device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
         b.zt = b.ti = b.y = b.cs = tileZero();
     return b;
 }
-__device__ __attribute__((noinline)) void bwdSweep(const Ctx &c, const RhsSpec &sp)
+SWEEP_FN void bwdSweep(const Ctx &cin, const RhsSpec &spin)
 {
+    const Ctx c = uniformCtx(cin);
+    const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     BwdIn cur = loadBwdIn(c, sp, K - 1, lane);
     Tile x = tileZero();

@@ -248,6 +248,33 @@ inline d4_t __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, d4_t c, int
     return d;
 }
 
+// ---- buffer resources (raw, stride 0): base + voffset + soffset, out-of-range loads return 0, stores are dropped ----
+struct hipemu_rsrc
+{
+    char *base;
+    unsigned nbytes;
+};
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+typedef unsigned int hipemu_u32x2 __attribute__((vector_size(8)));
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int num_records, int)
+{
+    return hipemu_rsrc{reinterpret_cast<char *>(p), unsigned(num_records)};
+}
+inline hipemu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int)
+{
+    hipemu_u32x2 v = {0u, 0u};
+    const unsigned o = unsigned(voffset) + unsigned(soffset);
+    if (o + 8u <= r.nbytes)
+        std::memcpy(&v, r.base + o, 8);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int)
+{
+    const unsigned o = unsigned(voffset) + unsigned(soffset);
+    if (o + 8u <= r.nbytes)
+        std::memcpy(r.base + o, &v, 8);
+}
+
 // ---- host runtime shim ----
 typedef int hipError_t;
 typedef void *hipStream_t;
