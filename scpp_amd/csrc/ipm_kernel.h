@@ -138,7 +138,12 @@ constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) p
 // Stage / segment records are stored FIELD-major: element f of stage k lives at st[f*64 + k], so that the
 // lane == stage phases read and write fully coalesced 512-byte rows (one lane per stage).
 constexpr int LANES = 64;
-__host__ __device__ inline size_t workspaceDoubles(int K) { return size_t(LANES) * STREC + size_t(LANES) * SEGREC + size_t(K) * (FACREC + SVREC); }
+// field-major copy of the segment dynamics (A 14x14, B 14x4, C 14x4, s, z) for the lane = segment phases
+constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX; // 336
+__host__ __device__ inline size_t workspaceDoubles(int K)
+{
+    return size_t(LANES) * STREC + size_t(LANES) * SEGREC + size_t(LANES) * DYNREC + size_t(K) * (FACREC + SVREC);
+}
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is
 //   buffer_load/store_dwordx2 v, v_lane_byte_offset, s[rsrc:rsrc+3], s_field_offset offen
@@ -190,6 +195,7 @@ struct Ctx
     int K, lane;
     double *st;  // [STREC][64]   field-major
     double *sg;  // [SEGREC][64]  field-major
+    double *dy;  // [DYNREC][64]  field-major copy of A,B,C,s,z
     double *fac; // [K][FACREC]
     double *sv;  // [K][SVREC]
     const double *A, *B, *C, *S, *Z; // dd of this instance
@@ -319,6 +325,30 @@ __device__ inline void dynRes(const Ctx &c, int k, A0 w0, A1 w1, AN nuv, double 
             acc -= A[i * NX + j] * w0[j];
         for (int j = 0; j < 3; j++)
             acc -= B[i * NU + j] * w0[13 + j] + C[i * NU + j] * w1[13 + j];
+        out[i] = acc;
+    }
+}
+// same on the field-major copy (coalesced, fully unrolled: all loads of a row are in flight together)
+template <class A0, class A1, class AN>
+__device__ inline void dynResF(const SV &dy, A0 w0, A1 w1, AN nuv, double sig, double *out)
+{
+    double x0[NV], u1[3];
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+        x0[j] = w0[j];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        u1[j] = w1[13 + j];
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+    {
+        double acc = stageX(w1, i) - dy[DY_S + i] * sig - nuv[i] - dy[DY_Z + i];
+#pragma unroll
+        for (int j = 0; j < 13; j++)
+            acc -= dy[DY_A + i * NX + j] * x0[j];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            acc -= dy[DY_B + i * NU + j] * x0[13 + j] + dy[DY_C + i * NU + j] * u1[j];
         out[i] = acc;
     }
 }

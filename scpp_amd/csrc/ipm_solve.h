@@ -441,6 +441,825 @@ __device__ inline void zeroT(const SV &st)
         st[F_TZ + OFF + i] = 0.;
 }
 
+
+// =====================================================================================================
+// The solver is split into OUT-OF-LINE phases.  Each phase gets its own register allocation (the monolithic
+// kernel kept >1000 values alive and spilled inside every hot loop); what survives a phase boundary lives in
+// the field-major records (global memory) or in the two small wave-uniform structs Glob / Iter, which the
+// kernel keeps in private memory and every phase copies in and out.
+// =====================================================================================================
+#ifdef SCPP_HIP_EMU
+#define PRIV
+#define PHASE_FN inline
+#else
+#define PRIV __attribute__((address_space(5)))
+#define PHASE_FN __device__ __attribute__((noinline))
+#endif
+
+// wave-uniform state of one solve
+struct Iter
+{
+    double wtrx, w_t, w_trt, w_vc, sigbar, gamma;
+    double resx0, resy0, resz0;
+    double mu, gap, pres, dres, pcost;
+    double rzs, rz3, rzc[3], rxs, rxds, rxn1;
+    double sigma_c, alpha, tzs, tzc[3];
+    Rhs b;
+    double bts;
+    int D, bad;
+};
+
+template <class T>
+__device__ inline T loadPriv(const PRIV T *p)
+{
+    T t;
+    __builtin_memcpy(&t, p, sizeof(T));
+    return t;
+}
+template <class T>
+__device__ inline void storePriv(PRIV T *p, const T &t)
+{
+    __builtin_memcpy(p, &t, sizeof(T));
+}
+
+// lane-local views used by every phase
+struct Views
+{
+    int k, K;
+    bool vst, vsg;
+    unsigned fm, act;
+    SV st, stN, sg, sgP, dy, dyP;
+};
+__device__ inline Views makeViews(const Ctx &c)
+{
+    const int k = c.lane, K = c.K;
+    Views v{k,
+            K,
+            k < K,
+            k < K - 1,
+            (k < K) ? fixedMask(k, K) : 0u,
+            (k < K) ? activeMask(k, K) : 0u,
+            makeSV(c.st, STREC, unsigned(k < K ? k : 0)),
+            makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0)),
+            makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0)),
+            makeSV(c.sg, SEGREC, unsigned(k > 0 && k < K ? k - 1 : 0)),
+            makeSV(c.dy, DYNREC, unsigned(k < K - 1 ? k : 0)),
+            makeSV(c.dy, DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0))};
+    return v;
+}
+
+// ---- setup: clear records, field-major copy of the dynamics, trust-region centre, fixed values ----
+PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const double *X = uniformPtr(Xin), *U = uniformPtr(Uin), *uhat = uniformPtr(uhatIn);
+    const Views v = makeViews(c);
+    const int k = v.k, K = v.K;
+    const SV &st = v.st, &sg = v.sg, &dy = v.dy;
+    const double *ip = c.ip;
+    Glob g;
+    Iter it = loadPriv(ip_);
+    g.sig = g.dsg = g.n1 = 0.;
+    g.sigbar = it.sigbar;
+    g.ss = g.zs = g.s3 = g.z3 = 1.;
+    for (int i = 0; i < 3; i++)
+        g.sc3[i] = g.zc3[i] = g.dsc3[i] = g.dzc3[i] = g.lamC[i] = g.dsC[i] = g.dzC[i] = 0.;
+    g.dsig = g.ddsg = g.dn1 = g.dss = g.dzs = g.ds3 = g.dz3 = 0.;
+    g.hsig = g.Hsd = g.Hdd = g.schur = 0.;
+    g.seta = 1.;
+    g.sw[0] = 1.;
+    g.sw[1] = g.sw[2] = 0.;
+    int Dcount = 0;
+    // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
+    // never written afterwards but are swept by the vector updates)
+    if (v.vst)
+        for (int i = 0; i < STREC; i++)
+            st[i] = 0.;
+    if (v.vsg)
+    {
+        for (int i = 0; i < SEGREC; i++)
+            sg[i] = 0.;
+        // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
+        const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
+        for (int e = 0; e < NX * NX; e++)
+            dy[DY_A + e] = Ak[e];
+        for (int e = 0; e < NX * NU; e++)
+        {
+            dy[DY_B + e] = Bk[e];
+            dy[DY_C + e] = Ck[e];
+        }
+        for (int e = 0; e < NX; e++)
+        {
+            dy[DY_S + e] = c.S[k * NX + e];
+            dy[DY_Z + e] = c.Z[k * NX + e];
+        }
+    }
+    if (v.vst)
+    {
+        const double *Xb = X + size_t(k) * NX, *Ub = U + size_t(k) * NU;
+        for (int j = 0; j < 13; j++)
+            st[F_WBAR + j] = Xb[j];
+        for (int j = 0; j < 3; j++)
+            st[F_WBAR + 13 + j] = Ub[j];
+        for (int j = 0; j < 3; j++)
+            st[F_UHAT + j] = uhat[size_t(k) * 3 + j];
+        if (k == 0)
+            for (int j = 0; j < 13; j++)
+                st[F_W + j] = ip[IP_XINIT + j];
+        if (k == K - 1)
+            for (int j = 0; j < 13; j++)
+                if (v.fm & (1u << j))
+                    st[F_W + j] = ip[IP_XFINAL + j];
+        for (int b = 0; b < 8; b++)
+            if (v.act & (1u << b))
+                Dcount++;
+        // identity scalings
+        for (int i = 0; i < 6; i++)
+            st[F_ETA + i] = 1.;
+        for (int cix = 0; cix < NCONE; cix++)
+            st[F_WB + coneOff(cix)] = 1.;
+    }
+    if (v.vsg)
+        Dcount += 2 * NL;
+    {
+        const double dsum = wave_sum(double(Dcount));
+        it.D = int(dsum + 0.5) + 3;
+    }
+    it.bad = 0;
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+
+// ---- ECOS init, primal part: rhs of  min ||x||^2 + ||s||^2  s.t. equalities (W = I) ----
+PHASE_FN void phInitPrimalRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const SV &st = v.st, &stN = v.stN, &sg = v.sg, &dy = v.dy;
+    const double *ip = c.ip;
+    Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    prepareFactor(c, true, g);
+    Rhs b;
+    if (v.vst)
+    {
+        double r[NS], gw[NV], gdl;
+        saff(ip, v.act, st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, r);
+        LTmul(ip, v.fm, r, st + F_UHAT, gw, &gdl);
+        for (int j = 0; j < NV; j++)
+            st[F_BXW + j] = -gw[j];
+        st[F_BXD] = -gdl;
+    }
+    if (v.vsg)
+    {
+        double res[NL];
+        dynResF(dy, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
+        for (int i = 0; i < NL; i++)
+        {
+            sg[G_BXNU * NL + i] = 0.;
+            sg[G_BXNUB * NL + i] = 0.;
+            sg[G_BY * NL + i] = -res[i];
+        }
+    }
+    b.s = -((g.sig - 0.001) + (g.sig - it.sigbar));
+    b.ds = -(0.5 * (0.5 + 0.5 * g.dsg) - 0.5 * (0.5 - 0.5 * g.dsg));
+    b.n1 = 0.;
+    b.rhs3 = g.n1;
+    it.bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+    it.b = b;
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+PHASE_FN void phInitPrimalFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    Glob g = loadPriv(gp);
+    const Iter it = loadPriv(ip_);
+    borderSchur(c, g);
+    kktFinish(c, true, g, it.b, it.bts, F_VW, G_VL);
+    applyPrimalStep(c, g, 1.);
+    WAVE_SYNC();
+    evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    bring2cone(c, it.gamma, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    storePriv(gp, g);
+    WAVE_SYNC();
+}
+// ---- ECOS init, dual part: H x' + A'y = -c ; z = -L x' ----
+PHASE_FN void phInitDualRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const SV &st = v.st, &sg = v.sg;
+    Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    Rhs b;
+    if (v.vst)
+    {
+        for (int j = 0; j < NV; j++)
+            st[F_BXW + j] = 0.;
+        st[F_BXD] = -it.wtrx;
+    }
+    if (v.vsg)
+        for (int i = 0; i < NL; i++)
+        {
+            sg[G_BXNU * NL + i] = 0.;
+            sg[G_BXNUB * NL + i] = 0.;
+            sg[G_BY * NL + i] = 0.;
+        }
+    b.s = -it.w_t;
+    b.ds = -it.w_trt;
+    b.n1 = -it.w_vc;
+    b.rhs3 = 0.;
+    it.bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+    it.b = b;
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const int K = v.K;
+    const SV &st = v.st, &stN = v.stN, &sg = v.sg, &dy = v.dy;
+    const double *ip = c.ip;
+    Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    kktFinish(c, true, g, it.b, it.bts, F_VW, G_VL);
+    if (v.vst)
+    {
+        double t[NS];
+        Lmul(ip, v.act, st + F_DW, st[F_DDL], st + F_UHAT, t);
+        for (int i = 0; i < NS; i++)
+            st[F_Z + i] = -t[i];
+    }
+    if (v.vsg)
+        for (int i = 0; i < NL; i++)
+        {
+            sg[G_LAM * NL + i] = sg[G_DLAM * NL + i];
+            const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
+            sg[G_Z1 * NL + i] = -(dnub - dnu);
+            sg[G_Z2 * NL + i] = -(dnub + dnu);
+        }
+    g.zs = -g.dsig;
+    g.z3 = g.dz3;
+    g.zc3[0] = -0.5 * g.ddsg;
+    g.zc3[1] = 0.5 * g.ddsg;
+    g.zc3[2] = -g.dsig;
+    bring2cone(c, it.gamma, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+    WAVE_SYNC();
+    // ---- data norms for the termination test ----
+    {
+        double resx0 = sqrt(K * it.wtrx * it.wtrx + it.w_t * it.w_t + it.w_trt * it.w_trt + it.w_vc * it.w_vc);
+        resx0 = resx0 > 1. ? resx0 : 1.;
+        double nb = 0., nh = 0.;
+        double w0[NV], w1[NV];
+        for (int j = 0; j < NV; j++)
+            w0[j] = w1[j] = 0.;
+        if (v.vst)
+        {
+            for (int j = 0; j < NV; j++)
+                w0[j] = (v.fm & (1u << j)) ? double(st[F_W + j]) : 0.;
+            double r[NS];
+            saff(ip, v.act, w0, 0., st + F_WBAR, st + F_UHAT, r);
+            for (int i = 0; i < NS; i++)
+                nh += r[i] * r[i];
+        }
+        if (v.vsg)
+        {
+            const unsigned fmn = fixedMask(v.k + 1, K);
+            for (int j = 0; j < NV; j++)
+                w1[j] = (fmn & (1u << j)) ? double(stN[F_W + j]) : 0.;
+            double zero[NL], res[NL];
+            for (int i = 0; i < NL; i++)
+                zero[i] = 0.;
+            dynResF(dy, w0, w1, zero, 0., res);
+            for (int i = 0; i < NL; i++)
+                nb += res[i] * res[i];
+        }
+        nb = wave_sum(nb);
+        nh = wave_sum(nh) + 0.001 * 0.001 + 0.25 + 0.25 + it.sigbar * it.sigbar;
+        it.resx0 = resx0;
+        it.resy0 = sqrt(nb) > 1. ? sqrt(nb) : 1.;
+        it.resz0 = sqrt(nh) > 1. ? sqrt(nh) : 1.;
+    }
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+
+// ---- residuals, duality gap, termination quantities ----
+PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const int k = v.k;
+    const SV &st = v.st, &stN = v.stN, &sg = v.sg, &sgP = v.sgP, &dy = v.dy, &dyP = v.dyP;
+    const double *ip = c.ip;
+    const unsigned fm = v.fm;
+    const Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    double sas, sa3, sac[3];
+    evalAllSaff(c, g, F_RZ, G_RZ1, G_RZ2, sas, sa3, sac);
+    double resv[NL];
+    double p_gap = 0., p_rx = 0., p_ry = 0., p_rz = 0., p_xx = 0., p_yy = 0., p_zz = 0., p_ss = 0., p_rxs = 0., p_dl = 0.;
+    if (v.vst)
+    {
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+        {
+            const double sv = st[F_S + i], zv = st[F_Z + i];
+            const double r = sv - st[F_RZ + i];
+            st[F_RZ + i] = r;
+            p_gap += sv * zv;
+            p_rz += r * r;
+            p_zz += zv * zv;
+            p_ss += sv * sv;
+        }
+        double gw[NV], gdl;
+        LTmul(ip, fm, st + F_Z, st + F_UHAT, gw, &gdl);
+        const double rxd = it.wtrx - gdl;
+        st[F_RXD] = rxd;
+        // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
+        // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
+        double acc[NV], x0[NV], u1[3];
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+        {
+            acc[j] = 0.;
+            x0[j] = st[F_W + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            u1[j] = stN[F_W + 13 + j];
+        const double mk = v.vsg ? 1. : 0., mp = k > 0 ? 1. : 0.;
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+        {
+            double ra[13], rb[3], rc[3], rcp[3];
+#pragma unroll
+            for (int j = 0; j < 13; j++)
+                ra[j] = dy[DY_A + i * NX + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                rb[j] = dy[DY_B + i * NU + j];
+                rc[j] = dy[DY_C + i * NU + j];
+                rcp[j] = dyP[DY_C + i * NU + j];
+            }
+            const double l = mk * double(sg[G_LAM * NL + i]), lp = mp * double(sgP[G_LAM * NL + i]);
+            double rr = (i < 13 ? double(stN[F_W + (i < 13 ? i : 0)]) : 0.) - dy[DY_S + i] * g.sig - sg[G_NU * NL + i] - dy[DY_Z + i];
+#pragma unroll
+            for (int j = 0; j < 13; j++)
+            {
+                acc[j] -= ra[j] * l;
+                rr -= ra[j] * x0[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                acc[13 + j] -= rb[j] * l + rcp[j] * lp;
+                rr -= rb[j] * x0[13 + j] + rc[j] * u1[j];
+            }
+            if (i < 13)
+                acc[i] += lp;
+            resv[i] = rr;
+        }
+        p_rx += rxd * rxd;
+        const double dl = st[F_DL];
+        p_xx += dl * dl;
+        p_dl += dl;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+        {
+            const bool fx = fm & (1u << j);
+            const double r = -gw[j] + (fx ? 0. : acc[j]);
+            st[F_RXW + j] = r;
+            p_rx += fx ? 0. : r * r;
+            p_xx += fx ? 0. : x0[j] * x0[j];
+        }
+    }
+    if (v.vsg)
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+        {
+            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
+            const double r1 = s1 - sg[G_RZ1 * NL + i], r2 = s2 - sg[G_RZ2 * NL + i];
+            sg[G_RZ1 * NL + i] = r1;
+            sg[G_RZ2 * NL + i] = r2;
+            sg[G_RY * NL + i] = resv[i];
+            const double l = sg[G_LAM * NL + i];
+            const double rnu = -l + z1 - z2, rnub = -z1 - z2 + g.z3;
+            sg[G_RXNU * NL + i] = rnu;
+            sg[G_RXNUB * NL + i] = rnub;
+            p_gap += s1 * z1 + s2 * z2;
+            p_rz += r1 * r1 + r2 * r2;
+            p_zz += z1 * z1 + z2 * z2;
+            p_ss += s1 * s1 + s2 * s2;
+            p_ry += resv[i] * resv[i];
+            p_yy += l * l;
+            p_rx += rnu * rnu + rnub * rnub;
+            const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
+            p_xx += nu * nu + nub * nub;
+            p_rxs += dy[DY_S + i] * l;
+        }
+    }
+    p_gap = wave_sum(p_gap);
+    p_rx = wave_sum(p_rx);
+    p_ry = wave_sum(p_ry);
+    p_rz = wave_sum(p_rz);
+    p_xx = wave_sum(p_xx);
+    p_yy = wave_sum(p_yy);
+    p_zz = wave_sum(p_zz);
+    p_ss = wave_sum(p_ss);
+    p_rxs = wave_sum(p_rxs);
+    p_dl = wave_sum(p_dl);
+    it.rzs = g.ss - sas;
+    it.rz3 = g.s3 - sa3;
+    for (int i = 0; i < 3; i++)
+        it.rzc[i] = g.sc3[i] - sac[i];
+    it.rxs = it.w_t - g.zs - g.zc3[2] - p_rxs;
+    it.rxds = it.w_trt - 0.5 * g.zc3[0] + 0.5 * g.zc3[1];
+    it.rxn1 = it.w_vc - g.z3;
+    double gap = p_gap + g.ss * g.zs + g.s3 * g.z3;
+    double nrz = p_rz + it.rzs * it.rzs + it.rz3 * it.rz3;
+    double nzz = p_zz + g.zs * g.zs + g.z3 * g.z3;
+    double nss = p_ss + g.ss * g.ss + g.s3 * g.s3;
+    for (int i = 0; i < 3; i++)
+    {
+        gap += g.sc3[i] * g.zc3[i];
+        nrz += it.rzc[i] * it.rzc[i];
+        nzz += g.zc3[i] * g.zc3[i];
+        nss += g.sc3[i] * g.sc3[i];
+    }
+    const double nrx = p_rx + it.rxs * it.rxs + it.rxds * it.rxds + it.rxn1 * it.rxn1;
+    const double nxx = p_xx + g.sig * g.sig + g.dsg * g.dsg + g.n1 * g.n1;
+    it.gap = gap;
+    it.mu = gap / it.D;
+    it.pcost = it.w_t * g.sig + it.w_trt * g.dsg + it.w_vc * g.n1 + it.wtrx * p_dl;
+    {
+        const double nx_ = sqrt(nxx), ny_ = sqrt(p_yy), nz_ = sqrt(nzz), ns_ = sqrt(nss);
+        const double d1 = it.resy0 + nx_ > 1. ? it.resy0 + nx_ : 1.;
+        const double d2 = it.resz0 + nx_ + ns_ > 1. ? it.resz0 + nx_ + ns_ : 1.;
+        const double pa = sqrt(p_ry) / d1, pb = sqrt(nrz) / d2;
+        it.pres = pa > pb ? pa : pb;
+        const double d3 = it.resx0 + ny_ + nz_ > 1. ? it.resx0 + ny_ + nz_ : 1.;
+        it.dres = sqrt(nrx) / d3;
+    }
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+
+// ---- Nesterov-Todd scalings and the per-stage factorisation inputs ----
+PHASE_FN void phScalings(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const SV &st = v.st;
+    const unsigned act = v.act;
+    Glob g = loadPriv(gp);
+    int bad = 0;
+    if (v.vst)
+    {
+        bad |= coneScaling<C1, 17>(st, 0);
+        if (act & 2u)
+            bad |= coneScaling<C2, 3>(st, 1);
+        if (act & 4u)
+            bad |= coneScaling<C3, 3>(st, 2);
+        if (act & 8u)
+            bad |= coneScaling<C4, 3>(st, 3);
+        bad |= coneScaling<C5, 4>(st, 4);
+        bad |= coneScaling<C6, 3>(st, 5);
+    }
+    if (!cone::nt_scaling(g.sc3, g.zc3, 3, g.seta, g.sw))
+        bad = 1;
+    bad = wave_or(bad);
+    if (!bad)
+    {
+        cone::applyW(g.seta, g.sw, 3, g.zc3, g.lamC);
+        WAVE_SYNC();
+        prepareFactor(c, false, g);
+    }
+    ip_->bad = bad;
+    storePriv(gp, g);
+    WAVE_SYNC();
+}
+
+// ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
+PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+{
+    const Ctx c = uniformCtx(cin);
+    const int pass = uniformInt(passIn);
+    const Views v = makeViews(c);
+    const SV &st = v.st, &sg = v.sg;
+    const double *ip = c.ip;
+    const unsigned fm = v.fm, act = v.act;
+    Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    const double sigma_c = pass ? it.sigma_c : 0., mu = it.mu;
+    const double om = 1. - sigma_c;
+    if (v.vst)
+    {
+        const double sigmu = sigma_c * mu;
+        coneT<C1, 17>(st, 0, pass, om, sigmu);
+        if (act & 2u)
+            coneT<C2, 3>(st, 1, pass, om, sigmu);
+        else
+            zeroT<C2, 3>(st);
+        if (act & 4u)
+            coneT<C3, 3>(st, 2, pass, om, sigmu);
+        else
+            zeroT<C3, 3>(st);
+        if (act & 8u)
+            coneT<C4, 3>(st, 3, pass, om, sigmu);
+        else
+            zeroT<C4, 3>(st);
+        coneT<C5, 4>(st, 4, pass, om, sigmu);
+        coneT<C6, 3>(st, 5, pass, om, sigmu);
+        for (int which = 0; which < 2; which++)
+        {
+            const int o = which ? L2 : L1;
+            if (!(act & (1u << (6 + which))))
+            {
+                st[F_TZ + o] = 0.;
+                continue;
+            }
+            const double sv = st[F_S + o], zv = st[F_Z + o];
+            const double corr = pass ? (sigma_c * mu - st[F_DS + o] * st[F_DZ + o]) / sv : 0.;
+            st[F_TZ + o] = (zv / sv) * om * st[F_RZ + o] - zv + corr;
+        }
+        double gw[NV], gdl;
+        LTmul(ip, fm, st + F_TZ, st + F_UHAT, gw, &gdl);
+        double rxw[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            rxw[j] = st[F_RXW + j];
+        const double rxd = st[F_RXD];
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            st[F_BXW + j] = -om * rxw[j] + gw[j];
+        st[F_BXD] = -om * rxd + gdl;
+    }
+    if (v.vsg)
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+        {
+            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
+            const double c1 = pass ? (sigma_c * mu - sg[G_DS1 * NL + i] * sg[G_DZ1 * NL + i]) / s1 : 0.;
+            const double c2 = pass ? (sigma_c * mu - sg[G_DS2 * NL + i] * sg[G_DZ2 * NL + i]) / s2 : 0.;
+            const double rz1 = sg[G_RZ1 * NL + i], rz2 = sg[G_RZ2 * NL + i];
+            const double rxnu = sg[G_RXNU * NL + i], rxnub = sg[G_RXNUB * NL + i], ry = sg[G_RY * NL + i];
+            const double t1 = (z1 / s1) * om * rz1 - z1 + c1;
+            const double t2 = (z2 / s2) * om * rz2 - z2 + c2;
+            sg[G_TZ1 * NL + i] = t1;
+            sg[G_TZ2 * NL + i] = t2;
+            sg[G_BXNU * NL + i] = -om * rxnu + (-t1 + t2);
+            sg[G_BXNUB * NL + i] = -om * rxnub + (t1 + t2);
+            sg[G_BY * NL + i] = -om * ry;
+        }
+    }
+    it.tzs = (g.zs / g.ss) * om * it.rzs - g.zs + (pass ? (sigma_c * mu - g.dss * g.dzs) / g.ss : 0.);
+    {
+        double aa[3], b2[3];
+        for (int i = 0; i < 3; i++)
+            aa[i] = om * it.rzc[i];
+        cone::applyWinv2(g.seta, g.sw, 3, aa, b2);
+        if (pass == 0)
+            for (int i = 0; i < 3; i++)
+                it.tzc[i] = b2[i] - g.zc3[i];
+        else
+        {
+            double dsv[3];
+            cone::conicProduct(3, g.dsC, g.dzC, dsv);
+            for (int i = 0; i < 3; i++)
+                dsv[i] = -dsv[i];
+            dsv[0] += sigma_c * mu;
+            cone::conicDivision(3, g.lamC, dsv, dsv);
+            for (int i = 0; i < 3; i++)
+                dsv[i] -= g.lamC[i];
+            cone::applyWinv(g.seta, g.sw, 3, dsv, aa);
+            for (int i = 0; i < 3; i++)
+                it.tzc[i] = b2[i] + aa[i];
+        }
+    }
+    const double ds3v = -g.s3 * g.z3 + (pass ? (sigma_c * mu - g.ds3 * g.dz3) : 0.);
+    Rhs b;
+    b.s = -om * it.rxs + it.tzs + it.tzc[2];
+    b.ds = -om * it.rxds + 0.5 * it.tzc[0] - 0.5 * it.tzc[1];
+    b.n1 = -om * it.rxn1;
+    b.rhs3 = -om * it.rz3 - ds3v / g.z3;
+    it.bts = kktPrep(c, false, g, b, F_BETA, G_RHO);
+    it.b = b;
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+
+// ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
+PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+{
+    const Ctx c = uniformCtx(cin);
+    const int pass = uniformInt(passIn);
+    const Views v = makeViews(c);
+    const SV &st = v.st, &sg = v.sg;
+    const double *ip = c.ip;
+    const unsigned act = v.act;
+    Glob g = loadPriv(gp);
+    Iter it = loadPriv(ip_);
+    const double sigma_c = pass ? it.sigma_c : 0.;
+    const double om = 1. - sigma_c;
+    if (pass == 0)
+        borderSchur(c, g);
+    if (!(g.schur > 0.))
+        it.bad = 1;
+    kktFinish(c, false, g, it.b, it.bts, F_VW, G_VL);
+    double ainv = 0.;
+    if (v.vst)
+    {
+        double Ld[NS];
+        Lmul(ip, act, st + F_DW, st[F_DDL], st + F_UHAT, Ld);
+        double a0 = coneDir<C1, 17>(st, 0, om, Ld);
+        ainv = a0 > ainv ? a0 : ainv;
+        if (act & 2u)
+        {
+            a0 = coneDir<C2, 3>(st, 1, om, Ld);
+            ainv = a0 > ainv ? a0 : ainv;
+        }
+        if (act & 4u)
+        {
+            a0 = coneDir<C3, 3>(st, 2, om, Ld);
+            ainv = a0 > ainv ? a0 : ainv;
+        }
+        if (act & 8u)
+        {
+            a0 = coneDir<C4, 3>(st, 3, om, Ld);
+            ainv = a0 > ainv ? a0 : ainv;
+        }
+        a0 = coneDir<C5, 4>(st, 4, om, Ld);
+        ainv = a0 > ainv ? a0 : ainv;
+        a0 = coneDir<C6, 3>(st, 5, om, Ld);
+        ainv = a0 > ainv ? a0 : ainv;
+        for (int which = 0; which < 2; which++)
+        {
+            const int o = which ? L2 : L1;
+            if (!(act & (1u << (6 + which))))
+                continue;
+            const double sv = st[F_S + o], zv = st[F_Z + o];
+            const double dzv = -(zv / sv) * Ld[o] + st[F_TZ + o];
+            const double dsv = -om * st[F_RZ + o] + Ld[o];
+            st[F_DZ + o] = dzv;
+            st[F_DS + o] = dsv;
+            const double a1 = -dsv / sv, a2 = -dzv / zv;
+            ainv = a1 > ainv ? a1 : ainv;
+            ainv = a2 > ainv ? a2 : ainv;
+        }
+    }
+    double sumdnb = 0.;
+    if (v.vsg)
+    {
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+        {
+            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
+            const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
+            const double tz1 = sg[G_TZ1 * NL + i], tz2 = sg[G_TZ2 * NL + i], rz1 = sg[G_RZ1 * NL + i], rz2 = sg[G_RZ2 * NL + i];
+            const double L1v = dnub - dnu, L2v = dnub + dnu;
+            const double dz1 = -(z1 / s1) * L1v + tz1, ds1 = -om * rz1 + L1v;
+            const double dz2 = -(z2 / s2) * L2v + tz2, ds2 = -om * rz2 + L2v;
+            sg[G_DZ1 * NL + i] = dz1;
+            sg[G_DS1 * NL + i] = ds1;
+            sg[G_DZ2 * NL + i] = dz2;
+            sg[G_DS2 * NL + i] = ds2;
+            double m1 = -ds1 / s1, m2 = -dz1 / z1, m3 = -ds2 / s2, m4 = -dz2 / z2;
+            m1 = m1 > m2 ? m1 : m2;
+            m3 = m3 > m4 ? m3 : m4;
+            m1 = m1 > m3 ? m1 : m3;
+            ainv = m1 > ainv ? m1 : ainv;
+            sumdnb += dnub;
+        }
+    }
+    sumdnb = wave_sum(sumdnb);
+    g.dzs = -(g.zs / g.ss) * g.dsig + it.tzs;
+    g.dss = -om * it.rzs + g.dsig;
+    {
+        const double m1 = -g.dss / g.ss, m2 = -g.dzs / g.zs;
+        ainv = m1 > ainv ? m1 : ainv;
+        ainv = m2 > ainv ? m2 : ainv;
+    }
+    g.ds3 = -om * it.rz3 + (g.dn1 - sumdnb);
+    {
+        const double m1 = -g.ds3 / g.s3, m2 = -g.dz3 / g.z3;
+        ainv = m1 > ainv ? m1 : ainv;
+        ainv = m2 > ainv ? m2 : ainv;
+    }
+    {
+        const double Ld[3] = {0.5 * g.ddsg, -0.5 * g.ddsg, g.dsig};
+        double aa[3];
+        cone::applyWinv2(g.seta, g.sw, 3, Ld, aa);
+        for (int i = 0; i < 3; i++)
+        {
+            g.dzc3[i] = -aa[i] + it.tzc[i];
+            g.dsc3[i] = -om * it.rzc[i] + Ld[i];
+        }
+        cone::applyWinv(g.seta, g.sw, 3, g.dsc3, g.dsC);
+        cone::applyW(g.seta, g.sw, 3, g.dzc3, g.dzC);
+        const double a1 = cone::stepInv(3, g.lamC, g.dsC), a2 = cone::stepInv(3, g.lamC, g.dzC);
+        ainv = a1 > ainv ? a1 : ainv;
+        ainv = a2 > ainv ? a2 : ainv;
+    }
+    ainv = wave_max(ainv);
+    if (pass == 0)
+    {
+        double alpha_a = ainv > 0. ? 1. / ainv : 1.;
+        alpha_a = alpha_a < 1. ? alpha_a : 1.;
+        double sc = (1. - alpha_a) * (1. - alpha_a) * (1. - alpha_a);
+        sc = sc < 1e-4 ? 1e-4 : sc;
+        sc = sc > 1. ? 1. : sc;
+        it.sigma_c = sc;
+    }
+    else
+    {
+        double alpha = ainv > 0. ? it.gamma / ainv : 1.;
+        alpha = alpha < 1. ? alpha : 1.;
+        alpha = alpha < 0.999 ? alpha : 0.999;
+        alpha = alpha > 1e-8 ? alpha : 1e-8;
+        it.alpha = alpha;
+    }
+    storePriv(gp, g);
+    storePriv(ip_, it);
+    WAVE_SYNC();
+}
+
+// ---- x += alpha dx ; s += alpha ds ; z += alpha dz ----
+template <int N>
+__device__ inline void axpyFields(const SV &rec, int fDst, int fSrc, double alpha)
+{
+    double d[N], x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        d[i] = rec[fDst + i];
+        x[i] = rec[fSrc + i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        rec[fDst + i] = d[i] + alpha * x[i];
+}
+PHASE_FN void phUpdate(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const SV &st = v.st, &sg = v.sg;
+    Glob g = loadPriv(gp);
+    const double alpha = ip_->alpha;
+    if (v.vst)
+    {
+        double d[NV], x[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+        {
+            d[j] = st[F_W + j];
+            x[j] = st[F_DW + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            st[F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
+        axpyFields<1>(st, F_DL, F_DDL, alpha);
+        axpyFields<18>(st, F_S, F_DS, alpha);
+        axpyFields<NS - 18>(st, F_S + 18, F_DS + 18, alpha);
+        axpyFields<18>(st, F_Z, F_DZ, alpha);
+        axpyFields<NS - 18>(st, F_Z + 18, F_DZ + 18, alpha);
+    }
+    if (v.vsg)
+    {
+        axpyFields<NL>(sg, G_NU * NL, G_DNU * NL, alpha);
+        axpyFields<NL>(sg, G_NUB * NL, G_DNUB * NL, alpha);
+        axpyFields<NL>(sg, G_LAM * NL, G_DLAM * NL, alpha);
+        axpyFields<NL>(sg, G_S1 * NL, G_DS1 * NL, alpha);
+        axpyFields<NL>(sg, G_Z1 * NL, G_DZ1 * NL, alpha);
+        axpyFields<NL>(sg, G_S2 * NL, G_DS2 * NL, alpha);
+        axpyFields<NL>(sg, G_Z2 * NL, G_DZ2 * NL, alpha);
+    }
+    g.sig += alpha * g.dsig;
+    g.dsg += alpha * g.ddsg;
+    g.n1 += alpha * g.dn1;
+    g.ss += alpha * g.dss;
+    g.zs += alpha * g.dzs;
+    g.s3 += alpha * g.ds3;
+    g.z3 += alpha * g.dz3;
+    for (int i = 0; i < 3; i++)
+    {
+        g.sc3[i] += alpha * g.dsc3[i];
+        g.zc3[i] += alpha * g.dzc3[i];
+    }
+    storePriv(gp, g);
+    WAVE_SYNC();
+}
+
 #ifndef IPM_WAVES_PER_SIMD
 #define IPM_WAVES_PER_SIMD 2
 #endif
@@ -470,7 +1289,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     double *ws = a.ws + size_t(inst) * workspaceDoubles(K);
     c.st = ws;
     c.sg = ws + size_t(LANES) * STREC;
-    c.fac = c.sg + size_t(LANES) * SEGREC;
+    c.dy = c.sg + size_t(LANES) * SEGREC;
+    c.fac = c.dy + size_t(LANES) * DYNREC;
     c.sv = c.fac + size_t(K) * FACREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
     c.B = a.Bm + size_t(inst) * (K - 1) * NX * NU;
@@ -478,479 +1298,81 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.S = a.S + size_t(inst) * (K - 1) * NX;
     c.Z = a.Z + size_t(inst) * (K - 1) * NX;
     c.ip = a.ip + size_t(inst) * IP_N;
-    // the out-of-line sweeps take the context by reference; give them their own copy so that `c` never
-    // escapes and its pointers stay in SGPRs for the inlined lane=stage phases
-    Ctx cesc = c;
-    const double *ip = c.ip;
-    const double wtrx = a.wtrx[inst];
-    const double w_t = ip[IP_WT], w_trt = ip[IP_WTRT], w_vc = ip[IP_WVC];
-    const double sigbar = a.sigma[inst];
     const Settings opt = a.opt;
-    const unsigned fm = (k < K) ? fixedMask(k, K) : 0u, act = (k < K) ? activeMask(k, K) : 0u;
-    const SV st = makeSV(c.st, STREC, unsigned(k < K ? k : 0));
-    const SV stN = makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0)); // next stage's record
-    const SV sg = makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0));
-    const bool vst = k < K, vsg = k < K - 1;
 
     Glob g;
-    g.sig = g.dsg = g.n1 = 0.;
-    g.sigbar = sigbar;
-    g.ss = g.zs = g.s3 = g.z3 = 1.;
-    for (int i = 0; i < 3; i++)
-        g.sc3[i] = g.zc3[i] = 0.;
-    g.seta = 1.;
-    g.sw[0] = 1.;
-    g.sw[1] = g.sw[2] = 0.;
+    Iter it;
+    PRIV Glob *gp = (PRIV Glob *)&g;
+    PRIV Iter *itp = (PRIV Iter *)&it;
+    const double wtrx = a.wtrx[inst];
+    it.wtrx = wtrx;
+    it.w_t = c.ip[IP_WT];
+    it.w_trt = c.ip[IP_WTRT];
+    it.w_vc = c.ip[IP_WVC];
+    it.sigbar = a.sigma[inst];
+    it.gamma = opt.gamma;
+    it.sigma_c = 0.;
+    it.alpha = 1.;
 
-    // ---- stage setup: trust-region centre, fixed values, zero start ----
-    int Dcount = 0;
-    // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
-    // never written afterwards but are swept by the vector updates)
-    if (vst)
-        for (int i = 0; i < STREC; i++)
-            st[i] = 0.;
-    if (vsg)
-        for (int i = 0; i < SEGREC; i++)
-            sg[i] = 0.;
-    if (vst)
-    {
-        const double *Xb = a.X + (size_t(inst) * K + k) * NX, *Ub = a.U + (size_t(inst) * K + k) * NU;
-        for (int j = 0; j < 13; j++)
-            st[F_WBAR + j] = Xb[j];
-        for (int j = 0; j < 3; j++)
-            st[F_WBAR + 13 + j] = Ub[j];
-        for (int j = 0; j < 3; j++)
-            st[F_UHAT + j] = a.uhat[(size_t(inst) * K + k) * 3 + j];
-        for (int j = 0; j < NV; j++)
-            st[F_W + j] = 0.;
-        if (k == 0)
-            for (int j = 0; j < 13; j++)
-                st[F_W + j] = ip[IP_XINIT + j];
-        if (k == K - 1)
-            for (int j = 0; j < 13; j++)
-                if (fm & (1u << j))
-                    st[F_W + j] = ip[IP_XFINAL + j];
-        st[F_DL] = 0.;
-        for (int b = 0; b < 8; b++)
-            if (act & (1u << b))
-                Dcount++;
-        // identity scalings
-        for (int i = 0; i < 6; i++)
-            st[F_ETA + i] = 1.;
-        for (int i = 0; i < 33; i++)
-            st[F_WB + i] = 0.;
-        for (int cix = 0; cix < NCONE; cix++)
-            st[F_WB + coneOff(cix)] = 1.;
-    }
-    if (vsg)
-    {
-        for (int i = 0; i < NL; i++)
-        {
-            sg[G_NU * NL + i] = 0.;
-            sg[G_NUB * NL + i] = 0.;
-        }
-        Dcount += 2 * NL;
-    }
-    {
-        double dsum = wave_sum(double(Dcount));
-        Dcount = int(dsum + 0.5) + 3;
-    }
-    const int D = Dcount;
-    WAVE_SYNC();
-
-    // =============== initialisation (ECOS init, W = I) ===============
     PROF_T(tp0);
-    prepareFactor(c, true, g);
+    phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp);
+    // =============== initialisation (ECOS init, W = I) ===============
+    phInitPrimalRhs(c, gp, itp);
     {
-        // primal: bx = -L' saff(x0), by = -ry(x0), rhs3 = n1
-        Rhs b;
-        if (vst)
-        {
-            double r[NS], gw[NV], gdl;
-            saff(ip, act, st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, r);
-            LTmul(ip, fm, r, st + F_UHAT, gw, &gdl);
-            for (int j = 0; j < NV; j++)
-                st[F_BXW + j] = -gw[j];
-            st[F_BXD] = -gdl;
-        }
-        if (vsg)
-        {
-            double res[NL];
-            dynRes(c, k, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
-            for (int i = 0; i < NL; i++)
-            {
-                sg[G_BXNU * NL + i] = 0.;
-                sg[G_BXNUB * NL + i] = 0.;
-                sg[G_BY * NL + i] = -res[i];
-            }
-        }
-        b.s = -((g.sig - 0.001) + (g.sig - sigbar));
-        b.ds = -(0.5 * (0.5 + 0.5 * g.dsg) - 0.5 * (0.5 - 0.5 * g.dsg));
-        b.n1 = 0.;
-        b.rhs3 = g.n1;
-        const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
-        WAVE_SYNC();
         const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-        factorSweepFused(cesc, sh, sp);
-        bwdSweep(cesc, sp);
-        borderSchur(c, g);
-        kktFinish(c, true, g, b, bts, F_VW, G_VL);
-        PROF_T(tp1);
-        PROF_ADD(0, tp0, tp1);
-        applyPrimalStep(c, g, 1.);
-        WAVE_SYNC();
-        evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
-        bring2cone(c, opt.gamma, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+        factorSweepFused(c, sh, sp);
+        bwdSweep(c, sp);
     }
+    phInitPrimalFinish(c, gp, itp);
+    phInitDualRhs(c, gp, itp);
     {
-        // dual: H x' + A'y = -c ; z = -L x'
-        Rhs b;
-        if (vst)
-        {
-            for (int j = 0; j < NV; j++)
-                st[F_BXW + j] = 0.;
-            st[F_BXD] = -wtrx;
-        }
-        if (vsg)
-            for (int i = 0; i < NL; i++)
-            {
-                sg[G_BXNU * NL + i] = 0.;
-                sg[G_BXNUB * NL + i] = 0.;
-                sg[G_BY * NL + i] = 0.;
-            }
-        b.s = -w_t;
-        b.ds = -w_trt;
-        b.n1 = -w_vc;
-        b.rhs3 = 0.;
-        const double bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
-        WAVE_SYNC();
         const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-        fwdSweep(cesc, sp);
-        bwdSweep(cesc, sp);
-        kktFinish(c, true, g, b, bts, F_VW, G_VL);
-        if (vst)
-        {
-            double t[NS];
-            Lmul(ip, act, st + F_DW, st[F_DDL], st + F_UHAT, t);
-            for (int i = 0; i < NS; i++)
-                st[F_Z + i] = -t[i];
-        }
-        if (vsg)
-            for (int i = 0; i < NL; i++)
-            {
-                sg[G_LAM * NL + i] = sg[G_DLAM * NL + i];
-                const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
-                sg[G_Z1 * NL + i] = -(dnub - dnu);
-                sg[G_Z2 * NL + i] = -(dnub + dnu);
-            }
-        g.zs = -g.dsig;
-        g.z3 = g.dz3;
-        g.zc3[0] = -0.5 * g.ddsg;
-        g.zc3[1] = 0.5 * g.ddsg;
-        g.zc3[2] = -g.dsig;
-        bring2cone(c, opt.gamma, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+        fwdSweep(c, sp);
+        bwdSweep(c, sp);
     }
-    WAVE_SYNC();
-
-    // ---- data norms for the termination test ----
-    double resx0, resy0, resz0;
-    {
-        resx0 = sqrt(K * wtrx * wtrx + w_t * w_t + w_trt * w_trt + w_vc * w_vc);
-        resx0 = resx0 > 1. ? resx0 : 1.;
-        double nb = 0., nh = 0.;
-        double w0[NV], w1[NV];
-        if (vst)
-        {
-            for (int j = 0; j < NV; j++)
-                w0[j] = (fm & (1u << j)) ? st[F_W + j] : 0.;
-            double r[NS];
-            saff(ip, act, w0, 0., st + F_WBAR, st + F_UHAT, r);
-            for (int i = 0; i < NS; i++)
-                nh += r[i] * r[i];
-        }
-        if (vsg)
-        {
-            const unsigned fmn = fixedMask(k + 1, K);
-            for (int j = 0; j < NV; j++)
-                w1[j] = (fmn & (1u << j)) ? stN[F_W + j] : 0.;
-            double zero[NL], res[NL];
-            for (int i = 0; i < NL; i++)
-                zero[i] = 0.;
-            dynRes(c, k, w0, w1, zero, 0., res);
-            for (int i = 0; i < NL; i++)
-                nb += res[i] * res[i];
-        }
-        nb = wave_sum(nb);
-        nh = wave_sum(nh) + 0.001 * 0.001 + 0.25 + 0.25 + sigbar * sigbar;
-        resy0 = sqrt(nb) > 1. ? sqrt(nb) : 1.;
-        resz0 = sqrt(nh) > 1. ? sqrt(nh) : 1.;
-    }
+    phInitDualFinish(c, gp, itp);
+    PROF_T(tp1);
+    PROF_ADD(0, tp0, tp1);
 
     int status = -1, iter = 0;
-    double pres = 0., dres = 0., gap = 0., pcost = 0.;
-    double rzs = 0., rz3 = 0., rzc[3] = {0., 0., 0.}, rxs = 0., rxds = 0., rxn1 = 0.;
     for (iter = 0;; iter++)
     {
-        // ================= residuals =================
         PROF_T(tr0);
-        double sas, sa3, sac[3];
-        evalAllSaff(c, g, F_RZ, G_RZ1, G_RZ2, sas, sa3, sac);
-        double p_gap = 0., p_rx = 0., p_ry = 0., p_rz = 0., p_xx = 0., p_yy = 0., p_zz = 0., p_ss = 0., p_rxs = 0., p_dl = 0.;
-        if (vst)
-        {
-            for (int i = 0; i < NS; i++)
-            {
-                const double sv = st[F_S + i], zv = st[F_Z + i];
-                const double r = sv - st[F_RZ + i];
-                st[F_RZ + i] = r;
-                p_gap += sv * zv;
-                p_rz += r * r;
-                p_zz += zv * zv;
-                p_ss += sv * sv;
-            }
-            double gw[NV], gdl;
-            LTmul(ip, fm, st + F_Z, st + F_UHAT, gw, &gdl);
-            const double rxd = wtrx - gdl;
-            st[F_RXD] = rxd;
-            double r[NV];
-            for (int j = 0; j < NV; j++)
-                r[j] = -gw[j];
-            if (vsg)
-                for (int i = 0; i < NL; i++)
-                {
-                    const double l = sg[G_LAM * NL + i];
-                    for (int j = 0; j < NV; j++)
-                        r[j] += Ment(c, k, fm, i, j) * l;
-                }
-            if (k > 0)
-                for (int i = 0; i < NL; i++)
-                {
-                    const double l = makeSV(c.sg, SEGREC, unsigned(k - 1))[G_LAM * NL + i];
-                    for (int j = 0; j < NV; j++)
-                        r[j] += Nent(c, k - 1, fm, i, j) * l;
-                }
-            p_rx += rxd * rxd;
-            p_xx += st[F_DL] * st[F_DL];
-            p_dl += st[F_DL];
-            for (int j = 0; j < NV; j++)
-            {
-                st[F_RXW + j] = r[j];
-                if (!(fm & (1u << j)))
-                {
-                    p_rx += r[j] * r[j];
-                    p_xx += st[F_W + j] * st[F_W + j];
-                }
-            }
-        }
-        if (vsg)
-        {
-            double res[NL];
-            dynRes(c, k, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
-            for (int i = 0; i < NL; i++)
-            {
-                const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-                const double r1 = s1 - sg[G_RZ1 * NL + i], r2 = s2 - sg[G_RZ2 * NL + i];
-                sg[G_RZ1 * NL + i] = r1;
-                sg[G_RZ2 * NL + i] = r2;
-                sg[G_RY * NL + i] = res[i];
-                const double l = sg[G_LAM * NL + i];
-                const double rnu = -l + z1 - z2, rnub = -z1 - z2 + g.z3;
-                sg[G_RXNU * NL + i] = rnu;
-                sg[G_RXNUB * NL + i] = rnub;
-                p_gap += s1 * z1 + s2 * z2;
-                p_rz += r1 * r1 + r2 * r2;
-                p_zz += z1 * z1 + z2 * z2;
-                p_ss += s1 * s1 + s2 * s2;
-                p_ry += res[i] * res[i];
-                p_yy += l * l;
-                p_rx += rnu * rnu + rnub * rnub;
-                const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
-                p_xx += nu * nu + nub * nub;
-                p_rxs += c.S[k * NX + i] * l;
-            }
-        }
-        p_gap = wave_sum(p_gap);
-        p_rx = wave_sum(p_rx);
-        p_ry = wave_sum(p_ry);
-        p_rz = wave_sum(p_rz);
-        p_xx = wave_sum(p_xx);
-        p_yy = wave_sum(p_yy);
-        p_zz = wave_sum(p_zz);
-        p_ss = wave_sum(p_ss);
-        p_rxs = wave_sum(p_rxs);
-        p_dl = wave_sum(p_dl);
-        rzs = g.ss - sas;
-        rz3 = g.s3 - sa3;
-        for (int i = 0; i < 3; i++)
-            rzc[i] = g.sc3[i] - sac[i];
-        rxs = w_t - g.zs - g.zc3[2] - p_rxs;
-        rxds = w_trt - 0.5 * g.zc3[0] + 0.5 * g.zc3[1];
-        rxn1 = w_vc - g.z3;
-        gap = p_gap + g.ss * g.zs + g.s3 * g.z3;
-        double nrz = p_rz + rzs * rzs + rz3 * rz3;
-        double nzz = p_zz + g.zs * g.zs + g.z3 * g.z3;
-        double nss = p_ss + g.ss * g.ss + g.s3 * g.s3;
-        for (int i = 0; i < 3; i++)
-        {
-            gap += g.sc3[i] * g.zc3[i];
-            nrz += rzc[i] * rzc[i];
-            nzz += g.zc3[i] * g.zc3[i];
-            nss += g.sc3[i] * g.sc3[i];
-        }
-        const double nrx = p_rx + rxs * rxs + rxds * rxds + rxn1 * rxn1;
-        const double nxx = p_xx + g.sig * g.sig + g.dsg * g.dsg + g.n1 * g.n1;
-        const double mu = gap / D;
-        pcost = w_t * g.sig + w_trt * g.dsg + w_vc * g.n1 + wtrx * p_dl;
-        {
-            const double nx_ = sqrt(nxx), ny_ = sqrt(p_yy), nz_ = sqrt(nzz), ns_ = sqrt(nss);
-            const double d1 = resy0 + nx_ > 1. ? resy0 + nx_ : 1.;
-            const double d2 = resz0 + nx_ + ns_ > 1. ? resz0 + nx_ + ns_ : 1.;
-            const double pa = sqrt(p_ry) / d1, pb = sqrt(nrz) / d2;
-            pres = pa > pb ? pa : pb;
-            const double d3 = resx0 + ny_ + nz_ > 1. ? resx0 + ny_ + nz_ : 1.;
-            dres = sqrt(nrx) / d3;
-        }
-        const double apc = fabs(pcost) > 1e-300 ? fabs(pcost) : 1e-300;
-        const double relgap = gap / apc;
-        if (!(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300)
-        {
-            status = -2;
-            break;
-        }
-        if (pres < opt.feastol && dres < opt.feastol && (gap < opt.abstol || relgap < opt.reltol))
-        {
-            status = 0;
-            break;
-        }
-        if (iter >= opt.maxit)
-        {
-            status = -1;
-            break;
-        }
-
-        // ================= scalings =================
+        phResiduals(c, gp, itp);
         PROF_T(tr1);
         PROF_ADD(1, tr0, tr1);
-        int bad = 0;
-        if (vst)
         {
-            bad |= coneScaling<C1, 17>(st, 0);
-            if (act & 2u)
-                bad |= coneScaling<C2, 3>(st, 1);
-            if (act & 4u)
-                bad |= coneScaling<C3, 3>(st, 2);
-            if (act & 8u)
-                bad |= coneScaling<C4, 3>(st, 3);
-            bad |= coneScaling<C5, 4>(st, 4);
-            bad |= coneScaling<C6, 3>(st, 5);
+            const double pres = it.pres, dres = it.dres, gap = it.gap;
+            const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
+            const double relgap = gap / apc;
+            if (!(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300)
+            {
+                status = -2;
+                break;
+            }
+            if (pres < opt.feastol && dres < opt.feastol && (gap < opt.abstol || relgap < opt.reltol))
+            {
+                status = 0;
+                break;
+            }
+            if (iter >= opt.maxit)
+            {
+                status = -1;
+                break;
+            }
         }
-        if (!cone::nt_scaling(g.sc3, g.zc3, 3, g.seta, g.sw))
-            bad = 1;
-        bad = wave_or(bad);
-        if (bad)
+        phScalings(c, gp, itp);
+        PROF_T(tr2);
+        PROF_ADD(2, tr1, tr2);
+        if (it.bad)
         {
             status = -2;
             break;
         }
-        cone::applyW(g.seta, g.sw, 3, g.zc3, g.lamC);
-        WAVE_SYNC();
-        PROF_T(tr2);
-        PROF_ADD(2, tr1, tr2);
-        prepareFactor(c, false, g);
-        PROF_T(tr3);
-        PROF_ADD(8, tr2, tr3);
-
-        double sigma_c = 0., alpha = 1.;
-        double tzs = 0., tzc[3] = {0., 0., 0.};
-        for (int pass = 0; pass < 2 && !bad; pass++)
+        for (int pass = 0; pass < 2; pass++)
         {
-            const double om = 1. - sigma_c;
             PROF_T(tq0);
-            // ---------- t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ----------
-            if (vst)
-            {
-                {
-                    const double sigmu = sigma_c * mu;
-                    coneT<C1, 17>(st, 0, pass, om, sigmu);
-                    if (act & 2u)
-                        coneT<C2, 3>(st, 1, pass, om, sigmu);
-                    else
-                        zeroT<C2, 3>(st);
-                    if (act & 4u)
-                        coneT<C3, 3>(st, 2, pass, om, sigmu);
-                    else
-                        zeroT<C3, 3>(st);
-                    if (act & 8u)
-                        coneT<C4, 3>(st, 3, pass, om, sigmu);
-                    else
-                        zeroT<C4, 3>(st);
-                    coneT<C5, 4>(st, 4, pass, om, sigmu);
-                    coneT<C6, 3>(st, 5, pass, om, sigmu);
-                }
-                for (int which = 0; which < 2; which++)
-                {
-                    const int o = which ? L2 : L1;
-                    if (!(act & (1u << (6 + which))))
-                    {
-                        st[F_TZ + o] = 0.;
-                        continue;
-                    }
-                    const double sv = st[F_S + o], zv = st[F_Z + o];
-                    const double corr = pass ? (sigma_c * mu - st[F_DS + o] * st[F_DZ + o]) / sv : 0.;
-                    st[F_TZ + o] = (zv / sv) * om * st[F_RZ + o] - zv + corr;
-                }
-                double gw[NV], gdl;
-                LTmul(ip, fm, st + F_TZ, st + F_UHAT, gw, &gdl);
-                for (int j = 0; j < NV; j++)
-                    st[F_BXW + j] = -om * st[F_RXW + j] + gw[j];
-                st[F_BXD] = -om * st[F_RXD] + gdl;
-            }
-            if (vsg)
-                for (int i = 0; i < NL; i++)
-                {
-                    const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-                    const double c1 = pass ? (sigma_c * mu - sg[G_DS1 * NL + i] * sg[G_DZ1 * NL + i]) / s1 : 0.;
-                    const double c2 = pass ? (sigma_c * mu - sg[G_DS2 * NL + i] * sg[G_DZ2 * NL + i]) / s2 : 0.;
-                    const double t1 = (z1 / s1) * om * sg[G_RZ1 * NL + i] - z1 + c1;
-                    const double t2 = (z2 / s2) * om * sg[G_RZ2 * NL + i] - z2 + c2;
-                    sg[G_TZ1 * NL + i] = t1;
-                    sg[G_TZ2 * NL + i] = t2;
-                    sg[G_BXNU * NL + i] = -om * sg[G_RXNU * NL + i] + (-t1 + t2);
-                    sg[G_BXNUB * NL + i] = -om * sg[G_RXNUB * NL + i] + (t1 + t2);
-                    sg[G_BY * NL + i] = -om * sg[G_RY * NL + i];
-                }
-            tzs = (g.zs / g.ss) * om * rzs - g.zs + (pass ? (sigma_c * mu - g.dss * g.dzs) / g.ss : 0.);
-            {
-                double aa[3], b2[3];
-                for (int i = 0; i < 3; i++)
-                    aa[i] = om * rzc[i];
-                cone::applyWinv2(g.seta, g.sw, 3, aa, b2);
-                if (pass == 0)
-                    for (int i = 0; i < 3; i++)
-                        tzc[i] = b2[i] - g.zc3[i];
-                else
-                {
-                    double dsv[3];
-                    cone::conicProduct(3, g.dsC, g.dzC, dsv);
-                    for (int i = 0; i < 3; i++)
-                        dsv[i] = -dsv[i];
-                    dsv[0] += sigma_c * mu;
-                    cone::conicDivision(3, g.lamC, dsv, dsv);
-                    for (int i = 0; i < 3; i++)
-                        dsv[i] -= g.lamC[i];
-                    cone::applyWinv(g.seta, g.sw, 3, dsv, aa);
-                    for (int i = 0; i < 3; i++)
-                        tzc[i] = b2[i] + aa[i];
-                }
-            }
-            const double ds3v = -g.s3 * g.z3 + (pass ? (sigma_c * mu - g.ds3 * g.dz3) : 0.);
-            Rhs b;
-            b.s = -om * rxs + tzs + tzc[2];
-            b.ds = -om * rxds + 0.5 * tzc[0] - 0.5 * tzc[1];
-            b.n1 = -om * rxn1;
-            b.rhs3 = -om * rz3 - ds3v / g.z3;
-            const double bts = kktPrep(c, false, g, b, F_BETA, G_RHO);
-            WAVE_SYNC();
+            phRhs(c, gp, itp, pass);
             PROF_T(tq1);
             PROF_ADD(4, tq0, tq1);
             if (pass == 0)
@@ -958,184 +1380,50 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
                 // column and of the affine right-hand side
                 const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-                factorSweepFused(cesc, sh, sp);
+                factorSweepFused(c, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
-                bwdSweep(cesc, sp);
-                borderSchur(c, g);
+                bwdSweep(c, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             else
             {
                 const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-                fwdSweep(cesc, sp);
+                fwdSweep(c, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
-                bwdSweep(cesc, sp);
+                bwdSweep(c, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
-            if (!(g.schur > 0.))
-                bad = 1;
-            kktFinish(c, false, g, b, bts, F_VW, G_VL);
             PROF_T(tq2);
             PROF_ADD(5, tq1, tq2);
-            // ---------- dz = -W^-2 L dx + t ; ds = -rz' + L dx ; step length ----------
-            double ainv = 0.;
-            if (vst)
-            {
-                double Ld[NS];
-                Lmul(ip, act, st + F_DW, st[F_DDL], st + F_UHAT, Ld);
-                {
-                    double a0 = coneDir<C1, 17>(st, 0, om, Ld);
-                    ainv = a0 > ainv ? a0 : ainv;
-                    if (act & 2u)
-                    {
-                        a0 = coneDir<C2, 3>(st, 1, om, Ld);
-                        ainv = a0 > ainv ? a0 : ainv;
-                    }
-                    if (act & 4u)
-                    {
-                        a0 = coneDir<C3, 3>(st, 2, om, Ld);
-                        ainv = a0 > ainv ? a0 : ainv;
-                    }
-                    if (act & 8u)
-                    {
-                        a0 = coneDir<C4, 3>(st, 3, om, Ld);
-                        ainv = a0 > ainv ? a0 : ainv;
-                    }
-                    a0 = coneDir<C5, 4>(st, 4, om, Ld);
-                    ainv = a0 > ainv ? a0 : ainv;
-                    a0 = coneDir<C6, 3>(st, 5, om, Ld);
-                    ainv = a0 > ainv ? a0 : ainv;
-                }
-                for (int which = 0; which < 2; which++)
-                {
-                    const int o = which ? L2 : L1;
-                    if (!(act & (1u << (6 + which))))
-                        continue;
-                    const double sv = st[F_S + o], zv = st[F_Z + o];
-                    const double dzv = -(zv / sv) * Ld[o] + st[F_TZ + o];
-                    const double dsv = -om * st[F_RZ + o] + Ld[o];
-                    st[F_DZ + o] = dzv;
-                    st[F_DS + o] = dsv;
-                    const double a1 = -dsv / sv, a2 = -dzv / zv;
-                    ainv = a1 > ainv ? a1 : ainv;
-                    ainv = a2 > ainv ? a2 : ainv;
-                }
-            }
-            double sumdnb = 0.;
-            if (vsg)
-                for (int i = 0; i < NL; i++)
-                {
-                    const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-                    const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
-                    const double L1v = dnub - dnu, L2v = dnub + dnu;
-                    const double dz1 = -(z1 / s1) * L1v + sg[G_TZ1 * NL + i], ds1 = -om * sg[G_RZ1 * NL + i] + L1v;
-                    const double dz2 = -(z2 / s2) * L2v + sg[G_TZ2 * NL + i], ds2 = -om * sg[G_RZ2 * NL + i] + L2v;
-                    sg[G_DZ1 * NL + i] = dz1;
-                    sg[G_DS1 * NL + i] = ds1;
-                    sg[G_DZ2 * NL + i] = dz2;
-                    sg[G_DS2 * NL + i] = ds2;
-                    double m1 = -ds1 / s1, m2 = -dz1 / z1, m3 = -ds2 / s2, m4 = -dz2 / z2;
-                    m1 = m1 > m2 ? m1 : m2;
-                    m3 = m3 > m4 ? m3 : m4;
-                    m1 = m1 > m3 ? m1 : m3;
-                    ainv = m1 > ainv ? m1 : ainv;
-                    sumdnb += dnub;
-                }
-            sumdnb = wave_sum(sumdnb);
-            g.dzs = -(g.zs / g.ss) * g.dsig + tzs;
-            g.dss = -om * rzs + g.dsig;
-            {
-                const double m1 = -g.dss / g.ss, m2 = -g.dzs / g.zs;
-                ainv = m1 > ainv ? m1 : ainv;
-                ainv = m2 > ainv ? m2 : ainv;
-            }
-            g.ds3 = -om * rz3 + (g.dn1 - sumdnb);
-            {
-                const double m1 = -g.ds3 / g.s3, m2 = -g.dz3 / g.z3;
-                ainv = m1 > ainv ? m1 : ainv;
-                ainv = m2 > ainv ? m2 : ainv;
-            }
-            {
-                const double Ld[3] = {0.5 * g.ddsg, -0.5 * g.ddsg, g.dsig};
-                double aa[3];
-                cone::applyWinv2(g.seta, g.sw, 3, Ld, aa);
-                for (int i = 0; i < 3; i++)
-                {
-                    g.dzc3[i] = -aa[i] + tzc[i];
-                    g.dsc3[i] = -om * rzc[i] + Ld[i];
-                }
-                cone::applyWinv(g.seta, g.sw, 3, g.dsc3, g.dsC);
-                cone::applyW(g.seta, g.sw, 3, g.dzc3, g.dzC);
-                const double a1 = cone::stepInv(3, g.lamC, g.dsC), a2 = cone::stepInv(3, g.lamC, g.dzC);
-                ainv = a1 > ainv ? a1 : ainv;
-                ainv = a2 > ainv ? a2 : ainv;
-            }
-            ainv = wave_max(ainv);
-            if (pass == 0)
-            {
-                double alpha_a = ainv > 0. ? 1. / ainv : 1.;
-                alpha_a = alpha_a < 1. ? alpha_a : 1.;
-                sigma_c = (1. - alpha_a) * (1. - alpha_a) * (1. - alpha_a);
-                sigma_c = sigma_c < 1e-4 ? 1e-4 : sigma_c;
-                sigma_c = sigma_c > 1. ? 1. : sigma_c;
-            }
-            else
-            {
-                alpha = ainv > 0. ? opt.gamma / ainv : 1.;
-                alpha = alpha < 1. ? alpha : 1.;
-                alpha = alpha < 0.999 ? alpha : 0.999;
-                alpha = alpha > 1e-8 ? alpha : 1e-8;
-            }
-            WAVE_SYNC();
+            phDirection(c, gp, itp, pass);
             PROF_T(tq3);
             PROF_ADD(6, tq2, tq3);
+            if (it.bad)
+                break;
         }
-        PROF_T(tu0);
-        if (bad)
+        if (it.bad)
         {
             status = -2;
             break;
         }
-        // ================= update =================
-        applyPrimalStep(c, g, alpha);
-        if (vst)
-            for (int i = 0; i < NS; i++)
-            {
-                st[F_S + i] += alpha * st[F_DS + i];
-                st[F_Z + i] += alpha * st[F_DZ + i];
-            }
-        if (vsg)
-            for (int i = 0; i < NL; i++)
-            {
-                sg[G_LAM * NL + i] += alpha * sg[G_DLAM * NL + i];
-                sg[G_S1 * NL + i] += alpha * sg[G_DS1 * NL + i];
-                sg[G_Z1 * NL + i] += alpha * sg[G_DZ1 * NL + i];
-                sg[G_S2 * NL + i] += alpha * sg[G_DS2 * NL + i];
-                sg[G_Z2 * NL + i] += alpha * sg[G_DZ2 * NL + i];
-            }
-        g.ss += alpha * g.dss;
-        g.zs += alpha * g.dzs;
-        g.s3 += alpha * g.ds3;
-        g.z3 += alpha * g.dz3;
-        for (int i = 0; i < 3; i++)
-        {
-            g.sc3[i] += alpha * g.dsc3[i];
-            g.zc3[i] += alpha * g.dzc3[i];
-        }
-        WAVE_SYNC();
+        PROF_T(tu0);
+        phUpdate(c, gp, itp);
         PROF_T(tu1);
         PROF_ADD(7, tu0, tu1);
     }
 
     // =============== outputs: readSolution + SC bookkeeping ===============
+    const bool vst = k < K;
+    const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0));
     double sum_delta = 0.;
     if (vst)
         sum_delta = st[F_DL];
     sum_delta = wave_sum(sum_delta);
+    const double n1 = g.n1, sig = g.sig, dsg = g.dsg;
 #ifdef IPM_PROFILE
     if (a.dbg && lane == 0)
     {
@@ -1148,13 +1436,13 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     if (a.dbg && lane == 0)
     {
         double *d = a.dbg + size_t(inst) * 32;
-        d[0] = pcost;
-        d[1] = gap;
-        d[2] = pres;
-        d[3] = dres;
+        d[0] = it.pcost;
+        d[1] = it.gap;
+        d[2] = it.pres;
+        d[3] = it.dres;
         d[4] = iter;
         d[5] = status;
-        d[6] = g.n1;
+        d[6] = n1;
         d[7] = sum_delta;
     }
     if (status == 0)
@@ -1170,14 +1458,14 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             Uo[3] = 0.;
         }
         if (lane == 0)
-            a.sigma[inst] = g.sig;
+            a.sigma[inst] = sig;
     }
     if (lane == 0)
     {
         a.ipm_iters[inst] += iter;
-        a.norm1_nu[inst] = g.n1;
+        a.norm1_nu[inst] = n1;
         a.sum_delta[inst] = sum_delta;
-        a.delta_sigma[inst] = g.dsg;
+        a.delta_sigma[inst] = dsg;
         if (a.do_sc_update)
         {
             a.sc_iters[inst] += 1;
@@ -1188,9 +1476,9 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             }
             else
             {
-                if (g.n1 < a.nu_tol)
+                if (n1 < a.nu_tol)
                     a.wtrx[inst] = wtrx * 2.;
-                const int conv = (sum_delta < a.delta_tol && g.n1 < a.nu_tol) ? 1 : 0;
+                const int conv = (sum_delta < a.delta_tol && n1 < a.nu_tol) ? 1 : 0;
                 if (conv)
                 {
                     a.converged[inst] = 1;

@@ -29,6 +29,7 @@ __device__ inline Ctx uniformCtx(const Ctx &cin)
     c.lane = threadIdx.x;
     c.st = uniformPtr(cin.st);
     c.sg = uniformPtr(cin.sg);
+    c.dy = uniformPtr(cin.dy);
     c.fac = uniformPtr(cin.fac);
     c.sv = uniformPtr(cin.sv);
     c.A = uniformPtr(cin.A);
