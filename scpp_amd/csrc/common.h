@@ -50,6 +50,33 @@ __device__ __forceinline__ T *uniformPtr(T *p)
 __device__ __forceinline__ int uniformInt(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// 1/d and 1/sqrt(d) from the hardware seed + two Newton steps (no div_scale / div_fixup special-case handling:
+// the arguments are positive, normal pivots)
+#ifdef SCPP_HIP_EMU
+inline double fastRcp(double d) { return 1. / d; }
+inline double fastRsqrt(double d) { return 1. / sqrt(d); }
+#else
+__device__ __forceinline__ double fastRcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fastRsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * y, e = __builtin_fma(-d * y, h, 0.5);
+    y = __builtin_fma(y, e, y);
+    h = 0.5 * y;
+    e = __builtin_fma(-d * y, h, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+#endif
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1)

@@ -175,6 +175,9 @@ struct SV
         __device__ const Ref &operator*=(double x) const { return *this = double(*this) * x; }
     };
     __device__ Ref operator[](int i) const { return Ref{rsrc, lb, (fo + i) * (LANES * 8)}; }
+    // lane-dependent field index: goes into the VGPR offset (a divergent SGPR offset would be resolved by a
+    // waterfall loop over its distinct values)
+    __device__ Ref dyn(int i) const { return Ref{rsrc, lb + (fo + i) * (LANES * 8), 0}; }
     __device__ SV operator+(int o) const { return SV{rsrc, lb, fo + o}; }
 };
 __device__ inline SV makeSV(double *block, int nfields, unsigned lane_index)

@@ -750,7 +750,64 @@ PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     WAVE_SYNC();
 }
 
+
+// batched field access: all loads (stores) of a group are issued back to back; buffer stores may alias buffer
+// loads as far as the compiler knows, so every phase is written as  load group -> compute -> store group
+template <int N>
+__device__ inline void ldf(const SV &r, int f, double (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = r[f + i];
+}
+template <int N>
+__device__ inline void stf(const SV &r, int f, const double (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        r[f + i] = v[i];
+}
+
 // ---- residuals, duality gap, termination quantities ----
+struct ResAcc
+{
+    double gap, rx, ry, rz, xx, yy, zz, ss, rxs, sumnb;
+};
+template <int I0, int N>
+__device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc &p)
+{
+    double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N], S[N];
+    ldf<N>(sg, G_NU * NL + I0, nu);
+    ldf<N>(sg, G_NUB * NL + I0, nub);
+    ldf<N>(sg, G_S1 * NL + I0, s1);
+    ldf<N>(sg, G_Z1 * NL + I0, z1);
+    ldf<N>(sg, G_S2 * NL + I0, s2);
+    ldf<N>(sg, G_Z2 * NL + I0, z2);
+    ldf<N>(sg, G_LAM * NL + I0, lam);
+    ldf<N>(dy, DY_S + I0, S);
+    double r1[N], r2[N], rnu[N], rnub[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        r1[i] = s1[i] - (nub[i] - nu[i]);
+        r2[i] = s2[i] - (nub[i] + nu[i]);
+        rnu[i] = -lam[i] + z1[i] - z2[i];
+        rnub[i] = -z1[i] - z2[i] + z3;
+        p.sumnb += nub[i];
+        p.gap += s1[i] * z1[i] + s2[i] * z2[i];
+        p.rz += r1[i] * r1[i] + r2[i] * r2[i];
+        p.zz += z1[i] * z1[i] + z2[i] * z2[i];
+        p.ss += s1[i] * s1[i] + s2[i] * s2[i];
+        p.yy += lam[i] * lam[i];
+        p.rx += rnu[i] * rnu[i] + rnub[i] * rnub[i];
+        p.xx += nu[i] * nu[i] + nub[i] * nub[i];
+        p.rxs += S[i] * lam[i];
+    }
+    stf<N>(sg, G_RZ1 * NL + I0, r1);
+    stf<N>(sg, G_RZ2 * NL + I0, r2);
+    stf<N>(sg, G_RXNU * NL + I0, rnu);
+    stf<N>(sg, G_RXNUB * NL + I0, rnub);
+}
 PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
@@ -761,54 +818,62 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     const unsigned fm = v.fm;
     const Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
-    double sas, sa3, sac[3];
-    evalAllSaff(c, g, F_RZ, G_RZ1, G_RZ2, sas, sa3, sac);
-    double resv[NL];
-    double p_gap = 0., p_rx = 0., p_ry = 0., p_rz = 0., p_xx = 0., p_yy = 0., p_zz = 0., p_ss = 0., p_rxs = 0., p_dl = 0.;
+    ResAcc p;
+    p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
+    double p_dl = 0.;
+    if (v.vsg)
+    {
+        resSegChunk<0, 5>(sg, dy, g.z3, p);
+        resSegChunk<5, 5>(sg, dy, g.z3, p);
+        resSegChunk<10, 4>(sg, dy, g.z3, p);
+    }
     if (v.vst)
     {
-#pragma unroll
-        for (int i = 0; i < NS; i++)
+        double x0[NV], gw[NV], gdl, dl;
         {
-            const double sv = st[F_S + i], zv = st[F_Z + i];
-            const double r = sv - st[F_RZ + i];
-            st[F_RZ + i] = r;
-            p_gap += sv * zv;
-            p_rz += r * r;
-            p_zz += zv * zv;
-            p_ss += sv * sv;
+            // rz = s - saff(x) ; gap ; L'z
+            double wbar[NV], uh[3], sa[NS], sv[NS];
+            ldf<NV>(st, F_W, x0);
+            ldf<NV>(st, F_WBAR, wbar);
+            ldf<3>(st, F_UHAT, uh);
+            dl = st[F_DL];
+            ldf<NS>(st, F_S, sv);
+            saff(ip, v.act, x0, dl, wbar, uh, sa);
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+            {
+                sa[i] = sv[i] - sa[i];
+                p.rz += sa[i] * sa[i];
+                p.ss += sv[i] * sv[i];
+            }
+            stf<NS>(st, F_RZ, sa);
+            double zv[NS];
+            ldf<NS>(st, F_Z, zv);
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+            {
+                p.gap += sv[i] * zv[i];
+                p.zz += zv[i] * zv[i];
+            }
+            LTmul(ip, fm, zv, uh, gw, &gdl);
         }
-        double gw[NV], gdl;
-        LTmul(ip, fm, st + F_Z, st + F_UHAT, gw, &gdl);
         const double rxd = it.wtrx - gdl;
-        st[F_RXD] = rxd;
         // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
         // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
-        double acc[NV], x0[NV], u1[3];
+        double acc[NV], u1[3], resv[NL];
 #pragma unroll
         for (int j = 0; j < NV; j++)
-        {
             acc[j] = 0.;
-            x0[j] = st[F_W + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            u1[j] = stN[F_W + 13 + j];
+        ldf<3>(stN, F_W + 13, u1);
         const double mk = v.vsg ? 1. : 0., mp = k > 0 ? 1. : 0.;
 #pragma unroll
         for (int i = 0; i < NL; i++)
         {
             double ra[13], rb[3], rc[3], rcp[3];
-#pragma unroll
-            for (int j = 0; j < 13; j++)
-                ra[j] = dy[DY_A + i * NX + j];
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-            {
-                rb[j] = dy[DY_B + i * NU + j];
-                rc[j] = dy[DY_C + i * NU + j];
-                rcp[j] = dyP[DY_C + i * NU + j];
-            }
+            ldf<13>(dy, DY_A + i * NX, ra);
+            ldf<3>(dy, DY_B + i * NU, rb);
+            ldf<3>(dy, DY_C + i * NU, rc);
+            ldf<3>(dyP, DY_C + i * NU, rcp);
             const double l = mk * double(sg[G_LAM * NL + i]), lp = mp * double(sgP[G_LAM * NL + i]);
             double rr = (i < 13 ? double(stN[F_W + (i < 13 ? i : 0)]) : 0.) - dy[DY_S + i] * g.sig - sg[G_NU * NL + i] - dy[DY_Z + i];
 #pragma unroll
@@ -826,68 +891,50 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
             if (i < 13)
                 acc[i] += lp;
             resv[i] = rr;
+            p.ry += v.vsg ? rr * rr : 0.;
         }
-        p_rx += rxd * rxd;
-        const double dl = st[F_DL];
-        p_xx += dl * dl;
+        p.rx += rxd * rxd;
+        p.xx += dl * dl;
         p_dl += dl;
+        double rxw[NV];
 #pragma unroll
         for (int j = 0; j < NV; j++)
         {
             const bool fx = fm & (1u << j);
             const double r = -gw[j] + (fx ? 0. : acc[j]);
-            st[F_RXW + j] = r;
-            p_rx += fx ? 0. : r * r;
-            p_xx += fx ? 0. : x0[j] * x0[j];
+            rxw[j] = r;
+            p.rx += fx ? 0. : r * r;
+            p.xx += fx ? 0. : x0[j] * x0[j];
         }
+        st[F_RXD] = rxd;
+        stf<NV>(st, F_RXW, rxw);
+        if (v.vsg)
+            stf<NL>(sg, G_RY * NL, resv);
     }
-    if (v.vsg)
-    {
-#pragma unroll
-        for (int i = 0; i < NL; i++)
-        {
-            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-            const double r1 = s1 - sg[G_RZ1 * NL + i], r2 = s2 - sg[G_RZ2 * NL + i];
-            sg[G_RZ1 * NL + i] = r1;
-            sg[G_RZ2 * NL + i] = r2;
-            sg[G_RY * NL + i] = resv[i];
-            const double l = sg[G_LAM * NL + i];
-            const double rnu = -l + z1 - z2, rnub = -z1 - z2 + g.z3;
-            sg[G_RXNU * NL + i] = rnu;
-            sg[G_RXNUB * NL + i] = rnub;
-            p_gap += s1 * z1 + s2 * z2;
-            p_rz += r1 * r1 + r2 * r2;
-            p_zz += z1 * z1 + z2 * z2;
-            p_ss += s1 * s1 + s2 * s2;
-            p_ry += resv[i] * resv[i];
-            p_yy += l * l;
-            p_rx += rnu * rnu + rnub * rnub;
-            const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
-            p_xx += nu * nu + nub * nub;
-            p_rxs += dy[DY_S + i] * l;
-        }
-    }
-    p_gap = wave_sum(p_gap);
-    p_rx = wave_sum(p_rx);
-    p_ry = wave_sum(p_ry);
-    p_rz = wave_sum(p_rz);
-    p_xx = wave_sum(p_xx);
-    p_yy = wave_sum(p_yy);
-    p_zz = wave_sum(p_zz);
-    p_ss = wave_sum(p_ss);
-    p_rxs = wave_sum(p_rxs);
+    p.gap = wave_sum(p.gap);
+    p.rx = wave_sum(p.rx);
+    p.ry = wave_sum(p.ry);
+    p.rz = wave_sum(p.rz);
+    p.xx = wave_sum(p.xx);
+    p.yy = wave_sum(p.yy);
+    p.zz = wave_sum(p.zz);
+    p.ss = wave_sum(p.ss);
+    p.rxs = wave_sum(p.rxs);
+    p.sumnb = wave_sum(p.sumnb);
     p_dl = wave_sum(p_dl);
+    const double sas = g.sig - 0.001, sa3 = g.n1 - p.sumnb;
+    const double sac[3] = {0.5 + 0.5 * g.dsg, 0.5 - 0.5 * g.dsg, g.sig - g.sigbar};
     it.rzs = g.ss - sas;
     it.rz3 = g.s3 - sa3;
     for (int i = 0; i < 3; i++)
         it.rzc[i] = g.sc3[i] - sac[i];
-    it.rxs = it.w_t - g.zs - g.zc3[2] - p_rxs;
+    it.rxs = it.w_t - g.zs - g.zc3[2] - p.rxs;
     it.rxds = it.w_trt - 0.5 * g.zc3[0] + 0.5 * g.zc3[1];
     it.rxn1 = it.w_vc - g.z3;
-    double gap = p_gap + g.ss * g.zs + g.s3 * g.z3;
-    double nrz = p_rz + it.rzs * it.rzs + it.rz3 * it.rz3;
-    double nzz = p_zz + g.zs * g.zs + g.z3 * g.z3;
-    double nss = p_ss + g.ss * g.ss + g.s3 * g.s3;
+    double gap = p.gap + g.ss * g.zs + g.s3 * g.z3;
+    double nrz = p.rz + it.rzs * it.rzs + it.rz3 * it.rz3;
+    double nzz = p.zz + g.zs * g.zs + g.z3 * g.z3;
+    double nss = p.ss + g.ss * g.ss + g.s3 * g.s3;
     for (int i = 0; i < 3; i++)
     {
         gap += g.sc3[i] * g.zc3[i];
@@ -895,16 +942,16 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
         nzz += g.zc3[i] * g.zc3[i];
         nss += g.sc3[i] * g.sc3[i];
     }
-    const double nrx = p_rx + it.rxs * it.rxs + it.rxds * it.rxds + it.rxn1 * it.rxn1;
-    const double nxx = p_xx + g.sig * g.sig + g.dsg * g.dsg + g.n1 * g.n1;
+    const double nrx = p.rx + it.rxs * it.rxs + it.rxds * it.rxds + it.rxn1 * it.rxn1;
+    const double nxx = p.xx + g.sig * g.sig + g.dsg * g.dsg + g.n1 * g.n1;
     it.gap = gap;
     it.mu = gap / it.D;
     it.pcost = it.w_t * g.sig + it.w_trt * g.dsg + it.w_vc * g.n1 + it.wtrx * p_dl;
     {
-        const double nx_ = sqrt(nxx), ny_ = sqrt(p_yy), nz_ = sqrt(nzz), ns_ = sqrt(nss);
+        const double nx_ = sqrt(nxx), ny_ = sqrt(p.yy), nz_ = sqrt(nzz), ns_ = sqrt(nss);
         const double d1 = it.resy0 + nx_ > 1. ? it.resy0 + nx_ : 1.;
         const double d2 = it.resz0 + nx_ + ns_ > 1. ? it.resz0 + nx_ + ns_ : 1.;
-        const double pa = sqrt(p_ry) / d1, pb = sqrt(nrz) / d2;
+        const double pa = sqrt(p.ry) / d1, pb = sqrt(nrz) / d2;
         it.pres = pa > pb ? pa : pb;
         const double d3 = it.resx0 + ny_ + nz_ > 1. ? it.resx0 + ny_ + nz_ : 1.;
         it.dres = sqrt(nrx) / d3;
@@ -949,6 +996,65 @@ PHASE_FN void phScalings(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
 }
 
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
+// segment rows [I0, I0+N): LP blocks of nu / nu_b, fused with the condensation (kktPrep) of those rows
+template <int I0, int N>
+__device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sigmu, double dz3)
+{
+    double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N], qv[N], einv[N];
+    ldf<N>(sg, G_S1 * NL + I0, s1);
+    ldf<N>(sg, G_Z1 * NL + I0, z1);
+    ldf<N>(sg, G_S2 * NL + I0, s2);
+    ldf<N>(sg, G_Z2 * NL + I0, z2);
+    ldf<N>(sg, G_RZ1 * NL + I0, rz1);
+    ldf<N>(sg, G_RZ2 * NL + I0, rz2);
+    ldf<N>(sg, G_RXNU * NL + I0, rxnu);
+    ldf<N>(sg, G_RXNUB * NL + I0, rxnub);
+    ldf<N>(sg, G_RY * NL + I0, ry);
+    ldf<N>(sg, G_QV * NL + I0, qv);
+    ldf<N>(sg, G_EINV * NL + I0, einv);
+    double c1[N], c2[N];
+    if (pass)
+    {
+        double ds1[N], dz1[N], ds2[N], dz2[N];
+        ldf<N>(sg, G_DS1 * NL + I0, ds1);
+        ldf<N>(sg, G_DZ1 * NL + I0, dz1);
+        ldf<N>(sg, G_DS2 * NL + I0, ds2);
+        ldf<N>(sg, G_DZ2 * NL + I0, dz2);
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            c1[i] = (sigmu - ds1[i] * dz1[i]) / s1[i];
+            c2[i] = (sigmu - ds2[i] * dz2[i]) / s2[i];
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            c1[i] = c2[i] = 0.;
+    }
+    double t1[N], t2[N], dinv[N], bnb[N], btn[N], rho[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        const double d1 = z1[i] / s1[i], d2 = z2[i] / s2[i];
+        t1[i] = d1 * om * rz1[i] - z1[i] + c1[i];
+        t2[i] = d2 * om * rz2[i] - z2[i] + c2[i];
+        const double bxnu = -om * rxnu[i] + (-t1[i] + t2[i]);
+        const double bxnub = -om * rxnub[i] + (t1[i] + t2[i]);
+        const double by = -om * ry[i];
+        dinv[i] = 1. / (d1 + d2);
+        bnb[i] = bxnub - dz3;
+        btn[i] = bxnu - qv[i] * bnb[i];
+        rho[i] = by + einv[i] * btn[i];
+    }
+    stf<N>(sg, G_TZ1 * NL + I0, t1);
+    stf<N>(sg, G_TZ2 * NL + I0, t2);
+    stf<N>(sg, G_DINV * NL + I0, dinv);
+    stf<N>(sg, G_BNB * NL + I0, bnb);
+    stf<N>(sg, G_BTN * NL + I0, btn);
+    stf<N>(sg, G_RHO * NL + I0, rho);
+}
 PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
     const Ctx c = uniformCtx(cin);
@@ -960,10 +1066,44 @@ PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
     const double sigma_c = pass ? it.sigma_c : 0., mu = it.mu;
-    const double om = 1. - sigma_c;
+    const double om = 1. - sigma_c, sigmu = sigma_c * mu;
+    // ---- wave-uniform rows (sigma, delta_sigma, n1 and their cones) ----
+    it.tzs = (g.zs / g.ss) * om * it.rzs - g.zs + (pass ? (sigmu - g.dss * g.dzs) / g.ss : 0.);
+    {
+        double aa[3], b2[3];
+        for (int i = 0; i < 3; i++)
+            aa[i] = om * it.rzc[i];
+        cone::applyWinv2(g.seta, g.sw, 3, aa, b2);
+        if (pass == 0)
+            for (int i = 0; i < 3; i++)
+                it.tzc[i] = b2[i] - g.zc3[i];
+        else
+        {
+            double dsv[3];
+            cone::conicProduct(3, g.dsC, g.dzC, dsv);
+            for (int i = 0; i < 3; i++)
+                dsv[i] = -dsv[i];
+            dsv[0] += sigmu;
+            cone::conicDivision(3, g.lamC, dsv, dsv);
+            for (int i = 0; i < 3; i++)
+                dsv[i] -= g.lamC[i];
+            cone::applyWinv(g.seta, g.sw, 3, dsv, aa);
+            for (int i = 0; i < 3; i++)
+                it.tzc[i] = b2[i] + aa[i];
+        }
+    }
+    const double ds3v = -g.s3 * g.z3 + (pass ? (sigmu - g.ds3 * g.dz3) : 0.);
+    Rhs b;
+    b.s = -om * it.rxs + it.tzs + it.tzc[2];
+    b.ds = -om * it.rxds + 0.5 * it.tzc[0] - 0.5 * it.tzc[1];
+    b.n1 = -om * it.rxn1;
+    b.rhs3 = -om * it.rz3 - ds3v / g.z3;
+    g.dz3 = -b.n1;
+    it.bts = b.s - g.Hsd * b.ds / g.Hdd;
+    it.b = b;
+    // ---- stages ----
     if (v.vst)
     {
-        const double sigmu = sigma_c * mu;
         coneT<C1, 17>(st, 0, pass, om, sigmu);
         if (act & 2u)
             coneT<C2, 3>(st, 1, pass, om, sigmu);
@@ -979,109 +1119,163 @@ PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
             zeroT<C4, 3>(st);
         coneT<C5, 4>(st, 4, pass, om, sigmu);
         coneT<C6, 3>(st, 5, pass, om, sigmu);
-        for (int which = 0; which < 2; which++)
         {
-            const int o = which ? L2 : L1;
-            if (!(act & (1u << (6 + which))))
+            // the two LP rows (mass, minimum thrust)
+            double sv[2], zv[2], rz[2], dsv[2], dzv[2], tz[2];
+            ldf<2>(st, F_S + L1, sv);
+            ldf<2>(st, F_Z + L1, zv);
+            ldf<2>(st, F_RZ + L1, rz);
+            ldf<2>(st, F_DS + L1, dsv);
+            ldf<2>(st, F_DZ + L1, dzv);
+#pragma unroll
+            for (int w = 0; w < 2; w++)
             {
-                st[F_TZ + o] = 0.;
-                continue;
+                const double corr = pass ? (sigmu - dsv[w] * dzv[w]) / sv[w] : 0.;
+                tz[w] = (act & (1u << (6 + w))) ? (zv[w] / sv[w]) * om * rz[w] - zv[w] + corr : 0.;
             }
-            const double sv = st[F_S + o], zv = st[F_Z + o];
-            const double corr = pass ? (sigma_c * mu - st[F_DS + o] * st[F_DZ + o]) / sv : 0.;
-            st[F_TZ + o] = (zv / sv) * om * st[F_RZ + o] - zv + corr;
+            stf<2>(st, F_TZ + L1, tz);
         }
-        double gw[NV], gdl;
-        LTmul(ip, fm, st + F_TZ, st + F_UHAT, gw, &gdl);
-        double rxw[NV];
+        double tzv[NS], uh[3], gw[NV], gdl;
+        ldf<NS>(st, F_TZ, tzv);
+        ldf<3>(st, F_UHAT, uh);
+        LTmul(ip, fm, tzv, uh, gw, &gdl);
+        double rxw[NV], hdw[NV], beta[NV];
+        ldf<NV>(st, F_RXW, rxw);
+        ldf<NV>(st, F_HDW, hdw);
+        const double rxd = st[F_RXD], hdd = st[F_HDD];
+        const double bxd = -om * rxd + gdl;
+        const double q = bxd / hdd;
 #pragma unroll
         for (int j = 0; j < NV; j++)
-            rxw[j] = st[F_RXW + j];
-        const double rxd = st[F_RXD];
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-            st[F_BXW + j] = -om * rxw[j] + gw[j];
-        st[F_BXD] = -om * rxd + gdl;
+        {
+            rxw[j] = -om * rxw[j] + gw[j];
+            beta[j] = (fm & (1u << j)) ? 0. : rxw[j] - hdw[j] * q;
+        }
+        stf<NV>(st, F_BXW, rxw);
+        st[F_BXD] = bxd;
+        stf<NV>(st, F_BETA, beta);
     }
     if (v.vsg)
     {
-#pragma unroll
-        for (int i = 0; i < NL; i++)
-        {
-            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-            const double c1 = pass ? (sigma_c * mu - sg[G_DS1 * NL + i] * sg[G_DZ1 * NL + i]) / s1 : 0.;
-            const double c2 = pass ? (sigma_c * mu - sg[G_DS2 * NL + i] * sg[G_DZ2 * NL + i]) / s2 : 0.;
-            const double rz1 = sg[G_RZ1 * NL + i], rz2 = sg[G_RZ2 * NL + i];
-            const double rxnu = sg[G_RXNU * NL + i], rxnub = sg[G_RXNUB * NL + i], ry = sg[G_RY * NL + i];
-            const double t1 = (z1 / s1) * om * rz1 - z1 + c1;
-            const double t2 = (z2 / s2) * om * rz2 - z2 + c2;
-            sg[G_TZ1 * NL + i] = t1;
-            sg[G_TZ2 * NL + i] = t2;
-            sg[G_BXNU * NL + i] = -om * rxnu + (-t1 + t2);
-            sg[G_BXNUB * NL + i] = -om * rxnub + (t1 + t2);
-            sg[G_BY * NL + i] = -om * ry;
-        }
+        rhsSegChunk<0, 5>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<5, 5>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<10, 4>(sg, pass, om, sigmu, g.dz3);
     }
-    it.tzs = (g.zs / g.ss) * om * it.rzs - g.zs + (pass ? (sigma_c * mu - g.dss * g.dzs) / g.ss : 0.);
-    {
-        double aa[3], b2[3];
-        for (int i = 0; i < 3; i++)
-            aa[i] = om * it.rzc[i];
-        cone::applyWinv2(g.seta, g.sw, 3, aa, b2);
-        if (pass == 0)
-            for (int i = 0; i < 3; i++)
-                it.tzc[i] = b2[i] - g.zc3[i];
-        else
-        {
-            double dsv[3];
-            cone::conicProduct(3, g.dsC, g.dzC, dsv);
-            for (int i = 0; i < 3; i++)
-                dsv[i] = -dsv[i];
-            dsv[0] += sigma_c * mu;
-            cone::conicDivision(3, g.lamC, dsv, dsv);
-            for (int i = 0; i < 3; i++)
-                dsv[i] -= g.lamC[i];
-            cone::applyWinv(g.seta, g.sw, 3, dsv, aa);
-            for (int i = 0; i < 3; i++)
-                it.tzc[i] = b2[i] + aa[i];
-        }
-    }
-    const double ds3v = -g.s3 * g.z3 + (pass ? (sigma_c * mu - g.ds3 * g.dz3) : 0.);
-    Rhs b;
-    b.s = -om * it.rxs + it.tzs + it.tzc[2];
-    b.ds = -om * it.rxds + 0.5 * it.tzc[0] - 0.5 * it.tzc[1];
-    b.n1 = -om * it.rxn1;
-    b.rhs3 = -om * it.rz3 - ds3v / g.z3;
-    it.bts = kktPrep(c, false, g, b, F_BETA, G_RHO);
-    it.b = b;
     storePriv(gp, g);
     storePriv(ip_, it);
     WAVE_SYNC();
 }
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
+template <int I0, int N>
+__device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double &ainv, double &sumdnb)
+{
+    double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
+    double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
+    ldf<N>(sg, G_VL * NL + I0, vl);
+    ldf<N>(sg, G_BCL * NL + I0, bcl);
+    ldf<N>(sg, G_EINV * NL + I0, einv);
+    ldf<N>(sg, G_BTN * NL + I0, btn);
+    ldf<N>(sg, G_BNB * NL + I0, bnb);
+    ldf<N>(sg, G_DINV * NL + I0, dinv);
+    ldf<N>(sg, G_QV * NL + I0, qv);
+    ldf<N>(sg, G_S1 * NL + I0, s1);
+    ldf<N>(sg, G_Z1 * NL + I0, z1);
+    ldf<N>(sg, G_S2 * NL + I0, s2);
+    ldf<N>(sg, G_Z2 * NL + I0, z2);
+    ldf<N>(sg, G_TZ1 * NL + I0, tz1);
+    ldf<N>(sg, G_TZ2 * NL + I0, tz2);
+    ldf<N>(sg, G_RZ1 * NL + I0, rz1);
+    ldf<N>(sg, G_RZ2 * NL + I0, rz2);
+    double dlam[N], dnu[N], dnub[N], dz1[N], ds1[N], dz2[N], ds2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        dlam[i] = vl[i] - bcl[i] * dsig;
+        dnu[i] = einv[i] * (dlam[i] + btn[i]);
+        dnub[i] = bnb[i] * dinv[i] - qv[i] * dnu[i];
+        sumdnb += dnub[i];
+        const double L1v = dnub[i] - dnu[i], L2v = dnub[i] + dnu[i];
+        dz1[i] = -(z1[i] / s1[i]) * L1v + tz1[i];
+        ds1[i] = -om * rz1[i] + L1v;
+        dz2[i] = -(z2[i] / s2[i]) * L2v + tz2[i];
+        ds2[i] = -om * rz2[i] + L2v;
+        double m1 = -ds1[i] / s1[i], m2 = -dz1[i] / z1[i], m3 = -ds2[i] / s2[i], m4 = -dz2[i] / z2[i];
+        m1 = m1 > m2 ? m1 : m2;
+        m3 = m3 > m4 ? m3 : m4;
+        m1 = m1 > m3 ? m1 : m3;
+        ainv = m1 > ainv ? m1 : ainv;
+    }
+    stf<N>(sg, G_DLAM * NL + I0, dlam);
+    stf<N>(sg, G_DNU * NL + I0, dnu);
+    stf<N>(sg, G_DNUB * NL + I0, dnub);
+    stf<N>(sg, G_DZ1 * NL + I0, dz1);
+    stf<N>(sg, G_DS1 * NL + I0, ds1);
+    stf<N>(sg, G_DZ2 * NL + I0, dz2);
+    stf<N>(sg, G_DS2 * NL + I0, ds2);
+}
 PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
     const Ctx c = uniformCtx(cin);
     const int pass = uniformInt(passIn);
     const Views v = makeViews(c);
-    const SV &st = v.st, &sg = v.sg;
+    const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     const unsigned act = v.act;
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
     const double sigma_c = pass ? it.sigma_c : 0.;
     const double om = 1. - sigma_c;
-    if (pass == 0)
-        borderSchur(c, g);
-    if (!(g.schur > 0.))
-        it.bad = 1;
-    kktFinish(c, false, g, it.b, it.bts, F_VW, G_VL);
+    // ---- sigma row: border correction (and the border's Schur complement, once per factorisation) ----
+    {
+        double cv = 0., bs = 0.;
+        if (v.vsg)
+        {
+            double S[NL], vl[NL], bcl[NL];
+            ldf<NL>(dy, DY_S, S);
+            ldf<NL>(sg, G_VL * NL, vl);
+            ldf<NL>(sg, G_BCL * NL, bcl);
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+            {
+                cv -= S[i] * vl[i];
+                bs -= S[i] * bcl[i];
+            }
+        }
+        cv = wave_sum(cv);
+        if (pass == 0)
+        {
+            bs = wave_sum(bs);
+            g.schur = g.hsig - bs;
+        }
+        if (!(g.schur > 0.))
+            it.bad = 1;
+        g.dsig = (it.bts - cv) / g.schur;
+        g.ddsg = (it.b.ds - g.Hsd * g.dsig) / g.Hdd;
+    }
     double ainv = 0.;
     if (v.vst)
     {
         double Ld[NS];
-        Lmul(ip, act, st + F_DW, st[F_DDL], st + F_UHAT, Ld);
+        {
+            double dw[NV], bcw[NV], hdw[NV], uh[3];
+            ldf<NV>(st, F_VW, dw);
+            ldf<NV>(st, F_BCW, bcw);
+            ldf<NV>(st, F_HDW, hdw);
+            ldf<3>(st, F_UHAT, uh);
+            const double bxd = st[F_BXD], hdd = st[F_HDD];
+            double acc = 0.;
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+            {
+                dw[j] -= bcw[j] * g.dsig;
+                acc += hdw[j] * dw[j];
+            }
+            const double ddl = (bxd - acc) / hdd;
+            stf<NV>(st, F_DW, dw);
+            st[F_DDL] = ddl;
+            Lmul(ip, act, dw, ddl, uh, Ld);
+        }
         double a0 = coneDir<C1, 17>(st, 0, om, Ld);
         ainv = a0 > ainv ? a0 : ainv;
         if (act & 2u)
@@ -1103,46 +1297,35 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
         ainv = a0 > ainv ? a0 : ainv;
         a0 = coneDir<C6, 3>(st, 5, om, Ld);
         ainv = a0 > ainv ? a0 : ainv;
-        for (int which = 0; which < 2; which++)
         {
-            const int o = which ? L2 : L1;
-            if (!(act & (1u << (6 + which))))
-                continue;
-            const double sv = st[F_S + o], zv = st[F_Z + o];
-            const double dzv = -(zv / sv) * Ld[o] + st[F_TZ + o];
-            const double dsv = -om * st[F_RZ + o] + Ld[o];
-            st[F_DZ + o] = dzv;
-            st[F_DS + o] = dsv;
-            const double a1 = -dsv / sv, a2 = -dzv / zv;
-            ainv = a1 > ainv ? a1 : ainv;
-            ainv = a2 > ainv ? a2 : ainv;
+            double sv[2], zv[2], rz[2], tz[2], dzv[2], dsv[2];
+            ldf<2>(st, F_S + L1, sv);
+            ldf<2>(st, F_Z + L1, zv);
+            ldf<2>(st, F_RZ + L1, rz);
+            ldf<2>(st, F_TZ + L1, tz);
+#pragma unroll
+            for (int w = 0; w < 2; w++)
+            {
+                const bool on = act & (1u << (6 + w));
+                dzv[w] = on ? -(zv[w] / sv[w]) * Ld[L1 + w] + tz[w] : 0.;
+                dsv[w] = on ? -om * rz[w] + Ld[L1 + w] : 0.;
+                const double a1 = on ? -dsv[w] / sv[w] : 0., a2 = on ? -dzv[w] / zv[w] : 0.;
+                ainv = a1 > ainv ? a1 : ainv;
+                ainv = a2 > ainv ? a2 : ainv;
+            }
+            stf<2>(st, F_DZ + L1, dzv);
+            stf<2>(st, F_DS + L1, dsv);
         }
     }
     double sumdnb = 0.;
     if (v.vsg)
     {
-#pragma unroll
-        for (int i = 0; i < NL; i++)
-        {
-            const double s1 = sg[G_S1 * NL + i], z1 = sg[G_Z1 * NL + i], s2 = sg[G_S2 * NL + i], z2 = sg[G_Z2 * NL + i];
-            const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
-            const double tz1 = sg[G_TZ1 * NL + i], tz2 = sg[G_TZ2 * NL + i], rz1 = sg[G_RZ1 * NL + i], rz2 = sg[G_RZ2 * NL + i];
-            const double L1v = dnub - dnu, L2v = dnub + dnu;
-            const double dz1 = -(z1 / s1) * L1v + tz1, ds1 = -om * rz1 + L1v;
-            const double dz2 = -(z2 / s2) * L2v + tz2, ds2 = -om * rz2 + L2v;
-            sg[G_DZ1 * NL + i] = dz1;
-            sg[G_DS1 * NL + i] = ds1;
-            sg[G_DZ2 * NL + i] = dz2;
-            sg[G_DS2 * NL + i] = ds2;
-            double m1 = -ds1 / s1, m2 = -dz1 / z1, m3 = -ds2 / s2, m4 = -dz2 / z2;
-            m1 = m1 > m2 ? m1 : m2;
-            m3 = m3 > m4 ? m3 : m4;
-            m1 = m1 > m3 ? m1 : m3;
-            ainv = m1 > ainv ? m1 : ainv;
-            sumdnb += dnub;
-        }
+        dirSegChunk<0, 5>(sg, om, g.dsig, ainv, sumdnb);
+        dirSegChunk<5, 5>(sg, om, g.dsig, ainv, sumdnb);
+        dirSegChunk<10, 4>(sg, om, g.dsig, ainv, sumdnb);
     }
     sumdnb = wave_sum(sumdnb);
+    g.dn1 = sumdnb - (g.s3 / g.z3) * g.dz3 - it.b.rhs3;
     g.dzs = -(g.zs / g.ss) * g.dsig + it.tzs;
     g.dss = -om * it.rzs + g.dsig;
     {

@@ -163,14 +163,14 @@ __device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
     HRaw h;
     h.e2 = st[F_HC];
     h.cc = st[F_HC + 1];
-    h.wcol = st[F_WB + 1 + i];
+    h.wcol = st.dyn(F_WB + 1 + i);
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
         const int row = g + 4 * r;
-        h.wrow[r] = st[F_WB + 1 + row];
+        h.wrow[r] = st.dyn(F_WB + 1 + row);
         const int idx = hsIndex(row, i);
-        h.hs[r] = st[F_HS + (idx >= 0 ? idx : 0)];
+        h.hs[r] = st.dyn(F_HS + (idx >= 0 ? idx : 0));
     }
     return h;
 }

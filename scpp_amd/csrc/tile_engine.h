@@ -134,8 +134,13 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 }
 
 // Li = chol(A)^-1 (lower triangular, D-layout) of the SPD leading n x n block of tile A; rows/cols >= n: identity.
-// Fully unrolled, branch-free elimination: per step ONE LDS turnaround (publish pivot column of A and pivot row
-// of R, read the 7 values this lane needs in one batch), one reciprocal, 8 predicated FMAs.
+// Gaussian elimination on [A | I], fully unrolled so that everything that depends only on the step index is
+// resolved at compile time (which register holds pivot row j, which register rows lie entirely above /
+// below the pivot).  Per step: ONE LDS turnaround (publish pivot column of A and pivot row of R, read the
+// <= 8 values this lane needs in one batch), a Newton reciprocal, <= 8 predicated FMAs.
+#ifndef INVCHOL_UNROLL
+#define INVCHOL_UNROLL _Pragma("unroll")
+#endif
 template <int n>
 __device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
 {
@@ -155,18 +160,19 @@ __device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
     if (g == (i & 3))
         sh.od[i] = od;
     WAVE_SYNC();
-#pragma unroll 1
+    INVCHOL_UNROLL
     for (int j = 0; j < n; j++)
     {
-        const int b = j & 1;
+        const int b = j & 1, rj_ = j >> 2;
         if (i == j)
         {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                sh.colA[b][g + 4 * r] = A.v[r];
+                if (4 * r + 3 >= j) // rows above the pivot are never read
+                    sh.colA[b][g + 4 * r] = A.v[r];
         }
         if (g == (j & 3))
-            { const int rj_ = j >> 2; sh.rowR[b][i] = rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3]; }
+            sh.rowR[b][i] = rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3];
         WAVE_SYNC();
         // one batch of LDS reads (no control flow in between)
         double d = sh.colA[b][j];
@@ -176,19 +182,23 @@ __device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
         double cr[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            cr[r] = sh.colA[b][g + 4 * r];
-        d = (d > 1e-14 * orig) ? d : 1e-14 * orig;
-        const double p = 1. / d;
+            cr[r] = (4 * r + 3 > j) ? sh.colA[b][g + 4 * r] : 0.;
+        d = fmax(d, 1e-14 * orig);
+        const double p = fastRcp(d);
         const double ajm = (i > j) ? aj : 0.;
         const double rjm = (i > j) ? 0. : rj;
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
-            const int row = g + 4 * r;
-            const double m = (row > j && row < n) ? cr[r] * p : 0.;
-            A.v[r] -= m * ajm;
-            R.v[r] -= m * rjm;
-            pvr[r] = (row == j) ? d : pvr[r];
+            if (4 * r + 3 > j) // some row of this register lies below the pivot
+            {
+                const int row = g + 4 * r;
+                const double m = (row > j && row < n) ? cr[r] * p : 0.;
+                A.v[r] -= m * ajm;
+                R.v[r] -= m * rjm;
+            }
+            if (r == rj_)
+                pvr[r] = (g + 4 * r == j) ? d : pvr[r];
         }
     }
     Tile Li;
@@ -197,7 +207,7 @@ __device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
     {
         const int row = g + 4 * r;
         if (row < n)
-            Li.v[r] = (i <= row) ? R.v[r] / sqrt(pvr[r]) : 0.;
+            Li.v[r] = (i <= row) ? R.v[r] * fastRsqrt(pvr[r]) : 0.;
         else
             Li.v[r] = (i == row) ? 1. : 0.;
     }
