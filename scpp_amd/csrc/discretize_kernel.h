@@ -22,9 +22,26 @@
 // Algorithmic HBM traffic per instance-call (RocketQuat, K=50): read 7,288 B, write 131,712 B.
 #pragma once
 #include "common.h"
+#include <utility>
 
 namespace scpp
 {
+
+// f(integral_constant<int,0>) ... f(integral_constant<int,RK_S-1>) : compile-time loop over the RK stages
+template <class F, int... S>
+__device__ inline void forEachStageImpl(F &&f, std::integer_sequence<int, S...>)
+{
+    (f(std::integral_constant<int, S>{}), ...);
+}
+template <class F>
+__device__ inline void forEachStage(F &&f)
+{
+    forEachStageImpl(f, std::make_integer_sequence<int, RK_S>{});
+}
+
+#ifndef DISC_WAVES_PER_SIMD
+#define DISC_WAVES_PER_SIMD 2
+#endif
 
 template <class Model, bool FOH, bool VT>
 struct DiscLayout
@@ -42,7 +59,7 @@ struct DiscLayout
 // X [B][K][NX], U [B][K][NU] (FOH) , sigma [B], par [B][NP]  ->  A [B][K-1][NX][NX], Bm, C [B][K-1][NX][NU],
 // S, Z [B][K-1][NX]   (row-major blocks).  active[B] (may be null): skip instances with active == 0.
 template <class Model, bool FOH, bool VT>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     discretize_kernel(int B, int K, const double *__restrict__ X, const double *__restrict__ U,
                       const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
                       const int *__restrict__ active,
@@ -111,9 +128,11 @@ __global__ void __launch_bounds__(WAVE)
     for (int step = 0; step < 5; step++)
     {
         const double t0 = double(step) * h;
-#pragma unroll
-        for (int s = 0; s < RK_S; s++)
-        {
+        // The 13 stages are instantiated with a COMPILE-TIME stage index: the tableau entries become
+        // immediates, zero coefficients vanish and kk[][] stays in registers (a rolled stage loop indexes it
+        // dynamically, i.e. from scratch memory, and tests the coefficients at run time).
+        forEachStage([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
             // ---- stage value ys = y + h * sum_j a_sj k_j ----
             const double ts = t0 + RK_C[s] * h;
 #pragma unroll
@@ -131,79 +150,74 @@ __global__ void __launch_bounds__(WAVE)
             }
             WAVE_SYNC();
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
+            const double frac = FOH ? ts / dt : 0.;
+            if (lane < NJ)
             {
-                const double frac = FOH ? ts / dt : 0.;
-                if (lane < NJ)
+                Dual1 xd[NX], ud[NU], fd[NX];
+#pragma unroll
+                for (int i = 0; i < NX; i++)
+                    xd[i] = Dual1(Ys[i], (lane == i) ? 1. : 0.);
+#pragma unroll
+                for (int i = 0; i < NU; i++)
+                    ud[i] = Dual1(u0[i] + frac * (u1[i] - u0[i]), (lane == NX + i) ? 1. : 0.);
+                Model::template systemFlowMap<Dual1>(xd, ud, p, fd);
+#pragma unroll
+                for (int i = 0; i < NX; i++)
+                    Jm[i * NJ + lane] = tscale * fd[i].d;
+                if (lane == 0)
                 {
-                    Dual1 xd[NX], ud[NU], fd[NX];
 #pragma unroll
                     for (int i = 0; i < NX; i++)
-                        xd[i] = Dual1(Ys[i], (lane == i) ? 1. : 0.);
-#pragma unroll
-                    for (int i = 0; i < NU; i++)
-                        ud[i] = Dual1(u0[i] + frac * (u1[i] - u0[i]), (lane == NX + i) ? 1. : 0.);
-                    Model::template systemFlowMap<Dual1>(xd, ud, p, fd);
-#pragma unroll
-                    for (int i = 0; i < NX; i++)
-                        Jm[i * NJ + lane] = tscale * fd[i].d;
-                    if (lane == 0)
-                    {
-#pragma unroll
-                        for (int i = 0; i < NX; i++)
-                            fv[i] = fd[i].v;
-                    }
+                        fv[i] = fd[i].v;
                 }
             }
             WAVE_SYNC();
             // ---- derivative of the owned entries ----
-            {
-                const double frac = FOH ? ts / dt : 0.;
 #pragma unroll
-                for (int m = 0; m < EPL; m++)
+            for (int m = 0; m < EPL; m++)
+            {
+                const int r = erow[m], c = ecol[m];
+                double d;
+                if (c == 0)
                 {
-                    const int r = erow[m], c = ecol[m];
-                    double d;
-                    if (c == 0)
+                    d = tscale * fv[r];
+                }
+                else
+                {
+                    double acc = 0.;
+#pragma unroll
+                    for (int j = 0; j < NX; j++)
+                        acc += Jm[r * NJ + j] * Ys[c * NX + j];
+                    if (c >= L::COL_B && c < L::COL_B + NU)
                     {
-                        d = tscale * fv[r];
+                        const double alpha = FOH ? (1. - frac) : 1.;
+                        acc += Jm[r * NJ + NX + (c - L::COL_B)] * alpha;
                     }
-                    else
+                    else if (FOH && c >= L::COL_C && c < L::COL_C + NU)
                     {
-                        double acc = 0.;
+                        acc += Jm[r * NJ + NX + (c - L::COL_C)] * frac;
+                    }
+                    else if (VT && c == L::COL_S)
+                    {
+                        acc += fv[r];
+                    }
+                    else if (c == L::COL_Z)
+                    {
+                        double q = VT ? 0. : fv[r];
 #pragma unroll
                         for (int j = 0; j < NX; j++)
-                            acc += Jm[r * NJ + j] * Ys[c * NX + j];
-                        if (c >= L::COL_B && c < L::COL_B + NU)
-                        {
-                            const double alpha = FOH ? (1. - frac) : 1.;
-                            acc += Jm[r * NJ + NX + (c - L::COL_B)] * alpha;
-                        }
-                        else if (FOH && c >= L::COL_C && c < L::COL_C + NU)
-                        {
-                            acc += Jm[r * NJ + NX + (c - L::COL_C)] * frac;
-                        }
-                        else if (VT && c == L::COL_S)
-                        {
-                            acc += fv[r];
-                        }
-                        else if (c == L::COL_Z)
-                        {
-                            double q = VT ? 0. : fv[r];
+                            q -= Jm[r * NJ + j] * Ys[j];
 #pragma unroll
-                            for (int j = 0; j < NX; j++)
-                                q -= Jm[r * NJ + j] * Ys[j];
-#pragma unroll
-                            for (int j = 0; j < NU; j++)
-                                q -= Jm[r * NJ + NX + j] * (u0[j] + frac * (u1[j] - u0[j]));
-                            acc += q;
-                        }
-                        d = acc;
+                        for (int j = 0; j < NU; j++)
+                            q -= Jm[r * NJ + NX + j] * (u0[j] + frac * (u1[j] - u0[j]));
+                        acc += q;
                     }
-                    kk[s][m] = d;
+                    d = acc;
                 }
+                kk[s][m] = d;
             }
             WAVE_SYNC();
-        }
+        });
         // ---- y += h * sum_s b_s k_s ----
 #pragma unroll
         for (int m = 0; m < EPL; m++)
