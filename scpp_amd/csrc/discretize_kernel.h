@@ -48,12 +48,17 @@ struct DiscLayout
 {
     static constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP;
     static constexpr int NJ = NX + NU;                                  // Jacobian columns
-    static constexpr int NCOLS = 1 + NX + NU + (FOH ? NU : 0) + (VT ? 1 : 0) + 1;
+    // integrated columns [x | Phi | Psi_B | Psi_C | psi_s]; psi_z is NOT integrated: Runge-Kutta methods
+    // commute with affine maps of the state, so  z = x(dt) - A x0 - B u0 - C u1 - s sigma  reproduces the
+    // integrated psi_z to round-off (the defect ODE of that combination is exactly the reference's z ODE)
+    static constexpr int NCOLS = 1 + NX + NU + (FOH ? NU : 0) + (VT ? 1 : 0);
     static constexpr int NENT = NX * NCOLS;
-    static constexpr int EPL = (NENT + WAVE - 1) / WAVE;                // entries per lane
-    static constexpr int COL_PHI = 1, COL_B = 1 + NX, COL_C = COL_B + NU;
-    static constexpr int COL_S = COL_C + (FOH ? NU : 0);
-    static constexpr int COL_Z = COL_S + (VT ? 1 : 0);
+    static constexpr int NG = WAVE / NX;                                // lane groups: lane = g * NX + row
+    static constexpr int EPL = (NCOLS + NG - 1) / NG;                   // columns per lane: col = m * NG + g
+    // column order [x | psi_s | Phi | Psi_B | Psi_C]: with NG = 4 groups (RocketQuat) the B and the C columns each
+    // fill one column slot m exactly, so their forcing terms need no per-lane selection
+    static constexpr int COL_S = 1, COL_PHI = 1 + (VT ? 1 : 0), COL_B = COL_PHI + NX, COL_C = COL_B + NU;
+    static constexpr int NJP = (NJ + 1) & ~1;                           // row pitch of the Jacobian tile (16-byte rows)
 };
 
 // X [B][K][NX], U [B][K][NU] (FOH) , sigma [B], par [B][NP]  ->  A [B][K-1][NX][NX], Bm, C [B][K-1][NX][NU],
@@ -67,20 +72,20 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                       double *__restrict__ Sout, double *__restrict__ Zout)
 {
     using L = DiscLayout<Model, FOH, VT>;
-    constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NCOLS = L::NCOLS, NENT = L::NENT, EPL = L::EPL;
+    constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
 
-    __shared__ double Ys[NENT];      // stage values of V (column-major: col*NX + row)
-    __shared__ double Jm[NX * NJ];   // [sigma*A | sigma*B] row-major
-    __shared__ double fv[NX];        // f(x,u) (unscaled)
+    __shared__ __attribute__((aligned(16))) double Ys[(NCOLS + NG) * NX]; // stage values of V (column-major: col*NX + row)
+    __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major
+    __shared__ double fv[NX];                                              // f(x,u) (unscaled)
 
     const int lane = threadIdx.x;
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
     // give one XCD all K-1 segments of an instance (they re-read the same X/U/par lines).
     const int nseg = K - 1;
     const long b = blockIdx.x;
-    const long xcd = b & 7, g = b >> 3;
-    const long inst = (g / nseg) * 8 + xcd;
-    const int k = int(g % nseg);
+    const long xcd = b & 7, gb = b >> 3;
+    const long inst = (gb / nseg) * 8 + xcd;
+    const int k = int(gb % nseg);
     if (inst >= B)
         return;
     if (active && active[inst] == 0)
@@ -101,25 +106,27 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
         u1[i] = FOH ? U[(inst * K + k + 1) * NU + i] : u0[i];
     }
 
-    // entries owned by this lane
-    int erow[EPL], ecol[EPL];
+    // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
+    // stage (kept in registers for all its columns) and one column of V per entry.
+    const bool lane_on = lane < NG * NX;
+    const int row = lane % NX, g = lane_on ? lane / NX : NG - 1;
+#ifndef SCPP_HIP_EMU
+    __builtin_assume(g >= 0 && g < NG);
+#endif
+    const double x0r = X[(inst * K + k) * NX + row];
     double y[EPL];
+    bool eon[EPL];
 #pragma unroll
     for (int m = 0; m < EPL; m++)
     {
-        const int e = lane + WAVE * m;
-        const int ee = e < NENT ? e : 0;
-        ecol[m] = ee / NX;
-        erow[m] = ee - ecol[m] * NX;
+        const int c = m * NG + g;
+        eon[m] = lane_on && c < NCOLS;
         double v = 0.;
-        if (e < NENT)
-        {
-            if (ecol[m] == 0)
-                v = X[(inst * K + k) * NX + erow[m]];
-            else if (ecol[m] >= L::COL_PHI && ecol[m] < L::COL_PHI + NX)
-                v = (ecol[m] - L::COL_PHI == erow[m]) ? 1. : 0.;
-        }
-        y[m] = v;
+        if (c == 0)
+            v = x0r;
+        else if (c >= L::COL_PHI && c < L::COL_PHI + NX)
+            v = (c - L::COL_PHI == row) ? 1. : 0.;
+        y[m] = eon[m] ? v : 0.;
     }
 
     double kk[RK_S][EPL];
@@ -144,9 +151,8 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                     if (RK_A[s][j] != 0.)
                         acc += RK_A[s][j] * kk[j][m];
                 const double ys = y[m] + h * acc;
-                const int e = lane + WAVE * m;
-                if (e < NENT)
-                    Ys[e] = ys;
+                if (eon[m])
+                    Ys[(m * NG + g) * NX + row] = ys;
             }
             WAVE_SYNC();
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 Model::template systemFlowMap<Dual1>(xd, ud, p, fd);
 #pragma unroll
                 for (int i = 0; i < NX; i++)
-                    Jm[i * NJ + lane] = tscale * fd[i].d;
+                    Jm[i * NJP + lane] = tscale * fd[i].d;
                 if (lane == 0)
                 {
 #pragma unroll
@@ -172,49 +178,41 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 }
             }
             WAVE_SYNC();
-            // ---- derivative of the owned entries ----
-#pragma unroll
-            for (int m = 0; m < EPL; m++)
+            // ---- derivative of the owned entries: d(row, c) = J[row,:] V[:,c] + forcing(row, c), branch-free ----
             {
-                const int r = erow[m], c = ecol[m];
-                double d;
-                if (c == 0)
+                double jr[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    jr[j] = Jm[row * NJP + j];
+                const double fr = fv[row];
+                const double alphaB = FOH ? (1. - frac) : 1.;
+#pragma unroll
+                for (int m = 0; m < EPL; m++)
                 {
-                    d = tscale * fv[r];
-                }
-                else
-                {
+                    const int c = m * NG + g;
                     double acc = 0.;
 #pragma unroll
                     for (int j = 0; j < NX; j++)
-                        acc += Jm[r * NJ + j] * Ys[c * NX + j];
-                    if (c >= L::COL_B && c < L::COL_B + NU)
+                        acc += jr[j] * Ys[c * NX + j];
+                    // forcing: B columns J[row, NX+j] * alpha ; C columns J[row, NX+j] * frac ; s column f ; x column: sigma f only.
+                    // Which kinds can occur in slot m is a compile-time fact (m is a constant after unrolling).
+                    double d = acc;
+                    const bool slotB = m * NG < L::COL_B + NU && m * NG + NG > L::COL_B;
+                    const bool slotC = FOH && m * NG < L::COL_C + NU && m * NG + NG > L::COL_C;
+                    if (slotB || slotC)
                     {
-                        const double alpha = FOH ? (1. - frac) : 1.;
-                        acc += Jm[r * NJ + NX + (c - L::COL_B)] * alpha;
+                        const bool isB = c >= L::COL_B && c < L::COL_B + NU;
+                        const bool isC = FOH && c >= L::COL_C && c < L::COL_C + NU;
+                        const int jj = isB ? c - L::COL_B : isC ? c - L::COL_C : 0;
+                        const double w = isB ? alphaB : isC ? frac : 0.;
+                        d += w * Jm[row * NJP + NX + jj];
                     }
-                    else if (FOH && c >= L::COL_C && c < L::COL_C + NU)
-                    {
-                        acc += Jm[r * NJ + NX + (c - L::COL_C)] * frac;
-                    }
-                    else if (VT && c == L::COL_S)
-                    {
-                        acc += fv[r];
-                    }
-                    else if (c == L::COL_Z)
-                    {
-                        double q = VT ? 0. : fv[r];
-#pragma unroll
-                        for (int j = 0; j < NX; j++)
-                            q -= Jm[r * NJ + j] * Ys[j];
-#pragma unroll
-                        for (int j = 0; j < NU; j++)
-                            q -= Jm[r * NJ + NX + j] * (u0[j] + frac * (u1[j] - u0[j]));
-                        acc += q;
-                    }
-                    d = acc;
+                    if (VT && m * NG <= L::COL_S && m * NG + NG > L::COL_S)
+                        d = (c == L::COL_S) ? d + fr : d;
+                    if (m == 0)
+                        d = (c == 0) ? tscale * fr : d;
+                    kk[s][m] = d;
                 }
-                kk[s][m] = d;
             }
             WAVE_SYNC();
         });
@@ -231,25 +229,44 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
         }
     }
 
-    // ---- write A_k, B_k, C_k, s_k, z_k ----
+    // ---- write A_k, B_k, C_k, s_k ; z_k from the affine identity ----
     const long seg = inst * nseg + k;
 #pragma unroll
     for (int m = 0; m < EPL; m++)
     {
-        const int e = lane + WAVE * m;
-        if (e >= NENT)
+        const int c = m * NG + g;
+        if (!eon[m])
             continue;
-        const int r = erow[m], c = ecol[m];
+        Ys[c * NX + row] = y[m];
         if (c >= L::COL_PHI && c < L::COL_PHI + NX)
-            Aout[seg * NX * NX + r * NX + (c - L::COL_PHI)] = y[m];
+            Aout[seg * NX * NX + row * NX + (c - L::COL_PHI)] = y[m];
         else if (c >= L::COL_B && c < L::COL_B + NU)
-            Bout[seg * NX * NU + r * NU + (c - L::COL_B)] = y[m];
+            Bout[seg * NX * NU + row * NU + (c - L::COL_B)] = y[m];
         else if (FOH && c >= L::COL_C && c < L::COL_C + NU)
-            Cout[seg * NX * NU + r * NU + (c - L::COL_C)] = y[m];
+            Cout[seg * NX * NU + row * NU + (c - L::COL_C)] = y[m];
         else if (VT && c == L::COL_S)
-            Sout[seg * NX + r] = y[m];
-        else if (c == L::COL_Z)
-            Zout[seg * NX + r] = y[m];
+            Sout[seg * NX + row] = y[m];
+    }
+    // stash x0 behind the integrated columns for the identity
+    if (lane < NX)
+        Ys[NCOLS * NX + lane] = x0r;
+    WAVE_SYNC();
+    if (lane < NX)
+    {
+        double z = Ys[lane]; // x(dt)
+#pragma unroll
+        for (int j = 0; j < NX; j++)
+            z -= Ys[(L::COL_PHI + j) * NX + lane] * Ys[NCOLS * NX + j];
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+        {
+            z -= Ys[(L::COL_B + j) * NX + lane] * u0[j];
+            if (FOH)
+                z -= Ys[(L::COL_C + j) * NX + lane] * u1[j];
+        }
+        if (VT)
+            z -= Ys[L::COL_S * NX + lane] * sg;
+        Zout[seg * NX + lane] = z;
     }
 }
 
