@@ -138,11 +138,14 @@ constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) p
 // Stage / segment records are stored FIELD-major: element f of stage k lives at st[f*64 + k], so that the
 // lane == stage phases read and write fully coalesced 512-byte rows (one lane per stage).
 constexpr int LANES = 64;
+// row pitch (doubles) of the field-major records: one row = one field of all K stages.  K rounded up to even
+// instead of 64 keeps rows 16-byte aligned and cuts the record traffic by 1 - K/64 (22 % at K = 50).
+__host__ __device__ inline int recPitch(int K) { return (K + 1) & ~1; }
 // field-major copy of the segment dynamics (A 14x14, B 14x4, C 14x4, s, z) for the lane = segment phases
 constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX; // 336
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
-    return size_t(LANES) * STREC + size_t(LANES) * SEGREC + size_t(LANES) * DYNREC + size_t(K) * (FACREC + SVREC);
+    return size_t(recPitch(K)) * (STREC + SEGREC + DYNREC) + size_t(K) * (FACREC + SVREC);
 }
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is
@@ -155,7 +158,8 @@ struct SV
 {
     __amdgpu_buffer_rsrc_t rsrc; // wave-uniform: the instance's stage or segment record block
     int lb;                      // lane offset in bytes
-    int fo;                      // field offset (doubles)
+    int fo;                      // field offset (fields)
+    int pb;                      // row pitch in bytes (wave-uniform)
     struct Ref
     {
         __amdgpu_buffer_rsrc_t rsrc;
@@ -174,15 +178,15 @@ struct SV
         __device__ const Ref &operator-=(double x) const { return *this = double(*this) - x; }
         __device__ const Ref &operator*=(double x) const { return *this = double(*this) * x; }
     };
-    __device__ Ref operator[](int i) const { return Ref{rsrc, lb, (fo + i) * (LANES * 8)}; }
+    __device__ Ref operator[](int i) const { return Ref{rsrc, lb, (fo + i) * pb}; }
     // lane-dependent field index: goes into the VGPR offset (a divergent SGPR offset would be resolved by a
     // waterfall loop over its distinct values)
-    __device__ Ref dyn(int i) const { return Ref{rsrc, lb + (fo + i) * (LANES * 8), 0}; }
-    __device__ SV operator+(int o) const { return SV{rsrc, lb, fo + o}; }
+    __device__ Ref dyn(int i) const { return Ref{rsrc, lb + (fo + i) * pb, 0}; }
+    __device__ SV operator+(int o) const { return SV{rsrc, lb, fo + o, pb}; }
 };
-__device__ inline SV makeSV(double *block, int nfields, unsigned lane_index)
+__device__ inline SV makeSV(double *block, int nfields, unsigned lane_index, int pitch)
 {
-    return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, nfields * LANES * 8, 0x00020000), int(lane_index * 8u), 0};
+    return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, nfields * pitch * 8, 0x00020000), int(lane_index * 8u), 0, pitch * 8};
 }
 
 struct Settings
@@ -196,6 +200,7 @@ struct Settings
 struct Ctx
 {
     int K, lane;
+    int pitch;   // row pitch of the field-major records (doubles)
     double *st;  // [STREC][64]   field-major
     double *sg;  // [SEGREC][64]  field-major
     double *dy;  // [DYNREC][64]  field-major copy of A,B,C,s,z
@@ -433,7 +438,7 @@ __device__ inline void addConeHs(double *Hs, double eta, AW w, int d, const int 
 __device__ inline void buildHs(const Ctx &c, int k, bool identity)
 {
     const unsigned fm = fixedMask(k, c.K), act = activeMask(k, c.K);
-    const SV st = makeSV(c.st, STREC, unsigned(k));
+    const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
     const SV eta = st + F_ETA, wb = st + F_WB, uh = st + F_UHAT;
     double Hs[27];
     for (int i = 0; i < 27; i++)

@@ -54,7 +54,7 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     const int k = c.lane, K = c.K;
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             if (identity)
@@ -100,7 +100,7 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
     g.dz3 = -b.n1;
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             const double d1 = dLP(identity, sg[G_S1 * NL + i], sg[G_Z1 * NL + i]);
@@ -115,7 +115,7 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
     }
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k));
+        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
         const unsigned fm = fixedMask(k, K);
         for (int j = 0; j < NV; j++)
             st[fBeta + j] = (fm & (1u << j)) ? 0. : st[F_BXW + j] - st[F_HDW + j] * st[F_BXD] / st[F_HDD];
@@ -130,7 +130,7 @@ __device__ inline void borderSchur(const Ctx &c, Glob &g)
     double acc = 0.;
     if (k < K - 1)
         for (int i = 0; i < NL; i++)
-            acc += -c.S[k * NX + i] * c.sg[size_t(G_BCL * NL + i) * LANES + k];
+            acc += -c.S[k * NX + i] * c.sg[size_t(G_BCL * NL + i) * c.pitch + k];
     acc = wave_sum(acc);
     g.schur = g.hsig - acc;
 }
@@ -143,14 +143,14 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     double cv = 0.;
     if (k < K - 1)
         for (int i = 0; i < NL; i++)
-            cv += -c.S[k * NX + i] * c.sg[size_t(gVL * NL + i) * LANES + k];
+            cv += -c.S[k * NX + i] * c.sg[size_t(gVL * NL + i) * c.pitch + k];
     cv = wave_sum(cv);
     g.dsig = (bts - cv) / g.schur;
     g.ddsg = (b.ds - g.Hsd * g.dsig) / g.Hdd;
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k));
+        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
         double acc = 0.;
         for (int j = 0; j < NV; j++)
         {
@@ -162,7 +162,7 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             const double dl = sg[gVL * NL + i] - sg[G_BCL * NL + i] * g.dsig;
@@ -205,7 +205,7 @@ __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
     const int k = c.lane, K = c.K;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k));
+        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
         const unsigned fm = fixedMask(k, K);
 #pragma unroll
         for (int j = 0; j < NV; j++)
@@ -217,7 +217,7 @@ __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             sg[G_NU * NL + i] += alpha * sg[G_DNU * NL + i];
@@ -236,12 +236,12 @@ __device__ inline void evalAllSaff(const Ctx &c, const Glob &g, int fOut, int g1
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k));
+        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
         saff(c.ip, activeMask(k, K), st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, st + fOut);
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
@@ -266,7 +266,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k)) + f;
+        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
             {
@@ -285,7 +285,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
@@ -308,7 +308,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     if (k < K)
     {
         const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k)) + f;
+        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
         for (int cix = 0; cix < NCONE; cix++)
             if (act & (1u << cix))
                 v[coneOff(cix)] += alpha;
@@ -319,7 +319,7 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k));
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
         for (int i = 0; i < NL; i++)
         {
             sg[g1 * NL + i] += alpha;
@@ -499,12 +499,12 @@ __device__ inline Views makeViews(const Ctx &c)
             k < K - 1,
             (k < K) ? fixedMask(k, K) : 0u,
             (k < K) ? activeMask(k, K) : 0u,
-            makeSV(c.st, STREC, unsigned(k < K ? k : 0)),
-            makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0)),
-            makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0)),
-            makeSV(c.sg, SEGREC, unsigned(k > 0 && k < K ? k - 1 : 0)),
-            makeSV(c.dy, DYNREC, unsigned(k < K - 1 ? k : 0)),
-            makeSV(c.dy, DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0))};
+            makeSV(c.st, STREC, unsigned(k < K ? k : 0), c.pitch),
+            makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0), c.pitch),
+            makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0), c.pitch),
+            makeSV(c.sg, SEGREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch),
+            makeSV(c.dy, DYNREC, unsigned(k < K - 1 ? k : 0), c.pitch),
+            makeSV(c.dy, DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch)};
     return v;
 }
 
@@ -1471,9 +1471,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.lane = lane;
     double *ws = a.ws + size_t(inst) * workspaceDoubles(K);
     c.st = ws;
-    c.sg = ws + size_t(LANES) * STREC;
-    c.dy = c.sg + size_t(LANES) * SEGREC;
-    c.fac = c.dy + size_t(LANES) * DYNREC;
+    c.pitch = recPitch(K);
+    c.sg = ws + size_t(c.pitch) * STREC;
+    c.dy = c.sg + size_t(c.pitch) * SEGREC;
+    c.fac = c.dy + size_t(c.pitch) * DYNREC;
     c.sv = c.fac + size_t(K) * FACREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
     c.B = a.Bm + size_t(inst) * (K - 1) * NX * NU;
@@ -1601,7 +1602,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
 
     // =============== outputs: readSolution + SC bookkeeping ===============
     const bool vst = k < K;
-    const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0));
+    const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0), c.pitch);
     double sum_delta = 0.;
     if (vst)
         sum_delta = st[F_DL];

@@ -27,6 +27,7 @@ __device__ inline Ctx uniformCtx(const Ctx &cin)
     Ctx c;
     c.K = uniformInt(cin.K);
     c.lane = threadIdx.x;
+    c.pitch = uniformInt(cin.pitch);
     c.st = uniformPtr(cin.st);
     c.sg = uniformPtr(cin.sg);
     c.dy = uniformPtr(cin.dy);
@@ -76,7 +77,7 @@ __device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane
     {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            t.v[r] = c.st[size_t(sp.fBeta + g + 4 * r) * LANES + k];
+            t.v[r] = c.st[size_t(sp.fBeta + g + 4 * r) * c.pitch + k];
     }
     return t;
 }
@@ -92,7 +93,7 @@ __device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane
         {
             const int row = g + 4 * r;
             if (row < NL)
-                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sg[size_t(sp.gRho * NL + row) * LANES + k];
+                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sg[size_t(sp.gRho * NL + row) * c.pitch + k];
         }
     }
     return t;
@@ -159,7 +160,7 @@ struct HRaw
 __device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
-    const SV st = makeSV(c.st, STREC, unsigned(k));
+    const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
     HRaw h;
     h.e2 = st[F_HC];
     h.cc = st[F_HC + 1];
@@ -267,7 +268,7 @@ __device__ inline FactorIn loadFactorIn(const Ctx &c, const RhsSpec &sp, int k, 
         f.n = loadNRaw(c, k, lane);
         f.rl = loadRhsL(c, sp, k, lane);
         f.rwn = loadRhsW(c, sp, k + 1, lane);
-        f.einv = c.sg[size_t(G_EINV * NL + (i < NL ? i : 0)) * LANES + k];
+        f.einv = c.sg[size_t(G_EINV * NL + (i < NL ? i : 0)) * c.pitch + k];
     }
     else
     {
@@ -354,12 +355,15 @@ SWEEP_FN void fwdSweep(const Ctx &cin, const RhsSpec &spin)
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     Tile G = loadRhsW(c, sp, 0, lane);
+    // two stages of loads in flight: the per-stage MFMA chain (~1k cycles) is much shorter than the loaded-HBM
+    // latency, so a distance-1 prefetch still stalls every stage
     FwdIn cur = loadFwdIn(c, sp, 0, lane);
+    FwdIn nx1 = K > 1 ? loadFwdIn(c, sp, 1, lane) : cur;
     for (int k = 0; k < K; k++)
     {
-        FwdIn nxt = cur;
-        if (k + 1 < K)
-            nxt = loadFwdIn(c, sp, k + 1, lane);
+        FwdIn nxt = nx1;
+        if (k + 2 < K)
+            nx1 = loadFwdIn(c, sp, k + 2, lane);
         double *svk = c.sv + size_t(k) * SVREC;
         const Tile a = mm(cur.lit, G);
         saveCols(svk, sp.n, lane, a);
@@ -383,7 +387,7 @@ __device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lan
         const int f = kind == 1 ? int(F_BCW) : sp.fOut;
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            c.st[size_t(f + g + 4 * r) * LANES + k] = x.v[r];
+            c.st[size_t(f + g + 4 * r) * c.pitch + k] = x.v[r];
     }
 }
 __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &l)
@@ -398,7 +402,7 @@ __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lan
         {
             const int row = g + 4 * r;
             if (row < NL)
-                c.sg[size_t(f * NL + row) * LANES + k] = l.v[r];
+                c.sg[size_t(f * NL + row) * c.pitch + k] = l.v[r];
         }
     }
 }
@@ -431,12 +435,13 @@ SWEEP_FN void bwdSweep(const Ctx &cin, const RhsSpec &spin)
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     BwdIn cur = loadBwdIn(c, sp, K - 1, lane);
+    BwdIn nx1 = K > 1 ? loadBwdIn(c, sp, K - 2, lane) : cur;
     Tile x = tileZero();
     for (int k = K - 1; k >= 0; k--)
     {
-        BwdIn nxt = cur;
-        if (k > 0)
-            nxt = loadBwdIn(c, sp, k - 1, lane);
+        BwdIn nxt = nx1;
+        if (k > 1)
+            nx1 = loadBwdIn(c, sp, k - 2, lane);
         if (k == K - 1)
         {
             x = mm(cur.li, cur.as); // Li' a = L^-T a
