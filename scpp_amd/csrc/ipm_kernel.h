@@ -131,7 +131,10 @@ enum SegField
     G_NFIELDS
 };
 constexpr int SEGREC = G_NFIELDS * NL; // 462
-constexpr int FACREC = 4 * 256;        // Li, Yt, Ti, Z tiles (16x16 row-major each)
+// per-stage factor record, PACKED (the kernel is HBM-throughput bound): Li lower triangle (136), Yt 16x14 (224),
+// Ti lower triangle of the 14x14 block (105).  Z = Ti N is not stored: N = [I | -C] makes it 4 extra matrix-core
+// instructions from Ti and the 42 entries of C.
+constexpr int FAC_LI = 0, FAC_YT = 136, FAC_TI = 360, FACREC = 472;
 constexpr int NRHS_MAX = 3;            // right-hand-side columns carried by one sweep
 constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) per stage
 

@@ -251,6 +251,36 @@ __device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
     return t;
 }
 
+// N' tile: entry (var a = g+4r, dyn row b = i) = N[b][a]; only the C part is loaded
+__device__ inline Tile loadNtRaw(const Ctx &c, int k, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = tileZero();
+#pragma unroll
+    for (int r = 3; r < 4; r++) // variables 13..15 live in register 3 (a = 12 + g)
+    {
+        const int a = g + 4 * r;
+        const double v = c.C[size_t(k) * NX * NU + (i < NL ? i : 0) * NU + (a >= 13 ? a - 13 : 0)];
+        t.v[r] = (i < NL && a >= 13) ? v : 0.;
+    }
+    return t;
+}
+__device__ inline Tile finishNt(const Tile &raw, unsigned fmn, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        double v = 0.;
+        if (i < NL && !(fmn & (1u << a)))
+            v = a < 13 ? (a == i ? 1. : 0.) : -raw.v[r];
+        t.v[r] = v;
+    }
+    return t;
+}
+
 struct FactorIn
 {
     HRaw h;
@@ -297,7 +327,7 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
         const Tile Li = invCholFactor<NV>(Phi, sh, lane);
-        storeTile(fk, lane, Li);
+        storeTri<NV>(fk + FAC_LI, lane, Li);
         const Tile Lit = transposeTile(Li, sh, lane);
         const Tile a = mm(Lit, G);
         saveCols(svk, sp.n, lane, a);
@@ -305,7 +335,7 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
             break;
         const unsigned fm = fixedMask(k, K), fmn = fixedMask(k + 1, K);
         const Tile Yt = mm(Lit, finishMt(cur.mt, fm, lane));
-        storeTile(fk + 256, lane, Yt);
+        storeYt(fk + FAC_YT, lane, Yt);
         Tile Th = mm(Yt, Yt);
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -315,10 +345,9 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
                 Th.v[r] = (row < NL) ? Th.v[r] + cur.einv : 1.;
         }
         const Tile Ti = invCholFactor<NL>(Th, sh, lane);
-        storeTile(fk + 512, lane, Ti);
+        storeTri<NL>(fk + FAC_TI, lane, Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
         Z = mm(Tit, finishN(cur.n, fmn, lane));
-        storeTile(fk + 768, lane, Z);
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(Yt, a));
         const Tile cc = mm(Tit, gl);
         saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
@@ -330,23 +359,24 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
 
 struct FwdIn
 {
-    Tile lit, yt, tit, z, rl, rwn;
+    Tile lit, yt, tit, ti, n, rl, rwn;
 };
 __device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
     const double *fk = c.fac + size_t(k) * FACREC;
     FwdIn f;
-    f.lit = loadTileT(fk, lane);
+    f.lit = loadTriT<NV>(fk + FAC_LI, lane);
     if (k < c.K - 1)
     {
-        f.yt = loadTile(fk + 256, lane);
-        f.tit = loadTileT(fk + 512, lane);
-        f.z = loadTile(fk + 768, lane);
+        f.yt = loadYt(fk + FAC_YT, lane);
+        f.tit = loadTriT<NL>(fk + FAC_TI, lane);
+        f.ti = loadTri<NL>(fk + FAC_TI, lane);
+        f.n = loadNRaw(c, k, lane);
         f.rl = loadRhsL(c, sp, k, lane);
         f.rwn = loadRhsW(c, sp, k + 1, lane);
     }
     else
-        f.yt = f.tit = f.z = f.rl = f.rwn = tileZero();
+        f.yt = f.tit = f.ti = f.n = f.rl = f.rwn = tileZero();
     return f;
 }
 SWEEP_FN void fwdSweep(const Ctx &cin, const RhsSpec &spin)
@@ -372,7 +402,8 @@ SWEEP_FN void fwdSweep(const Ctx &cin, const RhsSpec &spin)
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(cur.yt, a));
         const Tile cc = mm(cur.tit, gl);
         saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
-        G = tileAdd(cur.rwn, mm(cur.z, cc));
+        // Z' cc = N' (Ti' cc)
+        G = tileAdd(cur.rwn, mm(finishN(cur.n, fixedMask(k + 1, K), lane), mm(cur.ti, cc)));
         cur = nxt;
     }
     WAVE_SYNC();
@@ -409,24 +440,25 @@ __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lan
 
 struct BwdIn
 {
-    Tile zt, ti, y, li, cs, as;
+    Tile nt, tit, ti, y, li, cs, as;
 };
 __device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
     const double *fk = c.fac + size_t(k) * FACREC;
     const double *svk = c.sv + size_t(k) * SVREC;
     BwdIn b;
-    b.li = loadTile(fk, lane);
+    b.li = loadTri<NV>(fk + FAC_LI, lane);
     b.as = loadCols(svk, sp.n, lane);
     if (k < c.K - 1)
     {
-        b.zt = loadTileT(fk + 768, lane);
-        b.ti = loadTile(fk + 512, lane);
-        b.y = loadTileT(fk + 256, lane);
+        b.nt = loadNtRaw(c, k, lane);
+        b.tit = loadTriT<NL>(fk + FAC_TI, lane);
+        b.ti = loadTri<NL>(fk + FAC_TI, lane);
+        b.y = loadYtT(fk + FAC_YT, lane);
         b.cs = loadCols(svk + NRHS_MAX * 16, sp.n, lane);
     }
     else
-        b.zt = b.ti = b.y = b.cs = tileZero();
+        b.nt = b.tit = b.ti = b.y = b.cs = tileZero();
     return b;
 }
 SWEEP_FN void bwdSweep(const Ctx &cin, const RhsSpec &spin)
@@ -448,7 +480,8 @@ SWEEP_FN void bwdSweep(const Ctx &cin, const RhsSpec &spin)
         }
         else
         {
-            const Tile t = tileSub(mm(cur.zt, x), cur.cs); // Z x' - c
+            // Z x' - c  with  Z x' = Ti (N x')
+            const Tile t = tileSub(mm(cur.tit, mm(finishNt(cur.nt, fixedMask(k + 1, K), lane), x)), cur.cs);
             const Tile lam = mm(cur.ti, t);                 // Ti' t = T^-T t
             const Tile s = tileSub(cur.as, mm(cur.y, lam)); // a - Y' lam
             x = mm(cur.li, s);

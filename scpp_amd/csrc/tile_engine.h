@@ -73,6 +73,88 @@ __device__ inline void storeTile(double *p, int lane, const Tile &t)
         p[(g + 4 * r) * 16 + i] = t.v[r];
 }
 
+// ---- packed factor storage ----
+__device__ inline int triIdx(int row, int col) { return (row * (row + 1)) / 2 + col; }
+// lower triangle of the leading n x n block (row-major packed); outside it the tile is the identity
+template <int n>
+__device__ inline void storeTri(double *p, int lane, const Tile &t)
+{
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        if (row < n && i <= row)
+            p[triIdx(row, i)] = t.v[r];
+    }
+}
+template <int n>
+__device__ inline Tile loadTri(const double *p, int lane) // tile[row][col] = L[row][col]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        const bool in = row < n && i <= row;
+        const double v = p[in ? triIdx(row, i) : 0];
+        t.v[r] = in ? v : ((row >= n && row == i) ? 1. : 0.);
+    }
+    return t;
+}
+template <int n>
+__device__ inline Tile loadTriT(const double *p, int lane) // tile[a][b] = L[b][a]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        const bool in = i < n && a <= i;
+        const double v = p[in ? triIdx(i, a) : 0];
+        t.v[r] = in ? v : ((a >= n && a == i) ? 1. : 0.);
+    }
+    return t;
+}
+// Yt (16 variables x NL dynamics rows), row-major with pitch NL
+__device__ inline void storeYt(double *p, int lane, const Tile &t)
+{
+    const int g = lane >> 4, i = lane & 15;
+    if (i < NL)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            p[(g + 4 * r) * NL + i] = t.v[r];
+    }
+}
+__device__ inline Tile loadYt(const double *p, int lane) // tile[a][b] = Yt[a][b]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const double v = p[(g + 4 * r) * NL + (i < NL ? i : 0)];
+        t.v[r] = i < NL ? v : 0.;
+    }
+    return t;
+}
+__device__ inline Tile loadYtT(const double *p, int lane) // tile[a][b] = Yt[b][a]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        const double v = p[i * NL + (a < NL ? a : 0)];
+        t.v[r] = a < NL ? v : 0.;
+    }
+    return t;
+}
+
 // dynamics coupling tiles of segment k
 __device__ inline Tile loadM(const Ctx &c, int k, unsigned fm, int lane) // M[row][var]
 {
