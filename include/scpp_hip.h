@@ -17,6 +17,8 @@
  *   (incl. RocketQuat (non|re)dimensionalize*, getInitializedTrajectory,       scpp_hip_sc_solve
  *    getNewModelParameters: rocketQuat.cpp:39-68,156-201,291-332)
  *   SCAlgorithm::getSolution              scpp_core/include/SCAlgorithm.hpp:37 scpp_hip_download
+ *   SC_sim closed loop (warm start, plant  scpp/src/SC_sim.cpp:28-66            scpp_hip_sc_setup(warm_start=1),
+ *   step, stop rule)                                                            scpp_hip_simulate, scpp_hip_sc_set_active
  *
  * Conventions: every function returns 0 on success or a negative SCPP_E_* code; nothing throws or
  * exits.  One context per GPU, one host thread per context.  All host buffers are caller-owned,
@@ -100,6 +102,9 @@ extern "C"
     int scpp_hip_set_socp_opts(scpp_hip_ctx *ctx, const scpp_socp_opts *opts);
     int scpp_hip_sc_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_sc_opts *opts,
                           const double *x_init /* [B][14] dimensional */, int B, int warm_start);
+    /* restrict the next sc_iterate / sc_solve to a subset (mask[i] != 0); call after sc_setup.  This is the batched
+       form of SC_sim's per-closed-loop stop rule (scpp/src/SC_sim.cpp:57-62): finished loops are not solved again */
+    int scpp_hip_sc_set_active(scpp_hip_ctx *ctx, const int32_t *mask /* [B] */, int B);
     int scpp_hip_sc_iterate(scpp_hip_ctx *ctx, int *n_active);  /* one SCAlgorithm::iterate on every active instance */
     int scpp_hip_sc_solve(scpp_hip_ctx *ctx, int *n_converged); /* whole SCAlgorithm::solve loop on the device */
     int scpp_hip_socp_solve(scpp_hip_ctx *ctx);                 /* sub-problem only, on the current td/dd */

@@ -9,6 +9,7 @@
 #include "discretization.hpp"
 #include "models.hpp"
 #include "sc.hpp"
+#include "sc_sim.hpp"
 #include "socp.hpp"
 
 using namespace oracle;
@@ -329,6 +330,31 @@ int oracle_sc_solve(void *h, int warm_start)
     catch (const std::exception &e)
     {
         std::fprintf(stderr, "oracle_sc_solve: %s\n", e.what());
+        return -2;
+    }
+}
+// SC_sim.cpp:19-104 closed loop from the handle's current x_init.  Outputs (caller-allocated for max_steps):
+// X_sim [max_steps][nx], U_sim [max_steps][nu], t_plan [max_steps], sc_iters [max_steps]; meta = {steps, reached_end, solver_failed}
+int oracle_sc_sim(void *h, double time_step, int max_steps, double *X_sim, double *U_sim, double *t_plan, int *sc_iters, int *meta)
+{
+    try
+    {
+        return withAlg(h, [&](auto &a) {
+            auto r = scSim(a, time_step, max_steps);
+            std::memcpy(X_sim, r.X_sim.data(), r.X_sim.size() * sizeof(double));
+            std::memcpy(U_sim, r.U_sim.data(), r.U_sim.size() * sizeof(double));
+            std::memcpy(t_plan, r.t_plan.data(), r.t_plan.size() * sizeof(double));
+            for (size_t i = 0; i < r.sc_iterations.size(); i++)
+                sc_iters[i] = r.sc_iterations[i];
+            meta[0] = r.steps;
+            meta[1] = r.reached_end;
+            meta[2] = r.solver_failed;
+            return 0;
+        });
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_sc_sim: %s\n", e.what());
         return -2;
     }
 }

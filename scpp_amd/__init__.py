@@ -19,3 +19,4 @@ from ._lib import (  # noqa: F401
 from .parameter_server import ParameterServer  # noqa: F401
 from .models import RocketQuat, counter_uniform  # noqa: F401
 from .sc_algorithm import SCAlgorithm, load_sc_opts  # noqa: F401
+from .sc_sim import SCSim, interpolated_input  # noqa: F401

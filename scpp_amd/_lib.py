@@ -82,7 +82,7 @@ _lib_path = None
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
     "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
-    "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
+    "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
 ]
 
@@ -187,6 +187,10 @@ class Context:
         x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
         self.B = x_init.shape[0]
         _chk(self.lib.scpp_hip_sc_setup(self.h, C.byref(model_params), C.byref(sc_opts), _p(x_init), int(self.B), int(warm_start)), "sc_setup")
+
+    def sc_set_active(self, mask):
+        mask = np.ascontiguousarray(mask, dtype=np.int32).reshape(-1)
+        _chk(self.lib.scpp_hip_sc_set_active(self.h, _p(mask), int(mask.shape[0])), "sc_set_active")
 
     def sc_iterate(self):
         n = C.c_int(0)

@@ -441,6 +441,25 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
 }
 
+int scpp_hip_sc_set_active(scpp_hip_ctx *c, const int32_t *mask, int B)
+{
+    if (!c || !mask || B != c->B)
+        return SCPP_E_ARG;
+    if (!c->sc_ready)
+        return SCPP_E_STATE;
+    std::vector<int> m(size_t(B), 0);
+    int n = 0;
+    for (int i = 0; i < B; i++)
+    {
+        m[size_t(i)] = mask[i] != 0;
+        n += m[size_t(i)];
+    }
+    CHECK_HIP(hipMemcpyAsync(c->active, m.data(), size_t(B) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->last_active = n;
+    return SCPP_OK;
+}
+
 int scpp_hip_sc_iterate(scpp_hip_ctx *c, int *n_active)
 {
     if (!c || !c->sc_ready)
@@ -465,7 +484,7 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
 {
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
-    int n_active = c->B;
+    int n_active = c->last_active;
     for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
     {
         int rc = scpp_hip_sc_iterate(c, &n_active);

@@ -1,0 +1,82 @@
+"""Batched receding-horizon driver: host mirror of the reference's SC_sim executable
+(scpp/src/SC_sim.cpp:19-104) for B independent closed loops (Monte-Carlo over initial states).
+
+Per simulation step, exactly as the reference does for its single loop:
+  solve(warm_start = step > 0)            SC_sim.cpp:45-46   (warm start: SCAlgorithm.cpp:141-145 -- the previous
+                                                              solution is the initial trajectory, loadParameters() is
+                                                              skipped so weight_trust_region_trajectory keeps its doubled
+                                                              value, thrust_const is refreshed from the new trajectory)
+  u0 = U[0], u1 = interpolatedInput(U, dt, t, FOH)            SC_sim.cpp:49-51, commonFunctions.cpp:6-19
+  x <- simulate(model, dt, u0, u1, x)     SC_sim.cpp:53      (x aliases model.p.x_init: the plant state is the next
+                                                              solve's initial-state constraint, SC_sim.cpp:36)
+  stop when ||x - x_final|| < 0.02 or t < 0.25                SC_sim.cpp:57-62
+Loops that stopped (or whose sub-problem failed: the reference would terminate) are masked out of later solves.
+All numerical work runs in libscpp_hip.so (scpp_hip_sc_setup / sc_set_active / sc_solve / simulate)."""
+import numpy as np
+
+
+
+def interpolated_input(U, t, total_time, first_order_hold=True):
+    """commonFunctions.cpp:6-19 for a batch: U [B][K][nu], total_time [B] -> [B][nu]."""
+    U = np.asarray(U, dtype=np.float64)
+    B, K, _ = U.shape
+    total_time = np.broadcast_to(np.asarray(total_time, dtype=np.float64), (B,))
+    time_step = total_time / (K - 1)
+    i = np.minimum((t / time_step).astype(np.int64), K - 2)
+    rows = np.arange(B)
+    u0 = U[rows, i]
+    u1 = U[rows, i + 1] if first_order_hold else u0
+    t_intermediate = np.fmod(t, time_step) / time_step
+    return u0 + (u1 - u0) * t_intermediate[:, None]
+
+
+class SCSim:
+    def __init__(self, algorithm, time_step=0.05, max_steps=100):
+        self.alg = algorithm
+        self.time_step = float(time_step)
+        self.max_steps = int(max_steps)
+
+    def run(self, x_init):
+        alg, ctx, model = self.alg, self.alg.ctx, self.alg.model
+        x = np.array(x_init, dtype=np.float64).reshape(-1, 14)
+        B = x.shape[0]
+        x_final = np.array(list(model.p.x_final), dtype=np.float64)
+        par_dim = np.tile(model.flow_params(nondimensionalize=False), (B, 1))  # dimensional flow-map parameters for the plant
+        active = np.ones(B, dtype=np.int32)
+        steps = np.zeros(B, dtype=np.int32)
+        reached = np.zeros(B, dtype=bool)
+        failed = np.zeros(B, dtype=bool)
+        X_sim = [[] for _ in range(B)]
+        U_sim = [[] for _ in range(B)]
+        t_plan = [[] for _ in range(B)]
+        sc_iters = [[] for _ in range(B)]
+        for step in range(self.max_steps):
+            if not active.any():
+                break
+            ctx.sc_setup(model.p, alg.opts, x, warm_start=step > 0)
+            ctx.sc_set_active(active)
+            ctx.sc_solve()
+            out = ctx.download()
+            ok = (active != 0) & (out["status"] == 0)
+            failed |= (active != 0) & (out["status"] != 0)
+            u0 = out["U"][:, 0, :]
+            u1 = interpolated_input(out["U"], self.time_step, out["sigma"], bool(alg.opts.interpolate_input))
+            ctx.set_flow_params(par_dim)
+            x_new = ctx.simulate(self.time_step, u0, u1, x)
+            for b in np.nonzero(ok)[0]:
+                x[b] = x_new[b]
+                X_sim[b].append(x_new[b].copy())
+                U_sim[b].append(u0[b].copy())
+                t_plan[b].append(float(out["sigma"][b]))
+                sc_iters[b].append(int(out["sc_iters"][b]))
+                steps[b] += 1
+            end = ok & ((np.linalg.norm(x - x_final, axis=1) < 0.02) | (out["sigma"] < 0.25))
+            reached |= end
+            active = (ok & ~end).astype(np.int32)
+        return dict(
+            X_sim=[np.array(v).reshape(-1, 14) for v in X_sim],
+            U_sim=[np.array(v).reshape(-1, 4) for v in U_sim],
+            t_plan=[np.array(v) for v in t_plan],
+            sc_iters=[np.array(v, dtype=np.int32) for v in sc_iters],
+            steps=steps, reached_end=reached, solver_failed=failed, x=x,
+        )

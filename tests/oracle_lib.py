@@ -170,6 +170,20 @@ class SC:
     def solve(self, warm_start=False):
         return lib().oracle_sc_solve(self.h, int(warm_start))
 
+    def sim(self, time_step=0.05, max_steps=100):
+        """SC_sim.cpp:19-104 closed loop from the current x_init (oracle/sc_sim.hpp)."""
+        nx, nu = dims(self.model)[0], dims(self.model)[1]
+        X = np.zeros((max_steps, nx))
+        U = np.zeros((max_steps, nu))
+        tp = np.zeros(max_steps)
+        it = np.zeros(max_steps, dtype=np.int32)
+        meta = np.zeros(3, dtype=np.int32)
+        rc = lib().oracle_sc_sim(self.h, C.c_double(time_step), int(max_steps), _p(X), _p(U), _p(tp), _p(it), _p(meta))
+        assert rc == 0
+        n = int(meta[0])
+        return dict(X_sim=X[:n], U_sim=U[:n], t_plan=tp[:n], sc_iters=it[:n], steps=n, reached_end=bool(meta[1]),
+                    solver_failed=bool(meta[2]))
+
     def meta(self):
         m = np.zeros(12, dtype=np.int32)
         lib().oracle_sc_meta(self.h, _p(m))

@@ -68,3 +68,18 @@ def test_emu_simulate_matches_oracle(oracle, model, emu_lib):
     out = ctx.simulate(0.05, u0, u1, x)
     for b in range(4):
         assert np.abs(out[b] - oracle.simulate(0, par, 0.05, u0[b], u1[b], x[b])).max() < 1e-14
+
+
+def test_emu_sc_sim_matches_oracle(oracle, model, emu_lib):
+    """SC_sim closed loop (warm start, plant step, stop rule) through the kernels vs oracle/sc_sim.hpp."""
+    K, B, steps = 8, 2, 2
+    alg, x0 = _setup(model, emu_lib, K, B)
+    r = scpp_amd.SCSim(alg, time_step=0.05, max_steps=steps).run(x0)
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.randomize(20260927, b); sc.set_solver(1)
+        o = sc.sim(0.05, steps)
+        assert o["steps"] == r["steps"][b] == steps
+        assert list(o["sc_iters"]) == list(r["sc_iters"][b])
+        assert np.abs(o["X_sim"] - r["X_sim"][b]).max() <= 1e-9 * np.abs(o["X_sim"]).max()
+        assert np.abs(o["U_sim"] - r["U_sim"][b]).max() <= 1e-9 * np.abs(o["U_sim"]).max()
+        assert np.allclose(o["t_plan"], r["t_plan"][b], rtol=1e-10)

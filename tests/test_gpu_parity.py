@@ -198,3 +198,38 @@ def test_warm_start_resolve(oracle, model, alg):
     assert (second["status"] == 0).all()
     # the warm-started solve starts at the previous fixed point: trajectory barely moves
     assert _rel(second["X"], first["X"]) < 1e-2
+
+
+def test_sc_sim_closed_loop_matches_oracle(oracle, model, alg):
+    """Batched SC_sim (scpp/src/SC_sim.cpp:28-66): warm-started re-solves, plant step, per-loop stop mask, against the
+    oracle's restatement of the same driver, loop by loop."""
+    B, steps = 4, 3
+    x0 = model.randomized_initial_states(B)
+    r = scpp_amd.SCSim(alg, time_step=0.05, max_steps=steps).run(x0)
+    assert not r["solver_failed"].any()
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=int(alg.opts.K)); sc.randomize(20260927, b); sc.set_solver(1)
+        o = sc.sim(0.05, steps)
+        assert o["steps"] == r["steps"][b]
+        assert list(o["sc_iters"]) == list(r["sc_iters"][b])
+        assert np.abs(o["X_sim"] - r["X_sim"][b]).max() <= 1e-8 * np.abs(o["X_sim"]).max()
+        assert np.abs(o["U_sim"] - r["U_sim"][b]).max() <= 1e-8 * np.abs(o["U_sim"]).max()
+        assert np.allclose(o["t_plan"], r["t_plan"][b], rtol=1e-9)
+
+
+def test_sc_sim_stop_mask(model, alg):
+    """A loop that is masked out is not solved again: its stored plan and counters stay untouched."""
+    B = 4
+    x0 = model.randomized_initial_states(B)
+    alg.ctx.sc_setup(model.p, alg.opts, x0)
+    alg.ctx.sc_solve()
+    first = alg.ctx.download()
+    alg.ctx.sc_setup(model.p, alg.opts, x0, warm_start=True)
+    alg.ctx.sc_set_active(np.array([1, 0, 1, 0], dtype=np.int32))
+    alg.ctx.sc_solve()
+    second = alg.ctx.download()
+    for b in (1, 3):
+        assert second["sc_iters"][b] == 0
+        assert _rel(second["X"][b], first["X"][b]) < 1e-12
+    for b in (0, 2):
+        assert second["sc_iters"][b] > 0
