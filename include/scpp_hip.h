@@ -107,6 +107,9 @@ extern "C"
     int scpp_hip_sc_set_active(scpp_hip_ctx *ctx, const int32_t *mask /* [B] */, int B);
     int scpp_hip_sc_iterate(scpp_hip_ctx *ctx, int *n_active);  /* one SCAlgorithm::iterate on every active instance */
     int scpp_hip_sc_solve(scpp_hip_ctx *ctx, int *n_converged); /* whole SCAlgorithm::solve loop on the device */
+    /* tail of SCAlgorithm::solve (redimensionalizeTrajectory, SCAlgorithm.cpp:182-187) for callers that drive
+       sc_iterate themselves, e.g. to record every iterate like getAllSolutions (SCAlgorithm.cpp:217-232) */
+    int scpp_hip_sc_finish(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_socp_solve(scpp_hip_ctx *ctx);                 /* sub-problem only, on the current td/dd */
     /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,

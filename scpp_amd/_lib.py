@@ -82,7 +82,7 @@ _lib_path = None
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
     "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
-    "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
+    "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
 ]
 
@@ -195,6 +195,11 @@ class Context:
     def sc_iterate(self):
         n = C.c_int(0)
         _chk(self.lib.scpp_hip_sc_iterate(self.h, C.byref(n)), "sc_iterate")
+        return n.value
+
+    def sc_finish(self):
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_sc_finish(self.h, C.byref(n)), "sc_finish")
         return n.value
 
     def sc_solve(self):

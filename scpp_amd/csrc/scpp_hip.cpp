@@ -480,17 +480,10 @@ int scpp_hip_sc_iterate(scpp_hip_ctx *c, int *n_active)
     return SCPP_OK;
 }
 
-int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
+int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
 {
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
-    int n_active = c->last_active;
-    for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
-    {
-        int rc = scpp_hip_sc_iterate(c, &n_active);
-        if (rc)
-            return rc;
-    }
     if (c->sc.nondimensionalize)
     {
         SCBuffers b = scBuffers(c);
@@ -507,6 +500,20 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
         *n_converged = n;
     }
     return SCPP_OK;
+}
+
+int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
+{
+    if (!c || !c->sc_ready)
+        return SCPP_E_STATE;
+    int n_active = c->last_active;
+    for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
+    {
+        int rc = scpp_hip_sc_iterate(c, &n_active);
+        if (rc)
+            return rc;
+    }
+    return scpp_hip_sc_finish(c, n_converged);
 }
 
 int scpp_hip_socp_solve(scpp_hip_ctx *c)

@@ -1,0 +1,229 @@
+// C++17 host front end over the C ABI (include/scpp_hip.h): the reference's SCAlgorithm interface
+//   SCAlgorithm(Model::ptr_t), initialize(), solve(bool warm_start = false), getSolution(td&), getAllSolutions(v&)
+//   (scpp_core/include/SCAlgorithm.hpp:17-45, scpp_core/src/SCAlgorithm.cpp:14-232)
+// plus the batched overloads the device engine exists for.  All numerics run in libscpp_hip.so;
+// there is no CPU fallback -- construction throws if the library cannot create a device context.
+#pragma once
+#include <array>
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "parameter_server.hpp"
+#include "rocket_quat.hpp"
+#include "scpp_hip.h"
+
+using Model = scpp::models::RocketQuat; // the reference selects the model with a compile definition (CMakeLists.txt:33-55)
+
+// trajectoryData.hpp:8-32
+struct trajectory_data_t
+{
+    std::vector<Model::state_vector_t> X;
+    std::vector<Model::input_vector_t> U;
+    double t = 0.;
+    void initialize(size_t K, bool interpolate_input)
+    {
+        X.assign(K, Model::state_vector_t{});
+        U.assign(interpolate_input ? K : K - 1, Model::input_vector_t{});
+        t = 0.;
+    }
+    bool interpolatedInput() const { return U.size() == X.size(); }
+    size_t n_X() const { return X.size(); }
+    size_t n_U() const { return U.size(); }
+};
+
+namespace scpp
+{
+
+struct batch_result_t
+{
+    std::vector<trajectory_data_t> td;
+    std::vector<int32_t> sc_iterations, converged, status, ipm_iterations;
+    std::vector<double> norm1_nu, sum_delta;
+};
+
+class SCAlgorithm
+{
+public:
+    explicit SCAlgorithm(Model::ptr_t model_, int batch_max_ = 1, int device_ = 0, int K_override_ = 0)
+        : model(std::move(model_)), batch_max(batch_max_), device(device_), K_override(K_override_) {}
+    ~SCAlgorithm()
+    {
+        if (ctx)
+            scpp_hip_destroy(ctx);
+    }
+    SCAlgorithm(const SCAlgorithm &) = delete;
+    SCAlgorithm &operator=(const SCAlgorithm &) = delete;
+
+    // SCAlgorithm.cpp:22-64
+    void loadParameters()
+    {
+        ParameterServer ps(Model::getParameterFolder() + "/SC.info");
+        bool fft, ii, nd;
+        ps.loadScalar("free_final_time", fft);
+        ps.loadScalar("interpolate_input", ii);
+        ps.loadScalar("K", opts.K);
+        ps.loadScalar("nondimensionalize", nd);
+        ps.loadScalar("weight_time", opts.weight_time);
+        ps.loadScalar("weight_trust_region_time", opts.weight_trust_region_time);
+        ps.loadScalar("weight_trust_region_trajectory", opts.weight_trust_region_trajectory);
+        ps.loadScalar("weight_virtual_control", opts.weight_virtual_control);
+        ps.loadScalar("nu_tol", opts.nu_tol);
+        ps.loadScalar("delta_tol", opts.delta_tol);
+        ps.loadScalar("max_iterations", opts.max_iterations);
+        opts.free_final_time = fft;
+        opts.interpolate_input = ii;
+        opts.nondimensionalize = nd;
+        if (K_override > 0)
+            opts.K = K_override;
+    }
+    void initialize()
+    {
+        loadParameters();
+        check(scpp_hip_create(&ctx, device, SCPP_MODEL_ROCKETQUAT, opts.K, batch_max, 0), "scpp_hip_create");
+        td.initialize(size_t(opts.K), opts.interpolate_input != 0);
+    }
+
+    // ---- the reference's single-problem interface (instance = model->p.x_init) ----
+    void solve(bool warm_start = false)
+    {
+        const std::vector<Model::state_vector_t> x{model->p.x_init};
+        all_td.clear();
+        setup(x, warm_start, nullptr);
+        // drive the iterations from the host so that every iterate can be recorded (all_td, SCAlgorithm.cpp:160-170)
+        all_td.push_back(downloadOne(true));
+        int n_active = 1;
+        iterations = 0;
+        while (iterations < opts.max_iterations && n_active > 0)
+        {
+            iterations++;
+            check(scpp_hip_sc_iterate(ctx, &n_active), "scpp_hip_sc_iterate");
+            all_td.push_back(downloadOne(true));
+        }
+        int nconv = 0;
+        check(scpp_hip_sc_finish(ctx, &nconv), "scpp_hip_sc_finish");
+        converged = nconv > 0;
+        td = downloadOne(false);
+    }
+    void getSolution(trajectory_data_t &trajectory) const { trajectory = td; }
+    void getAllSolutions(std::vector<trajectory_data_t> &all_trajectories) { all_trajectories = all_td; }
+    bool hasConverged() const { return converged; }
+    int getIterations() const { return iterations; }
+
+    // ---- batched interface: B independent instances that differ in x_init ----
+    void solveBatch(const std::vector<Model::state_vector_t> &x_inits, batch_result_t &out, bool warm_start = false,
+                    const std::vector<int32_t> *active = nullptr)
+    {
+        setup(x_inits, warm_start, active);
+        int nconv = 0;
+        check(scpp_hip_sc_solve(ctx, &nconv), "scpp_hip_sc_solve");
+        download(int(x_inits.size()), out);
+    }
+    // scpp::simulate (scpp_core/src/simulation.cpp:25-42) for every row, SI units
+    void simulateBatch(double dt, const std::vector<Model::input_vector_t> &u0, const std::vector<Model::input_vector_t> &u1,
+                       std::vector<Model::state_vector_t> &x)
+    {
+        const int B = int(x.size());
+        std::vector<double> par(size_t(B) * 10), dts(size_t(B), dt);
+        for (int b = 0; b < B; b++)
+            model->flowParams(&par[size_t(b) * 10]);
+        check(scpp_hip_set_flow_params(ctx, par.data(), B), "scpp_hip_set_flow_params");
+        check(scpp_hip_simulate(ctx, dts.data(), &u0[0][0], &u1[0][0], &x[0][0], B), "scpp_hip_simulate");
+    }
+
+    scpp_sc_opts opts{};
+    Model::ptr_t model;
+
+private:
+    static void check(int rc, const char *what)
+    {
+        if (rc != SCPP_OK)
+            throw std::runtime_error(std::string(what) + " failed with code " + std::to_string(rc));
+    }
+    void setup(const std::vector<Model::state_vector_t> &x, bool warm_start, const std::vector<int32_t> *active)
+    {
+        if (!ctx)
+            throw std::runtime_error("SCAlgorithm::initialize() has not been called");
+        const int B = int(x.size());
+        check(scpp_hip_sc_setup(ctx, &model->p.abi, &opts, &x[0][0], B, warm_start ? 1 : 0), "scpp_hip_sc_setup");
+        if (active)
+            check(scpp_hip_sc_set_active(ctx, active->data(), B), "scpp_hip_sc_set_active");
+        scale_m = x[0][0];
+        scale_r = std::sqrt(x[0][1] * x[0][1] + x[0][2] * x[0][2] + x[0][3] * x[0][3]);
+    }
+    void download(int B, batch_result_t &out)
+    {
+        const size_t K = size_t(opts.K);
+        const size_t nB = size_t(B);
+        std::vector<double> X(nB * K * 14), U(nB * K * 4), sigma(nB, 0.);
+        out.sc_iterations.assign(size_t(B), 0);
+        out.converged.assign(size_t(B), 0);
+        out.status.assign(size_t(B), 0);
+        out.ipm_iterations.assign(size_t(B), 0);
+        out.norm1_nu.assign(size_t(B), 0.);
+        out.sum_delta.assign(size_t(B), 0.);
+        check(scpp_hip_download(ctx, X.data(), U.data(), sigma.data(), out.sc_iterations.data(), out.norm1_nu.data(),
+                                out.converged.data(), out.status.data(), out.ipm_iterations.data(), out.sum_delta.data()),
+              "scpp_hip_download");
+        out.td.resize(size_t(B));
+        for (int b = 0; b < B; b++)
+        {
+            trajectory_data_t &t = out.td[size_t(b)];
+            t.initialize(K, true);
+            for (size_t k = 0; k < K; k++)
+            {
+                for (int j = 0; j < 14; j++)
+                    t.X[k][size_t(j)] = X[(size_t(b) * K + k) * 14 + size_t(j)];
+                for (int j = 0; j < 4; j++)
+                    t.U[k][size_t(j)] = U[(size_t(b) * K + k) * 4 + size_t(j)];
+            }
+            t.t = sigma[size_t(b)];
+        }
+    }
+    // instance 0; redimensionalizeTrajectory on the host for iterates fetched mid-solve (rocketQuat.cpp:322-332)
+    trajectory_data_t downloadOne(bool redimensionalize)
+    {
+        batch_result_t r;
+        download(1, r);
+        trajectory_data_t t = r.td[0];
+        if (redimensionalize && opts.nondimensionalize)
+            for (size_t k = 0; k < t.X.size(); k++)
+            {
+                t.X[k][0] *= scale_m;
+                for (int j = 1; j < 7; j++)
+                    t.X[k][size_t(j)] *= scale_r;
+                for (int j = 0; j < 3; j++)
+                    t.U[k][size_t(j)] *= scale_m * scale_r;
+                t.U[k][3] *= scale_m * scale_r * scale_r;
+            }
+        return t;
+    }
+
+    int batch_max, device, K_override;
+    scpp_hip_ctx *ctx = nullptr;
+    trajectory_data_t td;
+    std::vector<trajectory_data_t> all_td;
+    bool converged = false;
+    int iterations = 0;
+    double scale_m = 1., scale_r = 1.;
+};
+
+// commonFunctions.cpp:6-19
+inline Model::input_vector_t interpolatedInput(const std::vector<Model::input_vector_t> &U, double t, double total_time,
+                                               bool first_order_hold)
+{
+    const size_t K = U.size();
+    const double time_step = total_time / double(K - 1);
+    const size_t i = std::min(size_t(t / time_step), K - 2);
+    const Model::input_vector_t u0 = U.at(i);
+    const Model::input_vector_t u1 = first_order_hold ? U.at(i + 1) : u0;
+    const double t_intermediate = std::fmod(t, time_step) / time_step;
+    Model::input_vector_t u;
+    for (size_t j = 0; j < 4; j++)
+        u[j] = u0[j] + (u1[j] - u0[j]) * t_intermediate;
+    return u;
+}
+
+} // namespace scpp

@@ -1,0 +1,105 @@
+// sc_oneshot: the reference's SC_oneshot executable (scpp/src/SC_oneshot.cpp:15-64) on the device engine.
+//   no arguments      : one trajectory from the shipped configuration, every iterate written to
+//                       <out>/output/RocketQuat/SC/<time>/<iter>/{X,U,t}.txt   (what the reference does)
+//   --batch B [--seed S]: B randomised initial states solved at once (the workload of BASELINE configs 1/2);
+//                       instance 0 is written to the same tree under iteration index 0, a summary goes to stdout
+//   --config DIR --out DIR --K n --device d
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "output.hpp"
+#include "sc_algorithm.hpp"
+
+namespace fs = std::filesystem;
+
+int main(int argc, char **argv)
+{
+    std::string config = "../scpp_amd/config", out = "..";
+    int batch = 0, K = 0, device = 0;
+    unsigned long long seed = 20260927ull;
+    for (int i = 1; i < argc; i++)
+    {
+        auto next = [&]() -> const char * {
+            if (i + 1 >= argc)
+            {
+                std::fprintf(stderr, "missing value for %s\n", argv[i]);
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (!std::strcmp(argv[i], "--batch"))
+            batch = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--seed"))
+            seed = std::strtoull(next(), nullptr, 10);
+        else if (!std::strcmp(argv[i], "--config"))
+            config = next();
+        else if (!std::strcmp(argv[i], "--out"))
+            out = next();
+        else if (!std::strcmp(argv[i], "--K"))
+            K = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--device"))
+            device = std::atoi(next());
+        else
+        {
+            std::fprintf(stderr, "unknown argument %s\n", argv[i]);
+            return 2;
+        }
+    }
+    try
+    {
+        Model::setParameterFolder(config);
+        auto model = std::make_shared<Model>();
+        model->loadParameters();
+
+        scpp::SCAlgorithm solver(model, batch > 0 ? batch : 1, device, K);
+        solver.initialize();
+
+        std::vector<trajectory_data_t> all_td;
+        if (batch <= 0)
+        {
+            solver.solve();
+            solver.getAllSolutions(all_td);
+            std::printf("%s after %d iterations.\n", solver.hasConverged() ? "Converged" : "No convergence", solver.getIterations());
+        }
+        else
+        {
+            std::vector<Model::state_vector_t> x_inits;
+            for (int b = 0; b < batch; b++)
+            {
+                Model inst = *model;
+                inst.p.randomizeInitialState(seed, uint64_t(b));
+                x_inits.push_back(inst.p.x_init);
+            }
+            scpp::batch_result_t r;
+            solver.solveBatch(x_inits, r);
+            long conv = 0, fails = 0, iters = 0;
+            for (int b = 0; b < batch; b++)
+            {
+                conv += r.converged[size_t(b)];
+                fails += r.status[size_t(b)] != 0;
+                iters += r.sc_iterations[size_t(b)];
+            }
+            std::printf("batch %d: converged %ld, solver failures %ld, mean SC iterations %.2f\n", batch, conv, fails, double(iters) / batch);
+            all_td.push_back(r.td[0]);
+        }
+
+        const fs::path outputPath = fs::path(out) / "output" / Model::getModelName() / "SC" / scpp::getTimeString();
+        for (size_t k = 0; k < all_td.size(); k++)
+        {
+            const fs::path iterationPath = outputPath / std::to_string(k);
+            scpp::makeDir(iterationPath);
+            scpp::writeRows(iterationPath / "X.txt", all_td[k].X);
+            scpp::writeRows(iterationPath / "U.txt", all_td[k].U);
+            std::ofstream f(iterationPath / "t.txt");
+            f << all_td[k].t;
+        }
+        std::printf("output: %s\n", outputPath.string().c_str());
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "sc_oneshot: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,88 @@
+"""C++17 host front end (scpp_amd/host): the reference's SC_oneshot / SC_sim executables over the C ABI.
+On this GPU-less machine the executables are linked against the CPU wave-emulation build of the kernels
+(`make emu`); the product binaries link libscpp_hip.so.  Outputs are the reference's CSV tree (6 significant
+digits), compared with the oracle run of the same instance."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "scpp_amd", "host")
+CONFIG = os.path.join(ROOT, "scpp_amd", "config")
+
+
+@pytest.fixture(scope="module")
+def host_emu(emu_lib):
+    subprocess.check_call(["make", "-s", "-C", HOST, "emu"])
+    return HOST
+
+
+def _read(path):
+    return np.loadtxt(path, delimiter=",", ndmin=2)
+
+
+def test_sc_oneshot_writes_reference_output_tree(oracle, host_emu, tmp_path):
+    K = 8
+    out = subprocess.check_output([os.path.join(host_emu, "sc_oneshot_emu"), "--K", str(K), "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    assert "No convergence after 15 iterations." in out or "Converged after" in out
+    runs = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SC" / "*"))
+    assert len(runs) == 1
+    iters = sorted(int(os.path.basename(d)) for d in glob.glob(os.path.join(runs[0], "*")))
+    sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.set_solver(1); sc.solve()
+    m = sc.meta()
+    assert iters == list(range(m["n_all_td"]))  # initial guess + one directory per iteration (SC_oneshot.cpp:38-62)
+    # every iterate, redimensionalised like getAllSolutions (SCAlgorithm.cpp:217-232), at the CSV's 6 significant digits
+    scales = sc.x_init()
+    ms, rs = scales[0], np.linalg.norm(scales[1:4])
+    for it in (0, 1, m["n_all_td"] - 1):
+        X, U, t = sc.iterate(it)
+        X = X.copy(); U = U.copy()
+        X[:, 0] *= ms; X[:, 1:7] *= rs; U[:, :3] *= ms * rs; U[:, 3] *= ms * rs * rs
+        Xf, Uf = _read(os.path.join(runs[0], str(it), "X.txt")), _read(os.path.join(runs[0], str(it), "U.txt"))
+        tf = float(open(os.path.join(runs[0], str(it), "t.txt")).read())
+        assert Xf.shape == (K, 14) and Uf.shape == (K, 4)
+        assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
+        assert np.allclose(Uf, U, rtol=2e-5, atol=2e-5 * np.abs(U).max())
+        assert abs(tf - t) <= 2e-5 * abs(t)
+
+
+def test_sc_oneshot_batch_and_sc_sim(oracle, host_emu, tmp_path):
+    K = 8
+    out = subprocess.check_output([os.path.join(host_emu, "sc_oneshot_emu"), "--K", str(K), "--batch", "3", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    assert "batch 3:" in out and "solver failures 0" in out
+    out = subprocess.check_output([os.path.join(host_emu, "sc_sim_emu"), "--K", str(K), "--steps", "2", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    assert "Average frequency" in out
+    run = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SC_sim" / "*" / "0"))[0]
+    Xf, Uf = _read(os.path.join(run, "X.txt")), _read(os.path.join(run, "U.txt"))
+    sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.set_solver(1)
+    o = sc.sim(0.05, 2)
+    assert Xf.shape == (2, 14) and Uf.shape == (2, 4)
+    assert np.allclose(Xf, o["X_sim"], rtol=2e-5, atol=2e-5 * np.abs(o["X_sim"]).max())
+    assert np.allclose(Uf, o["U_sim"], rtol=2e-5, atol=2e-5 * np.abs(o["U_sim"]).max())
+    assert abs(float(open(os.path.join(run, "t.txt")).read()) - 0.1) < 1e-12
+
+
+@pytest.mark.gpu
+def test_host_executables_on_gpu(oracle, tmp_path):
+    """The product binaries (linked against libscpp_hip.so) on the real device: SC_oneshot of the shipped K=50
+    scenario against the oracle, a 512-instance batch and a short batched SC_sim."""
+    import __graft_entry__ as g
+
+    g.build_host()
+    exe = os.path.join(HOST, "sc_oneshot")
+    out = subprocess.check_output([exe, "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    run = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SC" / "*"))[0]
+    sc = oracle.SC(oracle.ROCKETQUAT, K=50); sc.set_solver(1); sc.solve()
+    m = sc.meta()
+    last = m["n_all_td"] - 1
+    X, U, t = sc.solution()
+    Xf, Uf = _read(os.path.join(run, str(last), "X.txt")), _read(os.path.join(run, str(last), "U.txt"))
+    assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
+    assert np.allclose(Uf, U, rtol=2e-5, atol=2e-5 * np.abs(U).max())
+    out = subprocess.check_output([exe, "--batch", "512", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    assert "batch 512:" in out and "solver failures 0" in out
+    out = subprocess.check_output([os.path.join(HOST, "sc_sim"), "--batch", "64", "--steps", "3", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    assert "64 closed loops, 192 solves" in out
