@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic work per unit
 FLOP_PER_IPM_ITER = 2.0e6        # one Mehrotra iteration of one instance: 1 factorisation + 2 solves + cone algebra
-# (94.57e9 B fetched + 76.10e9 B written per launch) / (2048 instances x 23.59 IPM iterations per launch)
-IPM_TRAFFIC_BYTES_PER_ITER = 3.53e6
+# (79.04e9 B fetched + 65.37e9 B written per launch) / (2048 instances x 23.59 IPM iterations per launch)
+IPM_TRAFFIC_BYTES_PER_ITER = 2.99e6
 FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
 DISC_FLOP_PER_INSTANCE = 5.9e7    # 49 seg x 65 RHS x ~18.6 kflop (AD Jacobian + A*V + RK combination)
@@ -207,10 +207,10 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_TFLOPS,
                 # HBM bytes per launch: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes,
-                # profiles/r01_pmc_hbm_v3_batch2048.txt) per instance-IPM-iteration x this run's iterations per launch
+                # profiles/r01_pmc_hbm_v4_batch2048.txt) per instance-IPM-iteration x this run's iterations per launch
                 "traffic": IPM_TRAFFIC_BYTES_PER_ITER * stats["ipm_iters"] / max(tm["n_socp"], 1),
                 "traffic_GBs": IPM_TRAFFIC_BYTES_PER_ITER * stats["ipm_iters"] / socp_s / 1e9 if socp_s > 0 else 0.0,
-                "traffic_note": "PMC-measured 3.53 MB per instance-IPM-iteration (r01 v3 profile, batch 2048), scaled by the "
+                "traffic_note": "PMC-measured 2.99 MB per instance-IPM-iteration (r01 v4 profile, batch 2048), scaled by the "
                                 "iterations of this run; algorithmic minimum (read dd + write X,U) is 0.15 MB per launch-instance",
                 "avg_launch_ms": tm["ms_socp"] / max(tm["n_socp"], 1),
                 "launches": tm["n_socp"],
