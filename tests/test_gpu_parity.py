@@ -233,3 +233,27 @@ def test_sc_sim_stop_mask(model, alg):
         assert _rel(second["X"][b], first["X"][b]) < 1e-12
     for b in (0, 2):
         assert second["sc_iters"][b] > 0
+
+
+@pytest.mark.parametrize("K", [3, 15, 64])
+def test_edge_horizons_on_gpu(oracle, model, hip_lib, K):
+    """Smallest horizon, the reference's shipped K = 15, and the largest one the lane = stage mapping admits
+    (K = 64: every lane of the wavefront owns a stage), with a batch that does not fill the 8-instance XCD groups."""
+    B = 5
+    a = scpp_amd.SCAlgorithm(model, K=K, batch_max=8, library=hip_lib).initialize()
+    x0 = model.randomized_initial_states(B)
+    a.ctx.sc_setup(model.p, a.opts, x0)
+    a.ctx.sc_iterate()
+    out = a.ctx.download()
+    checked = 0
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=K); sc.randomize(20260927, b); sc.set_solver(1); sc.solve()
+        if sc.info()[0][5] != 0:
+            continue
+        X1, U1, t1 = sc.iterate(1)
+        assert out["status"][b] == 0
+        assert out["ipm_iters"][b] == int(sc.info()[0][4])
+        assert _rel(out["X"][b], X1) < 1e-8 and _rel(out["U"][b], U1) < 1e-8
+        checked += 1
+    assert checked >= 3
+    a.ctx.close()
