@@ -10,6 +10,7 @@
 #include "models.hpp"
 #include "sc.hpp"
 #include "sc_sim.hpp"
+#include "scvx.hpp"
 #include "socp.hpp"
 
 using namespace oracle;
@@ -490,3 +491,145 @@ int oracle_sc_batch(const char *config_root, int K, unsigned long long seed, lon
 }
 
 } // extern "C"
+
+
+// ---- SCvx (RocketQuat) ----
+namespace
+{
+struct SCvxHandle
+{
+    RocketQuat model;
+    std::unique_ptr<SCvxAlgorithm<RocketQuat>> alg;
+    SCvxHandle(const std::string &root, int K)
+    {
+        const std::string folder = root + "/" + RocketQuat::modelName();
+        model.loadParameters(folder);
+        alg.reset(new SCvxAlgorithm<RocketQuat>(&model, folder, K));
+        alg->initialize();
+    }
+};
+} // namespace
+
+extern "C"
+{
+void *oracle_scvx_create(const char *config_root, int K_override)
+{
+    try
+    {
+        return new SCvxHandle(config_root, K_override);
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_scvx_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void oracle_scvx_destroy(void *h) { delete static_cast<SCvxHandle *>(h); }
+int oracle_scvx_set_solver(void *h, int kind)
+{
+    static_cast<SCvxHandle *>(h)->alg->solver_kind = kind;
+    return 0;
+}
+int oracle_scvx_set_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    a.socp_settings.feastol = feastol;
+    a.socp_settings.abstol = abstol;
+    a.socp_settings.reltol = reltol;
+    a.socp_settings.maxit = maxit;
+    return 0;
+}
+int oracle_scvx_verbose(void *h, int v)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    a.socp_settings.verbose = v != 0;
+    a.structured_settings.verbose = v != 0;
+    return 0;
+}
+int oracle_scvx_set_reg(void *h, double dx, double deq, double dcone)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    a.socp_settings.delta_x = dx;
+    a.socp_settings.delta_eq = deq;
+    a.socp_settings.delta_cone = dcone;
+    return 0;
+}
+int oracle_scvx_randomize(void *h, unsigned long long seed, unsigned long long instance)
+{
+    static_cast<SCvxHandle *>(h)->model.p.randomizeInitialState(seed, instance);
+    return 0;
+}
+int oracle_scvx_set_max_iterations(void *h, int n)
+{
+    static_cast<SCvxHandle *>(h)->alg->max_iterations_override = size_t(n);
+    static_cast<SCvxHandle *>(h)->alg->max_iterations = size_t(n);
+    return 0;
+}
+int oracle_scvx_solve(void *h, int warm_start)
+{
+    try
+    {
+        auto &a = *static_cast<SCvxHandle *>(h)->alg;
+        const size_t keep = a.max_iterations;
+        a.solve(warm_start != 0);
+        (void)keep;
+        return a.solver_failed ? -1 : 0;
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_scvx_solve: %s\n", e.what());
+        return -2;
+    }
+}
+// meta: [K, nU, iterations, converged, n_all_td, n_info, solves, n, p, l, ncones, m]
+int oracle_scvx_meta(void *h, int *meta)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    meta[0] = a.td.K;
+    meta[1] = a.td.nU;
+    meta[2] = a.iterations;
+    meta[3] = a.converged;
+    meta[4] = int(a.all_td.size());
+    meta[5] = int(a.info.size());
+    meta[6] = a.solves;
+    for (int i = 0; i < 5; i++)
+        meta[7 + i] = a.last_dims[i];
+    return 0;
+}
+int oracle_scvx_get_iterate(void *h, int idx, double *X, double *U, double *t)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    const TrajectoryData *td = &a.td;
+    if (idx >= 0)
+    {
+        if (idx >= int(a.all_td.size()))
+            return -1;
+        td = &a.all_td[size_t(idx)];
+    }
+    std::memcpy(X, td->X.data(), td->X.size() * sizeof(double));
+    std::memcpy(U, td->U.data(), td->U.size() * sizeof(double));
+    *t = td->t;
+    return 0;
+}
+// per-solve rows: [norm1_nu, nonlinear_cost, actual_change, predicted_change, rho, trust_region(after), accepted, ipm_iters, exitflag]
+int oracle_scvx_get_info(void *h, double *rows, int max_rows)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    const int n = std::min<int>(max_rows, int(a.info.size()));
+    for (int i = 0; i < n; i++)
+    {
+        const SCvxIterationInfo &f = a.info[size_t(i)];
+        double *r = rows + i * 9;
+        r[0] = f.norm1_nu;
+        r[1] = f.nonlinear_cost;
+        r[2] = f.actual_change;
+        r[3] = f.predicted_change;
+        r[4] = f.rho;
+        r[5] = f.trust_region;
+        r[6] = f.accepted;
+        r[7] = f.ipm_iters;
+        r[8] = f.exitflag;
+    }
+    return n;
+}
+}

@@ -39,6 +39,12 @@ struct RQSocpInput
     const double *uhat;                 // [K][3] linearised min-thrust directions (thrust_const)
     RQStageData cst;
     double w_t, w_trt, w_trx, w_vc;     // cost weights
+    // SCvx mode (SCvxProblem.cpp:6-71): hard INPUT trust region ||u_k - ubar_k|| <= trust_region instead of the
+    // penalised state+input one, fixed final time.  Realised inside the same structure: delta_k is a constant
+    // (= trust_region, no elimination), the state rows of the trust cone are zero padding (same central path as the
+    // 4-dimensional cone: the barrier does not see zero components), S = 0 decouples the (then dummy) sigma block.
+    bool scvx = false;
+    double trust_region = 0.;
 };
 
 struct RQSocpSettings
@@ -380,9 +386,9 @@ class RQStructuredSocp
         const double *wb = &wbar[size_t(k) * NV];
         const double *uh = &P->uhat[size_t(k) * 3];
         const RQStageData &c = P->cst;
-        out[0] = dlk;
+        out[0] = P->scvx ? P->trust_region : dlk;
         for (int j = 0; j < NV; j++)
-            out[1 + j] = wb[j] - wk[j];
+            out[1 + j] = tx(j) * (wb[j] - wk[j]);
         out[17] = c.gs * wk[3];
         out[18] = wk[1];
         out[19] = wk[2];
@@ -403,6 +409,8 @@ class RQStructuredSocp
         out[34] = uh[0] * wk[13] + uh[1] * wk[14] + uh[2] * wk[15] - c.Tmin;
         maskInactive(k, out);
     }
+    // trust-cone row of stage variable j present?  (SCvx: inputs only)
+    double tx(int j) const { return (P->scvx && j < 13) ? 0. : 1.; }
     void maskInactive(int k, double *v) const
     {
         using namespace sipm;
@@ -421,9 +429,9 @@ class RQStructuredSocp
         using namespace sipm;
         const double *uh = &P->uhat[size_t(k) * 3];
         const RQStageData &c = P->cst;
-        out[0] = ddlk;
+        out[0] = P->scvx ? 0. : ddlk;
         for (int j = 0; j < NV; j++)
-            out[1 + j] = -dwk[j];
+            out[1 + j] = -tx(j) * dwk[j];
         out[17] = c.gs * dwk[3];
         out[18] = dwk[1];
         out[19] = dwk[2];
@@ -452,7 +460,7 @@ class RQStructuredSocp
         const RQStageData &c = P->cst;
         gdl = v[0];
         for (int j = 0; j < NV; j++)
-            gw[j] = -v[1 + j];
+            gw[j] = -tx(j) * v[1 + j];
         gw[3] += c.gs * v[17];
         gw[1] += v[18];
         gw[2] += v[19];
@@ -593,12 +601,25 @@ class RQStructuredSocp
             const Scaling &sc = scal[size_t(k) * NCONE + 0];
             const double e2 = 1. / (sc.eta * sc.eta);
             const double den = 2. * sc.w[0] * sc.w[0] - 1.;
-            hdd[k] = den * e2;
-            for (int j = 0; j < NV; j++)
-                hdw[size_t(k) * NV + j] = (fm[k] & (1u << j)) ? 0. : 2. * sc.w[0] * sc.w[1 + j] * e2;
-            for (int i = 0; i < NV; i++)
+            if (!P->scvx)
+            {
+                hdd[k] = den * e2;
                 for (int j = 0; j < NV; j++)
-                    H[i * NV + j] = e2 * ((i == j ? 1. : 0.) - (2. / den) * sc.w[1 + i] * sc.w[1 + j]);
+                    hdw[size_t(k) * NV + j] = (fm[k] & (1u << j)) ? 0. : 2. * sc.w[0] * sc.w[1 + j] * e2;
+                for (int i = 0; i < NV; i++)
+                    for (int j = 0; j < NV; j++)
+                        H[i * NV + j] = e2 * ((i == j ? 1. : 0.) - (2. / den) * sc.w[1 + i] * sc.w[1 + j]);
+            }
+            else
+            {
+                // delta is a constant: plain L' W^-2 L of the rows that exist, W^-2_ab = e2 (delta_ab + 2 w_a w_b), a,b >= 1
+                hdd[k] = 1.;
+                for (int j = 0; j < NV; j++)
+                    hdw[size_t(k) * NV + j] = 0.;
+                for (int i = 0; i < NV; i++)
+                    for (int j = 0; j < NV; j++)
+                        H[i * NV + j] = tx(i) * tx(j) * e2 * ((i == j ? 1. : 0.) + 2. * sc.w[1 + i] * sc.w[1 + j]);
+            }
         }
         if (act[k] & 2u)
         {
@@ -942,7 +963,7 @@ class RQStructuredSocp
             double acc = 0.;
             for (int j = 0; j < NV; j++)
                 acc += hdw[size_t(k) * NV + j] * dw[size_t(k) * NV + j];
-            ddl[k] = (b.d[k] - acc) / hdd[k];
+            ddl[k] = P->scvx ? 0. : (b.d[k] - acc) / hdd[k];
         }
         double sumnb = 0.;
         for (int k = 0; k < K - 1; k++)
@@ -1104,7 +1125,7 @@ class RQStructuredSocp
             {
                 double gw[NV], gdl;
                 LTmul(k, &z[size_t(k) * NS], gw, gdl);
-                rxd[k] = wtrx - gdl;
+                rxd[k] = P->scvx ? 0. : wtrx - gdl;
                 double *r = &rxw[size_t(k) * NV];
                 for (int j = 0; j < NV; j++)
                     r[j] = -gw[j];

@@ -237,6 +237,56 @@ class SC:
         return out
 
 
+class SCvx:
+    """Oracle SCvxAlgorithm handle for RocketQuat (oracle/scvx.hpp: SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:22-278)."""
+
+    def __init__(self, K=0, config_root=CONFIG_ROOT):
+        lib().oracle_scvx_create.restype = C.c_void_p
+        self.h = lib().oracle_scvx_create(config_root.encode(), int(K))
+        if not self.h:
+            raise RuntimeError("oracle_scvx_create failed")
+        self.h = C.c_void_p(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_scvx_destroy(self.h)
+            self.h = None
+
+    def set_solver(self, kind):
+        lib().oracle_scvx_set_solver(self.h, int(kind))
+
+    def set_tolerances(self, feastol=1e-8, abstol=1e-8, reltol=1e-8, maxit=100):
+        lib().oracle_scvx_set_tolerances(self.h, C.c_double(feastol), C.c_double(abstol), C.c_double(reltol), int(maxit))
+
+    def randomize(self, seed, instance):
+        return lib().oracle_scvx_randomize(self.h, C.c_ulonglong(seed), C.c_ulonglong(instance))
+
+    def set_max_iterations(self, n):
+        lib().oracle_scvx_set_max_iterations(self.h, int(n))
+
+    def solve(self, warm_start=False):
+        return lib().oracle_scvx_solve(self.h, int(warm_start))
+
+    def meta(self):
+        m = np.zeros(12, dtype=np.int32)
+        lib().oracle_scvx_meta(self.h, _p(m))
+        keys = "K nU iterations converged n_all_td n_info solves n p l ncones m".split()
+        return dict(zip(keys, [int(v) for v in m]))
+
+    def iterate(self, idx=-1):
+        m = self.meta()
+        X = np.zeros((m["K"], 14))
+        U = np.zeros((m["nU"], 4))
+        t = C.c_double(0)
+        assert lib().oracle_scvx_get_iterate(self.h, int(idx), _p(X), _p(U), C.byref(t)) == 0
+        return X, U, t.value
+
+    def info(self):
+        rows = np.zeros((256, 9))
+        n = lib().oracle_scvx_get_info(self.h, _p(rows), 256)
+        return rows[:n]
+
+
 def sc_batch(K, seed, first, count, nthreads=1, solver=1, config_root=CONFIG_ROOT):
     X = np.zeros((count, K, 14))
     U = np.zeros((count, K, 4))

@@ -1,0 +1,63 @@
+"""Oracle restatement of the SCvx variant (oracle/scvx.hpp: SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:22-278):
+problem dimensions against SURVEY.md §8(a) row a8', the structured twin's SCvx mode against the literal
+standard-form solver, and the accept / reject / radius-update logic."""
+import numpy as np
+
+
+def test_scvx_literal_problem_dimensions(oracle):
+    """n = 2273, p = 814, l = 1473, 300 cones (sum dim 1100) for RocketQuat K = 50 (SURVEY a8')."""
+    s = oracle.SCvx(K=50)
+    s.set_solver(0)
+    s.set_tolerances(1e-8, 1e-6, 1e-6, 3)  # only the assembly matters here: stop after 3 IPM iterations
+    s.set_max_iterations(1)
+    s.solve()
+    m = s.meta()
+    assert (m["n"], m["p"], m["l"], m["ncones"]) == (2273, 814, 1473, 300)
+    assert m["m"] == 1473 + 1100
+
+
+def test_scvx_twin_matches_literal_solver_on_first_subproblem(oracle):
+    K = 12
+    a = oracle.SCvx(K=K); a.set_solver(0); a.set_tolerances(1e-8, 1e-6, 1e-6, 100); a.set_max_iterations(1)
+    b = oracle.SCvx(K=K); b.set_solver(1); b.set_max_iterations(1)
+    assert a.solve() == 0 and b.solve() == 0
+    Xa, Ua, ta = a.iterate(1)
+    Xb, Ub, tb = b.iterate(1)
+    assert ta == tb  # fixed final time
+    # the objective (virtual control only) pins norm1_nu tightly; X and U sit on a flat optimal face, so two
+    # solvers stopped at different tolerances agree there to ~1e-5
+    assert np.abs(Xa - Xb).max() <= 2e-4 * np.abs(Xa).max()
+    assert np.abs(Ua - Ub).max() <= 2e-4 * np.abs(Ua).max()
+    ia, ib = a.info()[0], b.info()[0]
+    assert abs(ia[0] - ib[0]) <= 1e-6 * abs(ia[0])          # norm1_nu
+    assert abs(ia[1] - ib[1]) <= 1e-3 * abs(ia[1]) + 1e-6   # nonlinear cost of the candidate
+    # the hard input trust region is respected by both
+    X0, U0, _ = a.iterate(0)
+    assert np.linalg.norm(Ua - U0, axis=1).max() <= 5.0 * (1 + 1e-6)
+    assert np.linalg.norm(Ub - U0, axis=1).max() <= 5.0 * (1 + 1e-6)
+
+
+def test_scvx_accept_reject_logic(oracle):
+    """rho = dJ/dL drives the radius (SCvxAlgorithm.cpp:121-152); rejected candidates restore the trajectory and
+    re-solve without re-discretising; convergence = |dL| < change_threshold."""
+    s = oracle.SCvx(K=10); s.set_solver(1); s.set_max_iterations(12)
+    assert s.solve() == 0
+    m, info = s.meta(), s.info()
+    assert m["solves"] == len(info) and m["solves"] >= m["iterations"]
+    assert info[0][6] == 2  # first pass only records the nonlinear cost
+    tr = 5.0
+    for r in info[1:]:
+        norm1, J, dJ, dL, rho, tr_after, acc = r[:7]
+        if acc == 3:
+            assert abs(dL) < 1e-3
+            assert tr_after == tr
+        elif acc == 0:
+            assert rho < 0.0 and abs(tr_after - tr / 2.0) < 1e-15
+        else:
+            assert rho >= 0.0
+            want = tr / 2.0 if rho < 0.25 else (tr * 3.2 if rho >= 0.9 else tr)
+            assert abs(tr_after - want) < 1e-15
+        tr = tr_after
+    assert m["converged"] == int(info[-1][6] == 3)
+    # the nonlinear defect of the final trajectory is what the last accepted row reports
+    assert info[-1][1] < info[0][1]
