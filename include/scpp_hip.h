@@ -17,6 +17,9 @@
  *   (incl. RocketQuat (non|re)dimensionalize*, getInitializedTrajectory,       scpp_hip_sc_solve
  *    getNewModelParameters: rocketQuat.cpp:39-68,156-201,291-332)
  *   SCAlgorithm::getSolution              scpp_core/include/SCAlgorithm.hpp:37 scpp_hip_download
+ *   SCvxAlgorithm::initialize/solve/       scpp_core/src/SCvxAlgorithm.cpp:46-227, scpp_hip_scvx_setup, scpp_hip_scvx_solve,
+ *   iterate/getNonlinearCost on            SCvxProblem.cpp:6-71                   scpp_hip_scvx_download_state
+ *   buildSCvxProblem
  *   SC_sim closed loop (warm start, plant  scpp/src/SC_sim.cpp:28-66            scpp_hip_sc_setup(warm_start=1),
  *   step, stop rule)                                                            scpp_hip_simulate, scpp_hip_sc_set_active
  *
@@ -70,6 +73,15 @@ extern "C"
         double nu_tol, delta_tol;
     } scpp_sc_opts;
 
+    /* SCvx.info (SCvxAlgorithm.cpp:22-44) */
+    typedef struct
+    {
+        int K;
+        int interpolate_input, nondimensionalize, max_iterations;
+        double alpha, beta, rho_0, rho_1, rho_2;
+        double change_threshold, weight_virtual_control, trust_region;
+    } scpp_scvx_opts;
+
     /* interior-point settings (ECOS-style tolerances) */
     typedef struct
     {
@@ -111,6 +123,16 @@ extern "C"
        sc_iterate themselves, e.g. to record every iterate like getAllSolutions (SCAlgorithm.cpp:217-232) */
     int scpp_hip_sc_finish(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_socp_solve(scpp_hip_ctx *ctx);                 /* sub-problem only, on the current td/dd */
+    /* ---- SCvxAlgorithm boundary (RocketQuat): fixed final time, hard input trust region, rho-ratio radius update
+       (scpp_core/src/SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:61-227).  Results through scpp_hip_download
+       (sc_iters = SCvx iterations); per-instance radius, last nonlinear cost J, number of sub-problem solves and
+       [rho, dJ, dL, code] of the last decision (code 0 rejected, 1 accepted, 2 first pass, 3 converged) through
+       scpp_hip_scvx_download_state (any pointer may be NULL) ---- */
+    int scpp_hip_scvx_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_scvx_opts *opts,
+                            const double *x_init /* [B][14] dimensional */, int B, int warm_start);
+    int scpp_hip_scvx_solve(scpp_hip_ctx *ctx, int *n_converged);
+    int scpp_hip_scvx_download_state(scpp_hip_ctx *ctx, double *trust_region, double *nonlinear_cost, int32_t *solves,
+                                     double *last_decision /* [B][4] */);
     /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                           int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -409,6 +410,16 @@ class RQStructuredSocp
         out[34] = uh[0] * wk[13] + uh[1] * wk[14] + uh[2] * wk[15] - c.Tmin;
         maskInactive(k, out);
     }
+    // static dual regularisation -delta I of the multiplier block (every interior-point code has one; ECOS: 7e-8 with
+    // iterative refinement).  SCvx only: there the virtual control really goes to zero (E^-1 -> 0), and with the
+    // initial state fixed M_0 has rank 3 < 14, so Theta_0 = E^-1 + Y Y' would become numerically singular.
+    double dualReg() const
+    {
+        if (!P->scvx)
+            return 0.;
+        const char *e = std::getenv("ORACLE_SCVX_DUALREG");
+        return e ? std::atof(e) : 1e-9;
+    }
     // trust-cone row of stage variable j present?  (SCvx: inputs only)
     double tx(int j) const { return (P->scvx && j < 13) ? 0. : 1.; }
     void maskInactive(int k, double *v) const
@@ -758,7 +769,7 @@ class RQStructuredSocp
                     for (int q = 0; q < NV; q++)
                         acc += Yt[q * NV + i] * Yt[q * NV + j];
                     if (i == j)
-                        acc += Einv[size_t(k) * NL + i];
+                        acc += Einv[size_t(k) * NL + i] + dualReg();
                     Th[i * NL + j] = acc;
                 }
             double *Ti = &Tif[size_t(k) * 256];
@@ -1221,20 +1232,24 @@ class RQStructuredSocp
                 return -2;
             if (pres < opt.feastol && dres < opt.feastol && (gap < opt.abstol || relgap < opt.reltol))
                 return 0;
+            // ECOS's reduced-accuracy exit (feastol_inacc 1e-4, abstol_inacc / reltol_inacc 5e-5): when the iteration
+            // limit or a numerical breakdown is hit at an iterate that already satisfies the relaxed tolerances, ECOS
+            // returns it as "close to optimal" instead of failing
+            const bool inacc_ok = pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
             if (iter >= opt.maxit)
-                return -1;
+                return inacc_ok ? 0 : -1;
 
             // ---------- scalings, factorisation ----------
             if (!updateScalings())
             {
                 last_fail = 1;
-                return -2;
+                return inacc_ok ? 0 : -2;
             }
             if (!factor())
             {
                 if (opt.verbose)
                     std::printf("factor failed: code %d\n", last_fail);
-                return -2;
+                return inacc_ok ? 0 : -2;
             }
             // lambda = W z (scaled variable), per cone
             for (int k = 0; k < K; k++)

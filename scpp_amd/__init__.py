@@ -20,3 +20,4 @@ from .parameter_server import ParameterServer  # noqa: F401
 from .models import RocketQuat, counter_uniform  # noqa: F401
 from .sc_algorithm import SCAlgorithm, load_sc_opts  # noqa: F401
 from .sc_sim import SCSim, interpolated_input  # noqa: F401
+from .scvx_algorithm import SCvxAlgorithm, load_scvx_opts  # noqa: F401

@@ -54,6 +54,15 @@ class SCOpts(C.Structure):
     ]
 
 
+class SCvxOpts(C.Structure):
+    """scpp_scvx_opts (SCvx.info, SCvxAlgorithm.cpp:22-44)"""
+    _fields_ = [
+        ("K", C.c_int), ("interpolate_input", C.c_int), ("nondimensionalize", C.c_int), ("max_iterations", C.c_int),
+        ("alpha", C.c_double), ("beta", C.c_double), ("rho_0", C.c_double), ("rho_1", C.c_double), ("rho_2", C.c_double),
+        ("change_threshold", C.c_double), ("weight_virtual_control", C.c_double), ("trust_region", C.c_double),
+    ]
+
+
 class SocpOpts(C.Structure):
     _fields_ = [
         ("feastol", C.c_double),
@@ -82,7 +91,7 @@ _lib_path = None
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
     "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
-    "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
+    "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
 ]
 
@@ -196,6 +205,23 @@ class Context:
         n = C.c_int(0)
         _chk(self.lib.scpp_hip_sc_iterate(self.h, C.byref(n)), "sc_iterate")
         return n.value
+
+    # ---- SCvx boundary ----
+    def scvx_setup(self, model_params, scvx_opts, x_init, warm_start=False):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        self.B = x_init.shape[0]
+        _chk(self.lib.scpp_hip_scvx_setup(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(self.B), int(warm_start)), "scvx_setup")
+
+    def scvx_solve(self):
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_scvx_solve(self.h, C.byref(n)), "scvx_solve")
+        return n.value
+
+    def scvx_state(self):
+        B = self.B
+        tr, cost, solves, dec = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
+        _chk(self.lib.scpp_hip_scvx_download_state(self.h, _p(tr), _p(cost), _p(solves), _p(dec)), "scvx_download_state")
+        return dict(trust_region=tr, nonlinear_cost=cost, solves=solves, last_decision=dec)
 
     def sc_finish(self):
         n = C.c_int(0)

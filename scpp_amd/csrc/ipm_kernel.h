@@ -55,6 +55,10 @@ enum InstPar
     IP_MSCALE = 49,
     IP_RSCALE,
     IP_FINALTIME,
+    // SCvx mode (SCvxProblem.cpp:6-71) inside the same structure -- see oracle/structured_ipm.hpp (RQSocpInput::scvx):
+    // delta_k is the constant trust_region, the state rows of the trust cone are zero padding, S = 0 decouples sigma
+    IP_SCVX = 52,
+    IP_TR = 53,
     IP_N = 56
 };
 
@@ -248,9 +252,10 @@ __device__ inline void maskInactive(unsigned act, AV v)
 template <class AW, class AB, class AU, class AO>
 __device__ inline void saff(const double *ip, unsigned act, AW wk, double dlk, AB wb, AU uh, AO out)
 {
-    out[0] = dlk;
+    const bool scvx = ip[IP_SCVX] != 0.;
+    out[0] = scvx ? ip[IP_TR] : dlk;
     for (int j = 0; j < NV; j++)
-        out[1 + j] = wb[j] - wk[j];
+        out[1 + j] = (scvx && j < 13) ? 0. : wb[j] - wk[j];
     out[17] = ip[IP_GS] * wk[3];
     out[18] = wk[1];
     out[19] = wk[2];
@@ -275,9 +280,10 @@ __device__ inline void saff(const double *ip, unsigned act, AW wk, double dlk, A
 template <class AW, class AU, class AO>
 __device__ inline void Lmul(const double *ip, unsigned act, AW dwk, double ddlk, AU uh, AO out)
 {
-    out[0] = ddlk;
+    const bool scvx = ip[IP_SCVX] != 0.;
+    out[0] = scvx ? 0. : ddlk;
     for (int j = 0; j < NV; j++)
-        out[1 + j] = -dwk[j];
+        out[1 + j] = (scvx && j < 13) ? 0. : -dwk[j];
     out[17] = ip[IP_GS] * dwk[3];
     out[18] = dwk[1];
     out[19] = dwk[2];
@@ -302,9 +308,10 @@ __device__ inline void Lmul(const double *ip, unsigned act, AW dwk, double ddlk,
 template <class AV, class AU>
 __device__ inline void LTmul(const double *ip, unsigned fm, AV v, AU uh, double *gw, double *gdl)
 {
+    const bool scvx = ip[IP_SCVX] != 0.;
     *gdl = v[0];
     for (int j = 0; j < NV; j++)
-        gw[j] = -v[1 + j];
+        gw[j] = (scvx && j < 13) ? 0. : -v[1 + j];
     gw[3] += ip[IP_GS] * v[17];
     gw[1] += v[18];
     gw[2] += v[19];
@@ -447,13 +454,16 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
     for (int i = 0; i < 27; i++)
         Hs[i] = 0.;
     {
+        const bool scvx = c.ip[IP_SCVX] != 0.;
         const double e2 = 1. / (eta[0] * eta[0]);
         const double den = 2. * wb[0] * wb[0] - 1.;
-        st[F_HDD] = den * e2;
+        // SC: delta_k eliminated -> H = e2 (I - (2/den) w w').  SCvx: delta_k constant -> plain L'W^-2 L = e2 (I + 2 w w')
+        // on the rows that exist (the mask is applied where the tile is built, sweeps.h buildHTile)
+        st[F_HDD] = scvx ? 1. : den * e2;
         for (int j = 0; j < NV; j++)
-            st[F_HDW + j] = (fm & (1u << j)) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
+            st[F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
         st[F_HC] = e2;
-        st[F_HC + 1] = 2. / den;
+        st[F_HC + 1] = scvx ? -2. : 2. / den;
     }
     if (act & 2u)
     {

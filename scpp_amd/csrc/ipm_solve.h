@@ -158,7 +158,7 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
             st[F_DW + j] = d;
             acc += st[F_HDW + j] * d;
         }
-        st[F_DDL] = (st[F_BXD] - acc) / st[F_HDD];
+        st[F_DDL] = (c.ip[IP_SCVX] != 0.) ? 0. : (st[F_BXD] - acc) / st[F_HDD];
     }
     if (k < K - 1)
     {
@@ -857,7 +857,7 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
             }
             LTmul(ip, fm, zv, uh, gw, &gdl);
         }
-        const double rxd = it.wtrx - gdl;
+        const double rxd = (ip[IP_SCVX] != 0.) ? 0. : it.wtrx - gdl; // SCvx: delta_k is not a variable
         // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
         // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
         double acc[NV], u1[3], resv[NL];
@@ -981,8 +981,18 @@ PHASE_FN void phScalings(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
         bad |= coneScaling<C5, 4>(st, 4);
         bad |= coneScaling<C6, 3>(st, 5);
     }
+#ifdef SCPP_HIP_EMU
+    if (bad && getenv("SCPP_EMU_DEBUG"))
+        printf("[emu] lane %d stage cone scaling failed\n", v.k);
+#endif
     if (!cone::nt_scaling(g.sc3, g.zc3, 3, g.seta, g.sw))
+    {
         bad = 1;
+#ifdef SCPP_HIP_EMU
+        if (c.lane == 0 && getenv("SCPP_EMU_DEBUG"))
+            printf("[emu] sigma cone scaling failed: s=(%g %g %g) z=(%g %g %g)\n", g.sc3[0], g.sc3[1], g.sc3[2], g.zc3[0], g.zc3[1], g.zc3[2]);
+#endif
+    }
     bad = wave_or(bad);
     if (!bad)
     {
@@ -1249,7 +1259,13 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
             g.schur = g.hsig - bs;
         }
         if (!(g.schur > 0.))
+        {
             it.bad = 1;
+#ifdef SCPP_HIP_EMU
+            if (c.lane == 0 && getenv("SCPP_EMU_DEBUG"))
+                printf("[emu] schur %g hsig %g\n", g.schur, g.hsig);
+#endif
+        }
         g.dsig = (it.bts - cv) / g.schur;
         g.ddsg = (it.b.ds - g.Hsd * g.dsig) / g.Hdd;
     }
@@ -1271,7 +1287,7 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
                 dw[j] -= bcw[j] * g.dsig;
                 acc += hdw[j] * dw[j];
             }
-            const double ddl = (bxd - acc) / hdd;
+            const double ddl = (ip[IP_SCVX] != 0.) ? 0. : (bxd - acc) / hdd;
             stf<NV>(st, F_DW, dw);
             st[F_DDL] = ddl;
             Lmul(ip, act, dw, ddl, uh, Ld);
@@ -1519,6 +1535,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     PROF_ADD(0, tp0, tp1);
 
     int status = -1, iter = 0;
+    bool inacc_ok = false;
     for (iter = 0;; iter++)
     {
         PROF_T(tr0);
@@ -1539,9 +1556,12 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 status = 0;
                 break;
             }
+            // ECOS's reduced-accuracy exit (feastol_inacc 1e-4, abstol_inacc / reltol_inacc 5e-5): an iteration limit or a
+            // numerical breakdown at an iterate that already meets the relaxed tolerances returns that iterate
+            inacc_ok = pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
             if (iter >= opt.maxit)
             {
-                status = -1;
+                status = inacc_ok ? 0 : -1;
                 break;
             }
         }
@@ -1550,7 +1570,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         PROF_ADD(2, tr1, tr2);
         if (it.bad)
         {
-            status = -2;
+            status = inacc_ok ? 0 : -2;
             break;
         }
         for (int pass = 0; pass < 2; pass++)
@@ -1591,7 +1611,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         }
         if (it.bad)
         {
-            status = -2;
+            status = inacc_ok ? 0 : -2;
             break;
         }
         PROF_T(tu0);
@@ -1641,8 +1661,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 Uo[j] = st[F_W + 13 + j];
             Uo[3] = 0.;
         }
-        if (lane == 0)
-            a.sigma[inst] = sig;
+        if (lane == 0 && c.ip[IP_SCVX] == 0.)
+            a.sigma[inst] = sig; // SCvx: fixed final time (the sigma block is a decoupled dummy)
     }
     if (lane == 0)
     {

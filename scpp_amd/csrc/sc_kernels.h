@@ -81,6 +81,8 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
     ip[IP_MSCALE] = m_scale;
     ip[IP_RSCALE] = r_scale;
     ip[IP_FINALTIME] = mp.final_time;
+    ip[IP_SCVX] = 0.;
+    ip[IP_TR] = 0.;
 
     double *X = b.X + i * K * 14, *U = b.U + i * K * 4;
     if (!warm)

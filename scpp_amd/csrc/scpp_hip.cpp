@@ -10,6 +10,7 @@
 #include "ipm_solve.h"
 #include "model_rocketquat.h"
 #include "sc_kernels.h"
+#include "scvx_kernels.h"
 
 using namespace scpp;
 
@@ -33,6 +34,11 @@ struct scpp_hip_ctx
     double *x_init = nullptr, *ip = nullptr, *uhat = nullptr, *wtrx = nullptr, *ws = nullptr, *dbg = nullptr;
     int *active = nullptr, *converged = nullptr, *sc_iters = nullptr, *ipm_iters = nullptr, *status = nullptr, *counter = nullptr;
     double *norm1_nu = nullptr, *sum_delta = nullptr, *delta_sigma = nullptr;
+    // SCvx state (allocated on first scvx_setup)
+    double *vx_Xold = nullptr, *vx_Uold = nullptr, *vx_tr = nullptr, *vx_last = nullptr, *vx_cost = nullptr, *vx_info = nullptr;
+    int *vx_has_last = nullptr, *vx_needs_disc = nullptr, *vx_solves = nullptr;
+    scpp_scvx_opts scvx{};
+    bool scvx_ready = false;
     // simulate scratch
     double *sim_dt = nullptr, *sim_u0 = nullptr, *sim_u1 = nullptr, *sim_x = nullptr;
     scpp_sc_opts sc{};
@@ -167,7 +173,7 @@ SCBuffers scBuffers(scpp_hip_ctx *c)
     return b;
 }
 
-int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst)
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = false)
 {
     ipm::KernelArgs a;
     a.B = c->B;
@@ -184,7 +190,7 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst)
     a.uhat = c->uhat;
     a.ws = c->ws;
     a.wtrx = c->wtrx;
-    a.active = do_sc_update ? c->active : nullptr;
+    a.active = (do_sc_update || masked) ? c->active : nullptr;
     a.converged = c->converged;
     a.sc_iters = c->sc_iters;
     a.ipm_iters = c->ipm_iters;
@@ -313,7 +319,8 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->X, c->U, c->sigma, c->par, c->A, c->Bm, c->C, c->S, c->Z, c->x_init, c->ip, c->uhat, c->wtrx, c->ws,
                     c->dbg, c->active, c->converged, c->sc_iters, c->ipm_iters, c->status, c->counter, c->norm1_nu,
-                    c->sum_delta, c->delta_sigma, c->sim_dt, c->sim_u0, c->sim_u1, c->sim_x};
+                    c->sum_delta, c->delta_sigma, c->sim_dt, c->sim_u0, c->sim_u1, c->sim_x, c->vx_Xold, c->vx_Uold, c->vx_tr,
+                    c->vx_last, c->vx_cost, c->vx_info, c->vx_has_last, c->vx_needs_disc, c->vx_solves};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -514,6 +521,144 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
             return rc;
     }
     return scpp_hip_sc_finish(c, n_converged);
+}
+
+// ---------------------------------------------------------------- SCvx
+namespace
+{
+SCvxBuffers scvxBuffers(scpp_hip_ctx *c)
+{
+    SCvxBuffers v;
+    v.Xold = c->vx_Xold;
+    v.Uold = c->vx_Uold;
+    v.tr = c->vx_tr;
+    v.last_cost = c->vx_last;
+    v.cost = c->vx_cost;
+    v.info = c->vx_info;
+    v.has_last = c->vx_has_last;
+    v.needs_disc = c->vx_needs_disc;
+    v.solves = c->vx_solves;
+    return v;
+}
+} // namespace
+
+int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                        int B, int warm_start)
+{
+    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKETQUAT)
+        return SCPP_E_UNSUPPORTED;
+    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
+        return SCPP_E_UNSUPPORTED;
+    if (warm_start && (!c->scvx_ready || B != c->B))
+        return SCPP_E_STATE;
+    if (!c->vx_tr)
+    {
+        const size_t Bm = size_t(c->Bmax), K = size_t(c->K);
+        int rc = 0;
+        rc |= devAlloc(&c->vx_Xold, Bm * K * 14);
+        rc |= devAlloc(&c->vx_Uold, Bm * K * 4);
+        rc |= devAlloc(&c->vx_tr, Bm);
+        rc |= devAlloc(&c->vx_last, Bm);
+        rc |= devAlloc(&c->vx_cost, Bm);
+        rc |= devAlloc(&c->vx_info, Bm * 4);
+        rc |= devAlloc(&c->vx_has_last, Bm);
+        rc |= devAlloc(&c->vx_needs_disc, Bm);
+        rc |= devAlloc(&c->vx_solves, Bm);
+        if (rc)
+            return SCPP_E_HIP;
+    }
+    c->B = B;
+    c->mp = *mp;
+    c->scvx = *so;
+    // the trajectory / parameter set-up is the SC one (same model code); SCvx specifics are applied on top
+    scpp_sc_opts sc{};
+    sc.K = so->K;
+    sc.free_final_time = 0;
+    sc.interpolate_input = so->interpolate_input;
+    sc.nondimensionalize = so->nondimensionalize;
+    sc.max_iterations = so->max_iterations;
+    sc.weight_time = 1.;
+    sc.weight_trust_region_time = 1.;
+    sc.weight_trust_region_trajectory = 0.;
+    sc.weight_virtual_control = so->weight_virtual_control;
+    sc.nu_tol = 0.;
+    sc.delta_tol = 0.;
+    c->sc = sc;
+    c->mode = SCPP_MODE_FOH;
+    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * 14 * sizeof(double), c->stream));
+    SCBuffers b = scBuffers(c);
+    const unsigned grid = unsigned((B + 63) / 64);
+    hipLaunchKernelGGL(sc_setup_kernel, dim3(grid), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
+    hipLaunchKernelGGL(scvx_setup_kernel, dim3(grid), dim3(64), 0, c->stream, b, scvxBuffers(c), c->scvx, mp->final_time, warm_start);
+    c->sc_ready = false; // the SC entry points must not be mixed with an SCvx set-up
+    c->scvx_ready = true;
+    c->par_from_ip = true;
+    c->last_active = B;
+    return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
+}
+
+int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
+{
+    if (!c || !c->scvx_ready)
+        return SCPP_E_STATE;
+    SCBuffers b = scBuffers(c);
+    SCvxBuffers v = scvxBuffers(c);
+    const size_t K = size_t(c->K), B = size_t(c->B);
+    int n_active = c->last_active;
+    // every round = one sub-problem solve of every active instance; instances whose previous candidate was rejected
+    // re-solve on their old discretisation (needs_disc = 0), the others start a new SCvx iteration
+    const long max_rounds = long(c->scvx.max_iterations) * 64;
+    for (long round = 0; round < max_rounds && n_active > 0; round++)
+    {
+        int rc = discretizeDispatch(c, SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, n_active);
+        if (rc)
+            return rc;
+        CHECK_HIP(hipMemcpyAsync(c->vx_Xold, c->X, B * K * 14 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        CHECK_HIP(hipMemcpyAsync(c->vx_Uold, c->U, B * K * 4 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        rc = launchIpm(c, 0, n_active, true);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL((scvx_cost_kernel<RocketQuatModel>), dim3(unsigned(c->B)), dim3(WAVE), 0, c->stream, b, v,
+                           c->scvx.interpolate_input);
+        hipLaunchKernelGGL(scvx_update_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b, v, c->scvx);
+        rc = countActive(c, &n_active);
+        if (rc)
+            return rc;
+        c->last_active = n_active;
+    }
+    if (c->scvx.nondimensionalize)
+        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (n_converged)
+    {
+        std::vector<int> conv(c->B);
+        CHECK_HIP(hipMemcpy(conv.data(), c->converged, size_t(c->B) * sizeof(int), hipMemcpyDeviceToHost));
+        int n = 0;
+        for (int x : conv)
+            n += x;
+        *n_converged = n;
+    }
+    return SCPP_OK;
+}
+
+int scpp_hip_scvx_download_state(scpp_hip_ctx *c, double *trust_region, double *nonlinear_cost, int32_t *solves, double *last_decision)
+{
+    if (!c || !c->scvx_ready)
+        return SCPP_E_STATE;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    const size_t B = size_t(c->B);
+    if (trust_region)
+        CHECK_HIP(hipMemcpy(trust_region, c->vx_tr, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (nonlinear_cost)
+        CHECK_HIP(hipMemcpy(nonlinear_cost, c->vx_last, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (solves)
+        CHECK_HIP(hipMemcpy(solves, c->vx_solves, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (last_decision)
+        CHECK_HIP(hipMemcpy(last_decision, c->vx_info, B * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
 }
 
 int scpp_hip_socp_solve(scpp_hip_ctx *c)

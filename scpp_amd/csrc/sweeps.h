@@ -176,7 +176,7 @@ __device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
     return h;
 }
 // H_k (16x16, delta_k eliminated, fixed variables -> identity rows) as a D-layout tile
-__device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane)
+__device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane, bool scvx)
 {
     const int g = lane >> 4, i = lane & 15;
     const unsigned fm = fixedMask(k, K);
@@ -186,6 +186,8 @@ __device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane)
     {
         const int row = g + 4 * r;
         double v = h.e2 * ((row == i ? 1. : 0.) - h.cc * h.wrow[r] * h.wcol);
+        if (scvx && (row < 13 || i < 13)) // SCvx: the trust cone has no state rows
+            v = 0.;
         if (hsIndex(row, i) >= 0)
             v += h.hs[r];
         if ((fm & (1u << row)) || (fm & (1u << i)))
@@ -314,6 +316,10 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
     const int g = lane >> 4, i = lane & 15;
+    const bool scvx = c.ip[IP_SCVX] != 0.;
+    // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
+    // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
+    const double dual_reg = scvx ? 1e-9 : 0.;
     Tile Z = tileZero(), G = loadRhsW(c, sp, 0, lane);
     FactorIn cur = loadFactorIn(c, sp, 0, lane);
     for (int k = 0; k < K; k++)
@@ -323,10 +329,16 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
             nxt = loadFactorIn(c, sp, k + 1, lane); // prefetch: overlaps the elimination chain below
         double *fk = c.fac + size_t(k) * FACREC;
         double *svk = c.sv + size_t(k) * SVREC;
-        Tile Phi = buildHTile(cur.h, k, K, lane);
+        Tile Phi = buildHTile(cur.h, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
         const Tile Li = invCholFactor<NV>(Phi, sh, lane);
+#ifdef SCPP_HIP_EMU
+        if (getenv("SCPP_EMU_DEBUG"))
+            for (int r = 0; r < 4; r++)
+                if (!(Li.v[r] == Li.v[r]) || fabs(Li.v[r]) > 1e150 || !(Phi.v[r] == Phi.v[r]))
+                    printf("[emu] stage %d lane %d r %d Li %g Phi %g\n", k, lane, r, Li.v[r], Phi.v[r]);
+#endif
         storeTri<NV>(fk + FAC_LI, lane, Li);
         const Tile Lit = transposeTile(Li, sh, lane);
         const Tile a = mm(Lit, G);
@@ -342,9 +354,15 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
         {
             const int row = g + 4 * r;
             if (row == i)
-                Th.v[r] = (row < NL) ? Th.v[r] + cur.einv : 1.;
+                Th.v[r] = (row < NL) ? Th.v[r] + cur.einv + dual_reg : 1.;
         }
         const Tile Ti = invCholFactor<NL>(Th, sh, lane);
+#ifdef SCPP_HIP_EMU
+        if (getenv("SCPP_EMU_DEBUG"))
+            for (int r = 0; r < 4; r++)
+                if (!(Ti.v[r] == Ti.v[r]) || fabs(Ti.v[r]) > 1e150 || !(Th.v[r] == Th.v[r]))
+                    printf("[emu] stage %d lane %d r %d Ti %g Th %g einv %g\n", k, lane, r, Ti.v[r], Th.v[r], cur.einv);
+#endif
         storeTri<NL>(fk + FAC_TI, lane, Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
         Z = mm(Tit, finishN(cur.n, fmn, lane));

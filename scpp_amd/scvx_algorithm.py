@@ -1,0 +1,57 @@
+"""Batched mirror of the reference's SCvxAlgorithm front end (scpp_core/include/SCvxAlgorithm.hpp:18-48):
+loadParameters -> initialize -> solve(warm_start) -> getSolution, with a batch of initial states.  The iteration
+(sub-problem solve, nonlinear cost, accept / reject / radius update: SCvxAlgorithm.cpp:61-164) runs on the device."""
+import os
+
+import numpy as np
+
+from ._lib import MODEL_ROCKETQUAT, Context, SCvxOpts
+from .parameter_server import ParameterServer
+
+
+def load_scvx_opts(param_folder, K=None, max_iterations=None):
+    """SCvxAlgorithm::loadParameters (SCvxAlgorithm.cpp:22-44)."""
+    ps = ParameterServer(os.path.join(param_folder, "SCvx.info"))
+    o = SCvxOpts()
+    o.K = ps.load_scalar("K", int) if K is None else int(K)
+    o.nondimensionalize = int(ps.load_scalar("nondimensionalize", bool))
+    o.max_iterations = ps.load_scalar("max_iterations", int) if max_iterations is None else int(max_iterations)
+    o.alpha = ps.load_scalar("alpha")
+    o.beta = ps.load_scalar("beta")
+    o.rho_0 = ps.load_scalar("rho_0")
+    o.rho_1 = ps.load_scalar("rho_1")
+    o.rho_2 = ps.load_scalar("rho_2")
+    o.change_threshold = ps.load_scalar("change_threshold")
+    o.weight_virtual_control = ps.load_scalar("weight_virtual_control")
+    o.trust_region = ps.load_scalar("trust_region")
+    o.interpolate_input = int(ps.load_scalar("interpolate_input", bool))
+    return o
+
+
+class SCvxAlgorithm:
+    def __init__(self, model, K=None, batch_max=1, device=0, library=None, max_iterations=None):
+        self.model = model
+        self._max_iterations = max_iterations
+        self.opts = load_scvx_opts(model.getParameterFolder(), K, max_iterations)
+        self.batch_max, self.device, self.library = batch_max, device, library
+        self.ctx = None
+
+    def initialize(self):
+        """SCvxAlgorithm::initialize (SCvxAlgorithm.cpp:46-59): allocates the device context."""
+        self.ctx = Context(MODEL_ROCKETQUAT, self.opts.K, self.batch_max, self.device, self.library)
+        return self
+
+    def solve(self, x_init=None, warm_start=False):
+        """SCvxAlgorithm::solve for every row of x_init [B][14] (dimensional). Returns #converged."""
+        if x_init is None:
+            x_init = self.model.x_init[None, :]
+        x_init = np.atleast_2d(np.asarray(x_init, dtype=np.float64))
+        if not warm_start:
+            self.opts = load_scvx_opts(self.model.getParameterFolder(), self.opts.K, self._max_iterations)
+        self.ctx.scvx_setup(self.model.p, self.opts, x_init, warm_start=warm_start)
+        return self.ctx.scvx_solve()
+
+    def getSolution(self):
+        out = self.ctx.download()
+        out.update(self.ctx.scvx_state())
+        return out

@@ -83,3 +83,32 @@ def test_emu_sc_sim_matches_oracle(oracle, model, emu_lib):
         assert np.abs(o["X_sim"] - r["X_sim"][b]).max() <= 1e-9 * np.abs(o["X_sim"]).max()
         assert np.abs(o["U_sim"] - r["U_sim"][b]).max() <= 1e-9 * np.abs(o["U_sim"]).max()
         assert np.allclose(o["t_plan"], r["t_plan"][b], rtol=1e-10)
+
+
+def test_emu_scvx_matches_oracle(oracle, model, emu_lib):
+    """SCvx mode end to end (sub-problem in SCvx form, nonlinear cost, accept / reject / radius update on the device)
+    against oracle/scvx.hpp with the structured twin."""
+    K, B, maxit = 10, 3, 8
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    x0 = model.randomized_initial_states(B)
+    alg.solve(x0)
+    out = alg.getSolution()
+    compared = 0
+    for b in range(B):
+        s = oracle.SCvx(K=K); s.randomize(20260927, b); s.set_solver(1); s.set_max_iterations(maxit)
+        rc = s.solve()
+        m, info = s.meta(), s.info()
+        if rc != 0:
+            assert out["status"][b] != 0  # the same sub-problem breaks both solvers
+            continue
+        assert out["status"][b] == 0
+        assert out["sc_iters"][b] == m["iterations"] and out["solves"][b] == m["solves"]
+        assert out["converged"][b] == m["converged"]
+        assert abs(out["trust_region"][b] - info[-1][5]) <= 1e-12 * info[-1][5]
+        assert abs(out["nonlinear_cost"][b] - info[-1][1]) <= 1e-6 * max(1.0, abs(info[-1][1]))
+        X, U, t = s.iterate(-1)
+        assert np.abs(out["X"][b] - X).max() <= 1e-6 * np.abs(X).max()
+        assert np.abs(out["U"][b] - U).max() <= 1e-4 * np.abs(U).max()
+        assert out["sigma"][b] == t  # fixed final time
+        compared += 1
+    assert compared >= 2

@@ -257,3 +257,26 @@ def test_edge_horizons_on_gpu(oracle, model, hip_lib, K):
         checked += 1
     assert checked >= 3
     a.ctx.close()
+
+
+def test_scvx_mode_matches_oracle(oracle, model, hip_lib):
+    """SCvx variant on the device (scpp_hip_scvx_setup / scvx_solve): same accept / reject sequence, radius, iteration
+    and solve counts and final trajectory as oracle/scvx.hpp (structured twin) on the shipped K = 50 configuration."""
+    B = 6
+    a = scpp_amd.SCvxAlgorithm(model, batch_max=8, library=hip_lib).initialize()
+    x0 = model.randomized_initial_states(B)
+    nconv = a.solve(x0)
+    out = a.getSolution()
+    assert (out["status"] == 0).all()
+    assert nconv == int(out["converged"].sum())
+    for b in range(B):
+        s = oracle.SCvx(K=50); s.randomize(20260927, b); s.set_solver(1)
+        assert s.solve() == 0
+        m, info = s.meta(), s.info()
+        assert out["sc_iters"][b] == m["iterations"] and out["solves"][b] == m["solves"]
+        assert out["converged"][b] == m["converged"]
+        assert abs(out["trust_region"][b] - info[-1][5]) <= 1e-12 * info[-1][5]
+        X, U, t = s.iterate(-1)
+        assert _rel(out["X"][b], X) < 1e-6 and _rel(out["U"][b], U) < 1e-4
+        assert out["sigma"][b] == t
+    a.ctx.close()
