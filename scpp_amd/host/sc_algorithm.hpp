@@ -210,6 +210,126 @@ private:
     double scale_m = 1., scale_r = 1.;
 };
 
+// SCvxAlgorithm (scpp_core/include/SCvxAlgorithm.hpp:18-48, src/SCvxAlgorithm.cpp:14-260): same shape as SCAlgorithm;
+// fixed final time, hard input trust region with rho-ratio radius update.  The whole iteration runs on the device
+// (scpp_hip_scvx_setup / scpp_hip_scvx_solve).
+struct scvx_result_t : batch_result_t
+{
+    std::vector<double> trust_region, nonlinear_cost;
+    std::vector<int32_t> solves;
+};
+
+class SCvxAlgorithm
+{
+public:
+    explicit SCvxAlgorithm(Model::ptr_t model_, int batch_max_ = 1, int device_ = 0, int K_override_ = 0)
+        : model(std::move(model_)), batch_max(batch_max_), device(device_), K_override(K_override_) {}
+    ~SCvxAlgorithm()
+    {
+        if (ctx)
+            scpp_hip_destroy(ctx);
+    }
+    SCvxAlgorithm(const SCvxAlgorithm &) = delete;
+    SCvxAlgorithm &operator=(const SCvxAlgorithm &) = delete;
+
+    // SCvxAlgorithm.cpp:22-44
+    void loadParameters()
+    {
+        ParameterServer ps(Model::getParameterFolder() + "/SCvx.info");
+        bool ii, nd;
+        ps.loadScalar("K", opts.K);
+        ps.loadScalar("nondimensionalize", nd);
+        ps.loadScalar("max_iterations", opts.max_iterations);
+        ps.loadScalar("alpha", opts.alpha);
+        ps.loadScalar("beta", opts.beta);
+        ps.loadScalar("rho_0", opts.rho_0);
+        ps.loadScalar("rho_1", opts.rho_1);
+        ps.loadScalar("rho_2", opts.rho_2);
+        ps.loadScalar("change_threshold", opts.change_threshold);
+        ps.loadScalar("weight_virtual_control", opts.weight_virtual_control);
+        ps.loadScalar("trust_region", opts.trust_region);
+        ps.loadScalar("interpolate_input", ii);
+        opts.interpolate_input = ii;
+        opts.nondimensionalize = nd;
+        if (K_override > 0)
+            opts.K = K_override;
+    }
+    void initialize()
+    {
+        loadParameters();
+        const int rc = scpp_hip_create(&ctx, device, SCPP_MODEL_ROCKETQUAT, opts.K, batch_max, 0);
+        if (rc != SCPP_OK)
+            throw std::runtime_error("scpp_hip_create failed with code " + std::to_string(rc));
+    }
+    void solve(bool warm_start = false)
+    {
+        scvx_result_t r;
+        solveBatch({model->p.x_init}, r, warm_start);
+        td = r.td[0];
+        converged = r.converged[0] != 0;
+        iterations = r.sc_iterations[0];
+    }
+    void getSolution(trajectory_data_t &trajectory) const { trajectory = td; }
+    bool hasConverged() const { return converged; }
+    int getIterations() const { return iterations; }
+
+    void solveBatch(const std::vector<Model::state_vector_t> &x_inits, scvx_result_t &out, bool warm_start = false)
+    {
+        if (!ctx)
+            throw std::runtime_error("SCvxAlgorithm::initialize() has not been called");
+        if (!warm_start)
+            loadParameters(); // cold start re-reads SCvx.info (:179)
+        const int B = int(x_inits.size());
+        int rc = scpp_hip_scvx_setup(ctx, &model->p.abi, &opts, &x_inits[0][0], B, warm_start ? 1 : 0);
+        int nconv = 0;
+        if (rc == SCPP_OK)
+            rc = scpp_hip_scvx_solve(ctx, &nconv);
+        if (rc != SCPP_OK)
+            throw std::runtime_error("scpp_hip_scvx solve failed with code " + std::to_string(rc));
+        const size_t K = size_t(opts.K), nB = size_t(B);
+        std::vector<double> X(nB * K * 14), U(nB * K * 4), sigma(nB, 0.);
+        out.sc_iterations.assign(nB, 0);
+        out.converged.assign(nB, 0);
+        out.status.assign(nB, 0);
+        out.ipm_iterations.assign(nB, 0);
+        out.norm1_nu.assign(nB, 0.);
+        out.sum_delta.assign(nB, 0.);
+        out.trust_region.assign(nB, 0.);
+        out.nonlinear_cost.assign(nB, 0.);
+        out.solves.assign(nB, 0);
+        rc = scpp_hip_download(ctx, X.data(), U.data(), sigma.data(), out.sc_iterations.data(), out.norm1_nu.data(),
+                               out.converged.data(), out.status.data(), out.ipm_iterations.data(), out.sum_delta.data());
+        if (rc == SCPP_OK)
+            rc = scpp_hip_scvx_download_state(ctx, out.trust_region.data(), out.nonlinear_cost.data(), out.solves.data(), nullptr);
+        if (rc != SCPP_OK)
+            throw std::runtime_error("scpp_hip download failed with code " + std::to_string(rc));
+        out.td.resize(nB);
+        for (size_t b = 0; b < nB; b++)
+        {
+            trajectory_data_t &t = out.td[b];
+            t.initialize(K, true);
+            for (size_t k = 0; k < K; k++)
+            {
+                for (size_t j = 0; j < 14; j++)
+                    t.X[k][j] = X[(b * K + k) * 14 + j];
+                for (size_t j = 0; j < 4; j++)
+                    t.U[k][j] = U[(b * K + k) * 4 + j];
+            }
+            t.t = sigma[b];
+        }
+    }
+
+    scpp_scvx_opts opts{};
+    Model::ptr_t model;
+
+private:
+    int batch_max, device, K_override;
+    scpp_hip_ctx *ctx = nullptr;
+    trajectory_data_t td;
+    bool converged = false;
+    int iterations = 0;
+};
+
 // commonFunctions.cpp:6-19
 inline Model::input_vector_t interpolatedInput(const std::vector<Model::input_vector_t> &U, double t, double total_time,
                                                bool first_order_hold)

@@ -3,6 +3,7 @@
 //                       <out>/output/RocketQuat/SC/<time>/<iter>/{X,U,t}.txt   (what the reference does)
 //   --batch B [--seed S]: B randomised initial states solved at once (the workload of BASELINE configs 1/2);
 //                       instance 0 is written to the same tree under iteration index 0, a summary goes to stdout
+//   --scvx            : run the SCvx variant (SCvxAlgorithm, SCvx.info) instead of SCAlgorithm; output under .../SCvx/
 //   --config DIR --out DIR --K n --device d
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@ int main(int argc, char **argv)
     std::string config = "../scpp_amd/config", out = "..";
     int batch = 0, K = 0, device = 0;
     unsigned long long seed = 20260927ull;
+    bool scvx = false;
     for (int i = 1; i < argc; i++)
     {
         auto next = [&]() -> const char * {
@@ -28,7 +30,9 @@ int main(int argc, char **argv)
             }
             return argv[++i];
         };
-        if (!std::strcmp(argv[i], "--batch"))
+        if (!std::strcmp(argv[i], "--scvx"))
+            scvx = true;
+        else if (!std::strcmp(argv[i], "--batch"))
             batch = std::atoi(next());
         else if (!std::strcmp(argv[i], "--seed"))
             seed = std::strtoull(next(), nullptr, 10);
@@ -52,10 +56,46 @@ int main(int argc, char **argv)
         auto model = std::make_shared<Model>();
         model->loadParameters();
 
+        std::vector<trajectory_data_t> all_td;
+        if (scvx)
+        {
+            scpp::SCvxAlgorithm vsolver(model, batch > 0 ? batch : 1, device, K);
+            vsolver.initialize();
+            std::vector<Model::state_vector_t> x_inits;
+            if (batch <= 0)
+                x_inits.push_back(model->p.x_init);
+            for (int b = 0; b < batch; b++)
+            {
+                Model inst = *model;
+                inst.p.randomizeInitialState(seed, uint64_t(b));
+                x_inits.push_back(inst.p.x_init);
+            }
+            scpp::scvx_result_t r;
+            vsolver.solveBatch(x_inits, r);
+            long conv = 0, fails = 0, iters = 0, solves = 0;
+            for (size_t b = 0; b < x_inits.size(); b++)
+            {
+                conv += r.converged[b];
+                fails += r.status[b] != 0;
+                iters += r.sc_iterations[b];
+                solves += r.solves[b];
+            }
+            const double n = double(x_inits.size());
+            std::printf("SCvx batch %zu: converged %ld, solver failures %ld, mean iterations %.2f, mean sub-problem solves %.2f\n",
+                        x_inits.size(), conv, fails, double(iters) / n, double(solves) / n);
+            all_td.push_back(r.td[0]);
+            const fs::path outputPath = fs::path(out) / "output" / Model::getModelName() / "SCvx" / scpp::getTimeString() / "0";
+            scpp::makeDir(outputPath);
+            scpp::writeRows(outputPath / "X.txt", all_td[0].X);
+            scpp::writeRows(outputPath / "U.txt", all_td[0].U);
+            std::ofstream f(outputPath / "t.txt");
+            f << all_td[0].t;
+            std::printf("output: %s\n", outputPath.string().c_str());
+            return 0;
+        }
         scpp::SCAlgorithm solver(model, batch > 0 ? batch : 1, device, K);
         solver.initialize();
 
-        std::vector<trajectory_data_t> all_td;
         if (batch <= 0)
         {
             solver.solve();

@@ -86,3 +86,19 @@ def test_host_executables_on_gpu(oracle, tmp_path):
     assert "batch 512:" in out and "solver failures 0" in out
     out = subprocess.check_output([os.path.join(HOST, "sc_sim"), "--batch", "64", "--steps", "3", "--config", CONFIG, "--out", str(tmp_path)], text=True)
     assert "64 closed loops, 192 solves" in out
+
+
+def test_sc_oneshot_scvx_mode(oracle, host_emu, tmp_path):
+    """`sc_oneshot --scvx`: the C++ SCvxAlgorithm front end over scpp_hip_scvx_*, against the oracle's SCvx run."""
+    K = 10
+    out = subprocess.check_output([os.path.join(host_emu, "sc_oneshot_emu"), "--scvx", "--K", str(K), "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    s = oracle.SCvx(K=K); s.set_solver(1)
+    assert s.solve() == 0
+    m = s.meta()
+    assert f"converged {m['converged']}, solver failures 0, mean iterations {m['iterations']:.2f}, mean sub-problem solves {m['solves']:.2f}" in out
+    run = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SCvx" / "*" / "0"))[0]
+    X, U, t = s.iterate(-1)
+    Xf, Uf = _read(os.path.join(run, "X.txt")), _read(os.path.join(run, "U.txt"))
+    assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
+    assert np.allclose(Uf, U, rtol=2e-4, atol=2e-4 * np.abs(U).max())
+    assert abs(float(open(os.path.join(run, "t.txt")).read()) - t) <= 1e-5 * t
