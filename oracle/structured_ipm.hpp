@@ -1112,6 +1112,18 @@ class RQStructuredSocp
         std::vector<double> lamS(size_t(K) * NS), dsS(size_t(K) * NS), dzS(size_t(K) * NS); // scaled quantities
         double lamC[3], dsC[3], dzC[3];
 
+        // ECOS-style safeguarding: the last iterate that met the reduced tolerances is kept; if the residuals then
+        // explode (pres > 500 x previous, negative gap, NaN) that iterate is restored and returned
+        std::vector<double> bk_w, bk_dl;
+        double bk_sig = 0., bk_dsg = 0., bk_n1 = 0., pres_prev = 0.;
+        bool bk_valid = false;
+        auto restoreBest = [&]() {
+            w = bk_w;
+            dl = bk_dl;
+            sig = bk_sig;
+            dsg = bk_dsg;
+            n1 = bk_n1;
+        };
         for (int iter = 0;; iter++)
         {
             // ---------- residuals ----------
@@ -1228,14 +1240,30 @@ class RQStructuredSocp
             if (opt.verbose)
                 std::printf("%3d  pcost %+.8e gap %.2e pres %.2e dres %.2e mu %.2e sigma %.6f n1 %.3e\n", iter, pcost, gap,
                             pres, dres, mu, sig, n1);
-            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap))
-                return -2;
+            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) ||
+                (bk_valid && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
+            {
+                if (!bk_valid)
+                    return -2;
+                restoreBest();
+                return 0;
+            }
+            pres_prev = pres;
             if (pres < opt.feastol && dres < opt.feastol && (gap < opt.abstol || relgap < opt.reltol))
                 return 0;
             // ECOS's reduced-accuracy exit (feastol_inacc 1e-4, abstol_inacc / reltol_inacc 5e-5): when the iteration
             // limit or a numerical breakdown is hit at an iterate that already satisfies the relaxed tolerances, ECOS
             // returns it as "close to optimal" instead of failing
             const bool inacc_ok = pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
+            if (inacc_ok)
+            {
+                bk_w = w;
+                bk_dl = dl;
+                bk_sig = sig;
+                bk_dsg = dsg;
+                bk_n1 = n1;
+                bk_valid = true;
+            }
             if (iter >= opt.maxit)
                 return inacc_ok ? 0 : -1;
 
@@ -1368,6 +1396,17 @@ class RQStructuredSocp
                 b.n1 = -om * rxn1;
                 b.rhs3 = -om * rz3 - ds3v / z3;
                 kktSolve(b);
+                {
+                    // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be
+                    // applied: same reduced-accuracy exit as for the other numerical failures
+                    double chk = dsig * 0. + ddsg * 0. + dn1 * 0.;
+                    for (double v : dw)
+                        chk += v * 0.;
+                    for (double v : dlam)
+                        chk += v * 0.;
+                    if (!(chk == 0.))
+                        return inacc_ok ? 0 : -2;
+                }
                 // ---------- dz = -W^-2 L dx + t ;  ds = -rz' + L dx ----------
                 double ainv = 0.;
                 for (int k = 0; k < K; k++)

@@ -94,7 +94,8 @@ enum StageField
     F_BXD = 521,
     F_HS = 522,   // [27] small Hessian blocks of the non-trust-region cones
     F_HC = 549,   // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
-    STREC = 552
+    F_WBK = 552,  // [17] W and delta of the last iterate that met the reduced tolerances (ECOS-style best iterate)
+    STREC = 569
 };
 // ---- segment record: 33 fields of 14 doubles ----
 enum SegField

@@ -466,7 +466,9 @@ struct Iter
     double sigma_c, alpha, tzs, tzc[3];
     Rhs b;
     double bts;
-    int D, bad;
+    // ECOS-style safeguarding: scalars of the last iterate that met the reduced tolerances (its W / delta are in F_WBK)
+    double bk_sig, bk_dsg, bk_n1, pres_prev;
+    int D, bad, bk_valid;
 };
 
 template <class T>
@@ -956,6 +958,24 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
         const double d3 = it.resx0 + ny_ + nz_ > 1. ? it.resx0 + ny_ + nz_ : 1.;
         it.dres = sqrt(nrx) / d3;
     }
+    {
+        // keep the iterate if it already meets ECOS's reduced tolerances (returned if the path breaks down later)
+        const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
+        const bool inacc = it.pres < 1e-4 && it.dres < 1e-4 && (it.gap < 5e-5 || it.gap / apc < 5e-5);
+        if (inacc)
+        {
+            if (v.vst)
+            {
+                double xw[NV + 1];
+                ldf<NV + 1>(st, F_W, xw); // W[16], delta
+                stf<NV + 1>(st, F_WBK, xw);
+            }
+            it.bk_sig = g.sig;
+            it.bk_dsg = g.dsg;
+            it.bk_n1 = g.n1;
+            it.bk_valid = 1;
+        }
+    }
     storePriv(ip_, it);
     WAVE_SYNC();
 }
@@ -1269,7 +1289,7 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
         g.dsig = (it.bts - cv) / g.schur;
         g.ddsg = (it.b.ds - g.Hsd * g.dsig) / g.Hdd;
     }
-    double ainv = 0.;
+    double ainv = 0., finite_chk = g.dsig * 0. + g.ddsg * 0.;
     if (v.vst)
     {
         double Ld[NS];
@@ -1286,6 +1306,7 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
             {
                 dw[j] -= bcw[j] * g.dsig;
                 acc += hdw[j] * dw[j];
+                finite_chk += dw[j] * 0.; // NaN / Inf -> NaN
             }
             const double ddl = (ip[IP_SCVX] != 0.) ? 0. : (bxd - acc) / hdd;
             stf<NV>(st, F_DW, dw);
@@ -1341,6 +1362,11 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
         dirSegChunk<10, 4>(sg, om, g.dsig, ainv, sumdnb);
     }
     sumdnb = wave_sum(sumdnb);
+    // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
+    // (sumdnb carries dlam through dnu / dnub)
+    finite_chk = wave_sum(finite_chk + sumdnb * 0.);
+    if (!(finite_chk == 0.))
+        it.bad = 1;
     g.dn1 = sumdnb - (g.s3 / g.z3) * g.dz3 - it.b.rhs3;
     g.dzs = -(g.zs / g.ss) * g.dsig + it.tzs;
     g.dss = -om * it.rzs + g.dsig;
@@ -1513,6 +1539,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     it.gamma = opt.gamma;
     it.sigma_c = 0.;
     it.alpha = 1.;
+    it.bk_valid = 0;
+    it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
 
     PROF_T(tp0);
     phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp);
@@ -1535,7 +1563,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     PROF_ADD(0, tp0, tp1);
 
     int status = -1, iter = 0;
-    bool inacc_ok = false;
+    bool inacc_ok = false, bk_prev = false, use_backup = false;
+    double pres_prev = 0.;
     for (iter = 0;; iter++)
     {
         PROF_T(tr0);
@@ -1546,11 +1575,16 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             const double pres = it.pres, dres = it.dres, gap = it.gap;
             const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
             const double relgap = gap / apc;
-            if (!(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300)
+            const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300;
+            // ECOS-style safeguarding: residual explosion after an acceptable iterate -> return that iterate
+            if (nonfinite || (bk_prev && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
             {
-                status = -2;
+                status = bk_prev ? 0 : -2;
+                use_backup = bk_prev;
                 break;
             }
+            pres_prev = pres;
+            bk_prev = it.bk_valid != 0;
             if (pres < opt.feastol && dres < opt.feastol && (gap < opt.abstol || relgap < opt.reltol))
             {
                 status = 0;
@@ -1623,11 +1657,13 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     // =============== outputs: readSolution + SC bookkeeping ===============
     const bool vst = k < K;
     const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0), c.pitch);
+    // W / delta to report: the current iterate, or the restored best one (use_backup)
+    const int fW = use_backup ? int(F_WBK) : int(F_W);
     double sum_delta = 0.;
     if (vst)
-        sum_delta = st[F_DL];
+        sum_delta = st[fW + 16];
     sum_delta = wave_sum(sum_delta);
-    const double n1 = g.n1, sig = g.sig, dsg = g.dsg;
+    const double n1 = use_backup ? it.bk_n1 : g.n1, sig = use_backup ? it.bk_sig : g.sig, dsg = use_backup ? it.bk_dsg : g.dsg;
 #ifdef IPM_PROFILE
     if (a.dbg && lane == 0)
     {
@@ -1655,10 +1691,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         {
             double *Xo = a.X + (size_t(inst) * K + k) * NX, *Uo = a.U + (size_t(inst) * K + k) * NU;
             for (int j = 0; j < 13; j++)
-                Xo[j] = st[F_W + j];
+                Xo[j] = st[fW + j];
             Xo[13] = 0.;
             for (int j = 0; j < 3; j++)
-                Uo[j] = st[F_W + 13 + j];
+                Uo[j] = st[fW + 13 + j];
             Uo[3] = 0.;
         }
         if (lane == 0 && c.ip[IP_SCVX] == 0.)
