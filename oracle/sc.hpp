@@ -6,6 +6,7 @@
 // The sub-problem is re-assembled into standard form every iteration (the reference binds
 // Epigraph `dynpar` pointers into td/dd instead; same numbers).
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <type_traits>
 #include <string>
@@ -253,9 +254,12 @@ class SCAlgorithm
         in.w_trt = weight_trust_region_time;
         in.w_trx = weight_trust_region_trajectory;
         in.w_vc = weight_virtual_control;
-        RQStructuredSocp solver;
-        solver.opt = structured_settings;
-        RQSocpOutput r = solver.solve(in);
+        // sub-problems of consecutive SC iterations are close: the interior-point iteration restarts from the previous
+        // solve's point (structured_ipm.hpp: warm start); ORACLE_WARM=0 forces ECOS-style cold starts
+        const char *we = std::getenv("ORACLE_WARM");
+        const bool warm = ipm_warm_start && !(we && std::atoi(we) == 0);
+        twin.opt = structured_settings;
+        RQSocpOutput r = twin.solve(in, warm);
         last_structured = r;
         if (r.status != 0)
         {
@@ -279,6 +283,8 @@ class SCAlgorithm
         throw std::runtime_error("structured IPM: RocketQuat only");
     }
     RQSocpOutput last_structured;
+    RQStructuredSocp twin;
+    bool ipm_warm_start = true;
 
     // SCAlgorithm.cpp:66-132
     bool iterate()
@@ -344,6 +350,7 @@ class SCAlgorithm
         {
             loadParameters();
             model->getInitializedTrajectory(td);
+            twin.have_prev = false; // cold SC solve: cold interior-point start
         }
         model->getNewModelParameters(td); // updateModelParameters()
         size_t iteration = 0;

@@ -271,9 +271,8 @@ class SCvxAlgorithm
         in.w_vc = weight_virtual_control;
         in.scvx = true;
         in.trust_region = trust_region;
-        RQStructuredSocp solver;
-        solver.opt = structured_settings;
-        RQSocpOutput r = solver.solve(in);
+        twin.opt = structured_settings;
+        RQSocpOutput r = twin.solve(in, true); // warm interior-point start from the previous sub-problem (sc.hpp)
         ipm_iters = r.iters;
         exitflag = r.status;
         if (r.status != 0)
@@ -357,6 +356,7 @@ class SCvxAlgorithm
         {
             loadParameters();
             model->getInitializedTrajectory(td);
+            twin.have_prev = false; // cold solve: cold interior-point start
         }
         model->getNewModelParameters(td); // updateModelParameters()
         size_t iteration = 0;
@@ -379,6 +379,7 @@ class SCvxAlgorithm
     }
 
     int last_dims[5] = {0, 0, 0, 0, 0};
+    RQStructuredSocp twin;
 };
 
 } // namespace oracle

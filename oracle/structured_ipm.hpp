@@ -238,12 +238,17 @@ class RQStructuredSocp
     RQSocpSettings opt;
     int last_fail = 0;
 
-    RQSocpOutput solve(const RQSocpInput &in)
+    // warm = true: start the interior-point iteration from the previous solve's primal-dual point (kept in this
+    // object) shifted back into the cone interior, instead of ECOS's cold initialisation
+    RQSocpOutput solve(const RQSocpInput &in, bool warm = false)
     {
         using namespace sipm;
         P = &in;
+        warm_start = warm && have_prev && K == in.K;
+        restored_best = false;
         K = in.K;
-        alloc();
+        if (!warm_start)
+            alloc();
         setupStages();
         RQSocpOutput out;
         out.status = run(out);
@@ -266,8 +271,11 @@ class RQStructuredSocp
         out.sum_delta = 0.;
         for (int k = 0; k < K; k++)
             out.sum_delta += dl[k];
+        have_prev = out.status == 0 && !restored_best;
         return out;
     }
+    bool have_prev = false, warm_start = false, restored_best = false;
+    double warm_theta = 1e-2;
 
   private:
     const RQSocpInput *P = nullptr;
@@ -994,6 +1002,16 @@ class RQStructuredSocp
     {
         using namespace sipm;
         const double wtrx = P->w_trx;
+        if (warm_start)
+        {
+            // primal point and multipliers of the previous solve; slacks re-evaluated on the new data and pushed
+            // theta into the interior, duals likewise
+            evalAllSaff(s, s1, s2, ss, s3, sc3);
+            shiftToCone(s, s1, s2, ss, s3, sc3, warm_theta);
+            shiftToCone(z, z1, z2, zs, z3, zc3, warm_theta);
+        }
+        else
+        {
         // ---------- initialisation (ECOS init with W = I; two solves on one factorisation) ----------
         identityScaling = true;
         setIdentityScalings();
@@ -1067,6 +1085,7 @@ class RQStructuredSocp
             zc3[1] = 0.5 * ddsg;
             zc3[2] = -dsig;
             bring2cone(z, z1, z2, zs, z3, zc3);
+        }
         }
         identityScaling = false;
 
@@ -1246,6 +1265,7 @@ class RQStructuredSocp
                 if (!bk_valid)
                     return -2;
                 restoreBest();
+                restored_best = true; // slacks / duals are those of the broken iterate: no warm start from here
                 return 0;
             }
             pres_prev = pres;
@@ -1558,6 +1578,60 @@ class RQStructuredSocp
         oc[2] = sig - P->sigbar;
     }
 
+    // warm start: v += (theta + max violation) e over the whole product cone
+    void shiftToCone(std::vector<double> &v, std::vector<double> &v1, std::vector<double> &v2, double &vs, double &v3,
+                     double *vc, double theta) const
+    {
+        using namespace sipm;
+        double alpha = 0.;
+        auto lp = [&](double r) {
+            if (-r > alpha)
+                alpha = -r;
+        };
+        auto soc = [&](const double *r, int d) {
+            double nrm = 0.;
+            for (int i = 1; i < d; i++)
+                nrm += r[i] * r[i];
+            lp(r[0] - std::sqrt(nrm));
+        };
+        for (int k = 0; k < K; k++)
+        {
+            for (int c = 0; c < NCONE; c++)
+                if (act[k] & (1u << c))
+                    soc(&v[size_t(k) * NS + cone_off[c]], cone_dim[c]);
+            if (act[k] & 64u)
+                lp(v[size_t(k) * NS + L1]);
+            if (act[k] & 128u)
+                lp(v[size_t(k) * NS + L2]);
+        }
+        for (size_t i = 0; i < v1.size(); i++)
+        {
+            lp(v1[i]);
+            lp(v2[i]);
+        }
+        lp(vs);
+        lp(v3);
+        soc(vc, 3);
+        alpha += theta;
+        for (int k = 0; k < K; k++)
+        {
+            for (int c = 0; c < NCONE; c++)
+                if (act[k] & (1u << c))
+                    v[size_t(k) * NS + cone_off[c]] += alpha;
+            if (act[k] & 64u)
+                v[size_t(k) * NS + L1] += alpha;
+            if (act[k] & 128u)
+                v[size_t(k) * NS + L2] += alpha;
+        }
+        for (size_t i = 0; i < v1.size(); i++)
+        {
+            v1[i] += alpha;
+            v2[i] += alpha;
+        }
+        vs += alpha;
+        v3 += alpha;
+        vc[0] += alpha;
+    }
     // ECOS bring2cone over the whole product cone
     void bring2cone(std::vector<double> &v, std::vector<double> &v1, std::vector<double> &v2, double &vs, double &v3,
                     double *vc) const

@@ -151,9 +151,10 @@ constexpr int LANES = 64;
 __host__ __device__ inline int recPitch(int K) { return (K + 1) & ~1; }
 // field-major copy of the segment dynamics (A 14x14, B 14x4, C 14x4, s, z) for the lane = segment phases
 constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX; // 336
+constexpr int GSAVE = 16; // wave-uniform scalars of the last solve (sigma, delta_sigma, n1 and their slacks / duals): warm start
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
-    return size_t(recPitch(K)) * (STREC + SEGREC + DYNREC) + size_t(K) * (FACREC + SVREC);
+    return size_t(recPitch(K)) * (STREC + SEGREC + DYNREC) + size_t(K) * (FACREC + SVREC) + GSAVE;
 }
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is
@@ -214,6 +215,7 @@ struct Ctx
     double *dy;  // [DYNREC][64]  field-major copy of A,B,C,s,z
     double *fac; // [K][FACREC]
     double *sv;  // [K][SVREC]
+    double *gsave; // [GSAVE]
     const double *A, *B, *C, *S, *Z; // dd of this instance
     const double *ip;                // instance parameters
 };

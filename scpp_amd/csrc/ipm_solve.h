@@ -36,6 +36,7 @@ struct KernelArgs
     double *norm1_nu, *sum_delta, *delta_sigma;
     double nu_tol, delta_tol;
     int max_sc_iterations;
+    int *warm;                   // [B] (may be null) 1: the workspace holds the primal-dual point of a successful previous solve
     int do_sc_update;            // 1: apply readSolution + convergence logic ; 0: plain sub-problem solve
     Settings opt;
     double *dbg;                 // optional [B][8]: pcost, gap, pres, dres, iters, status
@@ -332,6 +333,79 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
 }
 
 
+// warm start: v += (theta + largest violation) e over the whole product cone (oracle/structured_ipm.hpp: shiftToCone)
+__device__ inline void shiftToCone(const Ctx &c, double theta, int f, int g1, int g2, double &vs, double &v3, double *vc)
+{
+    const int k = c.lane, K = c.K;
+    double alpha = 0.;
+    if (k < K)
+    {
+        const unsigned act = activeMask(k, K);
+        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
+        for (int cix = 0; cix < NCONE; cix++)
+            if (act & (1u << cix))
+            {
+                const SV r = v + coneOff(cix);
+                double nrm = 0.;
+                for (int i = 1; i < coneDim(cix); i++)
+                    nrm += r[i] * r[i];
+                const double cres = r[0] - sqrt(nrm);
+                if (-cres > alpha)
+                    alpha = -cres;
+            }
+        if ((act & 64u) && -v[L1] > alpha)
+            alpha = -v[L1];
+        if ((act & 128u) && -v[L2] > alpha)
+            alpha = -v[L2];
+    }
+    if (k < K - 1)
+    {
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
+        for (int i = 0; i < NL; i++)
+        {
+            const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
+            if (-a > alpha)
+                alpha = -a;
+            if (-b > alpha)
+                alpha = -b;
+        }
+    }
+    if (-vs > alpha)
+        alpha = -vs;
+    if (-v3 > alpha)
+        alpha = -v3;
+    {
+        const double cres = vc[0] - sqrt(vc[1] * vc[1] + vc[2] * vc[2]);
+        if (-cres > alpha)
+            alpha = -cres;
+    }
+    alpha = wave_max(alpha) + theta;
+    if (k < K)
+    {
+        const unsigned act = activeMask(k, K);
+        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
+        for (int cix = 0; cix < NCONE; cix++)
+            if (act & (1u << cix))
+                v[coneOff(cix)] += alpha;
+        if (act & 64u)
+            v[L1] += alpha;
+        if (act & 128u)
+            v[L2] += alpha;
+    }
+    if (k < K - 1)
+    {
+        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
+        for (int i = 0; i < NL; i++)
+        {
+            sg[g1 * NL + i] += alpha;
+            sg[g2 * NL + i] += alpha;
+        }
+    }
+    vs += alpha;
+    v3 += alpha;
+    vc[0] += alpha;
+}
+
 // ---- per-cone work on register arrays (compile-time offset / dimension) ----
 template <int OFF, int D>
 __device__ inline void ldv(const SV &st, int f, double (&v)[D])
@@ -511,8 +585,9 @@ __device__ inline Views makeViews(const Ctx &c)
 }
 
 // ---- setup: clear records, field-major copy of the dynamics, trust-region centre, fixed values ----
-PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
 {
+    const bool warm = uniformInt(warmIn) != 0;
     const Ctx c = uniformCtx(cin);
     const double *X = uniformPtr(Xin), *U = uniformPtr(Uin), *uhat = uniformPtr(uhatIn);
     const Views v = makeViews(c);
@@ -531,16 +606,35 @@ PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, cons
     g.seta = 1.;
     g.sw[0] = 1.;
     g.sw[1] = g.sw[2] = 0.;
+    if (warm)
+    {
+        // warm start: primal point, slacks and duals of the previous solve stay in the records; the wave-uniform part
+        // was saved at the end of that solve
+        const double *gs = c.gsave;
+        g.sig = gs[0];
+        g.dsg = gs[1];
+        g.n1 = gs[2];
+        g.ss = gs[3];
+        g.zs = gs[4];
+        g.s3 = gs[5];
+        g.z3 = gs[6];
+        for (int i = 0; i < 3; i++)
+        {
+            g.sc3[i] = gs[7 + i];
+            g.zc3[i] = gs[10 + i];
+        }
+    }
     int Dcount = 0;
     // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
     // never written afterwards but are swept by the vector updates)
-    if (v.vst)
+    if (v.vst && !warm)
         for (int i = 0; i < STREC; i++)
             st[i] = 0.;
     if (v.vsg)
     {
-        for (int i = 0; i < SEGREC; i++)
-            sg[i] = 0.;
+        if (!warm)
+            for (int i = 0; i < SEGREC; i++)
+                sg[i] = 0.;
         // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
         const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
         for (int e = 0; e < NX * NX; e++)
@@ -576,10 +670,13 @@ PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, cons
             if (v.act & (1u << b))
                 Dcount++;
         // identity scalings
-        for (int i = 0; i < 6; i++)
-            st[F_ETA + i] = 1.;
-        for (int cix = 0; cix < NCONE; cix++)
-            st[F_WB + coneOff(cix)] = 1.;
+        if (!warm)
+        {
+            for (int i = 0; i < 6; i++)
+                st[F_ETA + i] = 1.;
+            for (int cix = 0; cix < NCONE; cix++)
+                st[F_WB + coneOff(cix)] = 1.;
+        }
     }
     if (v.vsg)
         Dcount += 2 * NL;
@@ -711,7 +808,32 @@ PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     g.zc3[1] = 0.5 * g.ddsg;
     g.zc3[2] = -g.dsig;
     bring2cone(c, it.gamma, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+    storePriv(gp, g);
+    storePriv(ip_, it);
     WAVE_SYNC();
+}
+// ---- warm start: slacks re-evaluated on the new data and pushed theta into the interior, duals likewise ----
+PHASE_FN void phWarmInit(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    Glob g = loadPriv(gp);
+    const double theta = 1e-2;
+    evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    WAVE_SYNC();
+    shiftToCone(c, theta, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    shiftToCone(c, theta, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+    storePriv(gp, g);
+    WAVE_SYNC();
+}
+// ---- data norms for the termination test (ECOS-style scaling) ----
+PHASE_FN void phDataNorms(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+{
+    const Ctx c = uniformCtx(cin);
+    const Views v = makeViews(c);
+    const int K = v.K;
+    const SV &st = v.st, &stN = v.stN, &dy = v.dy;
+    const double *ip = c.ip;
+    Iter it = loadPriv(ip_);
     // ---- data norms for the termination test ----
     {
         double resx0 = sqrt(K * it.wtrx * it.wtrx + it.w_t * it.w_t + it.w_trt * it.w_trt + it.w_vc * it.w_vc);
@@ -747,7 +869,6 @@ PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
         it.resy0 = sqrt(nb) > 1. ? sqrt(nb) : 1.;
         it.resz0 = sqrt(nh) > 1. ? sqrt(nh) : 1.;
     }
-    storePriv(gp, g);
     storePriv(ip_, it);
     WAVE_SYNC();
 }
@@ -1518,6 +1639,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.dy = c.sg + size_t(c.pitch) * SEGREC;
     c.fac = c.dy + size_t(c.pitch) * DYNREC;
     c.sv = c.fac + size_t(K) * FACREC;
+    c.gsave = c.sv + size_t(K) * SVREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
     c.B = a.Bm + size_t(inst) * (K - 1) * NX * NU;
     c.C = a.C + size_t(inst) * (K - 1) * NX * NU;
@@ -1543,22 +1665,32 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
 
     PROF_T(tp0);
-    phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp);
-    // =============== initialisation (ECOS init, W = I) ===============
-    phInitPrimalRhs(c, gp, itp);
+    const int warm = (a.warm && a.warm[inst] != 0) ? 1 : 0;
+    phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
+    if (warm)
     {
-        const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-        factorSweepFused(c, sh, sp);
-        bwdSweep(c, sp);
+        // sub-problems of consecutive SC iterations are close: restart from the previous primal-dual point
+        phWarmInit(c, gp, itp);
     }
-    phInitPrimalFinish(c, gp, itp);
-    phInitDualRhs(c, gp, itp);
+    else
     {
-        const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-        fwdSweep(c, sp);
-        bwdSweep(c, sp);
+        // =============== initialisation (ECOS init, W = I) ===============
+        phInitPrimalRhs(c, gp, itp);
+        {
+            const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
+            factorSweepFused(c, sh, sp);
+            bwdSweep(c, sp);
+        }
+        phInitPrimalFinish(c, gp, itp);
+        phInitDualRhs(c, gp, itp);
+        {
+            const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
+            fwdSweep(c, sp);
+            bwdSweep(c, sp);
+        }
+        phInitDualFinish(c, gp, itp);
     }
-    phInitDualFinish(c, gp, itp);
+    phDataNorms(c, gp, itp);
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
 
@@ -1702,6 +1834,22 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     }
     if (lane == 0)
     {
+        // wave-uniform part of the final primal-dual point (the rest is in the records) for a warm start of the next solve
+        double *gs = c.gsave;
+        gs[0] = g.sig;
+        gs[1] = g.dsg;
+        gs[2] = g.n1;
+        gs[3] = g.ss;
+        gs[4] = g.zs;
+        gs[5] = g.s3;
+        gs[6] = g.z3;
+        for (int i = 0; i < 3; i++)
+        {
+            gs[7 + i] = g.sc3[i];
+            gs[10 + i] = g.zc3[i];
+        }
+        if (a.warm)
+            a.warm[inst] = (status == 0 && !use_backup) ? 1 : 0;
         a.ipm_iters[inst] += iter;
         a.norm1_nu[inst] = n1;
         a.sum_delta[inst] = sum_delta;

@@ -32,6 +32,7 @@ struct scpp_hip_ctx
     double *A = nullptr, *Bm = nullptr, *C = nullptr, *S = nullptr, *Z = nullptr;
     // SC state
     double *x_init = nullptr, *ip = nullptr, *uhat = nullptr, *wtrx = nullptr, *ws = nullptr, *dbg = nullptr;
+    int *ipm_warm = nullptr; // [B] the workspace holds a warm-startable point
     int *active = nullptr, *converged = nullptr, *sc_iters = nullptr, *ipm_iters = nullptr, *status = nullptr, *counter = nullptr;
     double *norm1_nu = nullptr, *sum_delta = nullptr, *delta_sigma = nullptr;
     // SCvx state (allocated on first scvx_setup)
@@ -201,6 +202,7 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = 
     a.nu_tol = c->sc.nu_tol;
     a.delta_tol = c->sc.delta_tol;
     a.max_sc_iterations = c->sc.max_iterations;
+    a.warm = c->ipm_warm;
     a.do_sc_update = do_sc_update;
     a.opt.feastol = c->socp.feastol;
     a.opt.abstol = c->socp.abstol;
@@ -285,6 +287,7 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     rc |= devAlloc(&c->sim_u1, B * nu);
     rc |= devAlloc(&c->sim_x, B * nx);
     rc |= devAlloc(&c->active, B);
+    rc |= devAlloc(&c->ipm_warm, B);
     rc |= devAlloc(&c->converged, B);
     rc |= devAlloc(&c->sc_iters, B);
     rc |= devAlloc(&c->ipm_iters, B);
@@ -308,6 +311,7 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
         return SCPP_E_HIP;
     }
     (void)hipMemset(c->active, 0, B * sizeof(int));
+    (void)hipMemset(c->ipm_warm, 0, B * sizeof(int));
     *out = c;
     return SCPP_OK;
 }
@@ -320,7 +324,7 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
     void *ptrs[] = {c->X, c->U, c->sigma, c->par, c->A, c->Bm, c->C, c->S, c->Z, c->x_init, c->ip, c->uhat, c->wtrx, c->ws,
                     c->dbg, c->active, c->converged, c->sc_iters, c->ipm_iters, c->status, c->counter, c->norm1_nu,
                     c->sum_delta, c->delta_sigma, c->sim_dt, c->sim_u0, c->sim_u1, c->sim_x, c->vx_Xold, c->vx_Uold, c->vx_tr,
-                    c->vx_last, c->vx_cost, c->vx_info, c->vx_has_last, c->vx_needs_disc, c->vx_solves};
+                    c->vx_last, c->vx_cost, c->vx_info, c->vx_has_last, c->vx_needs_disc, c->vx_solves, c->ipm_warm};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -440,6 +444,9 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     c->sc = *so;
     c->mode = SCPP_MODE_FOH | SCPP_MODE_VT;
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!warm_start || c->scvx_ready) // cold SC solve (or a context last used in SCvx mode): cold interior-point start
+        CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
+    c->scvx_ready = false;
     SCBuffers b = scBuffers(c);
     hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
     c->sc_ready = true;
@@ -589,6 +596,8 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
     c->mode = SCPP_MODE_FOH;
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * 14 * sizeof(double), c->stream));
+    if (!warm_start)
+        CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
     SCBuffers b = scBuffers(c);
     const unsigned grid = unsigned((B + 63) / 64);
     hipLaunchKernelGGL(sc_setup_kernel, dim3(grid), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);

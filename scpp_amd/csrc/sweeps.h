@@ -33,6 +33,7 @@ __device__ inline Ctx uniformCtx(const Ctx &cin)
     c.dy = uniformPtr(cin.dy);
     c.fac = uniformPtr(cin.fac);
     c.sv = uniformPtr(cin.sv);
+    c.gsave = uniformPtr(cin.gsave);
     c.A = uniformPtr(cin.A);
     c.B = uniformPtr(cin.B);
     c.C = uniformPtr(cin.C);

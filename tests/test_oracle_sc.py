@@ -29,8 +29,10 @@ def test_rocketquat_regression_and_initial_guess_quirks(oracle):
     assert sc.solve() == 0
     inf = sc.info()
     assert sc.meta()["iterations"] == rec["iterations"]
-    assert np.allclose(inf[:, 0], rec["norm1_nu"], rtol=1e-6, atol=1e-9)
-    assert np.allclose(inf[:, 3], rec["sigma"], rtol=1e-7)
+    # the record was generated with cold interior-point starts; the default warm-started iteration has to reproduce it
+    # to solver tolerance (sub-problem optima are unique)
+    assert np.allclose(inf[:, 0], rec["norm1_nu"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(inf[:, 3], rec["sigma"], rtol=1e-6)
     # initial guess quirks (SURVEY F9 b,c): k/K interpolation -> last node != x_final; thrust (Tmax - Tmin)/2
     X0, U0, t0 = sc.iterate(0)
     s = sc.scales()
