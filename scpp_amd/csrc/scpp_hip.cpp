@@ -2,6 +2,7 @@
 // -DSCPP_HIP_EMU, by g++ against tests/emu/hip_emu.h (CPU-side kernel unit tests only).
 #include "../../include/scpp_hip.h"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -27,6 +28,9 @@ struct scpp_hip_ctx
     int device = 0, model = 0, K = 0, Bmax = 0, B = 0;
     int nx = 0, nu = 0, np = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // second half of the batch in the pipelined SC loop
+    unsigned ipm_lds_pad = 0; // measured: restricting ipm to one wave per SIMD (36 KB pad) costs more than the overlap gains
+    hipEvent_t ev_skew = nullptr, ev_join = nullptr;
     // trajectory + discretization
     double *X = nullptr, *U = nullptr, *sigma = nullptr, *par = nullptr;
     double *A = nullptr, *Bm = nullptr, *C = nullptr, *S = nullptr, *Z = nullptr;
@@ -82,17 +86,26 @@ hipEvent_t getEvent(scpp_hip_ctx *c)
         return nullptr;
     return e;
 }
-void spanBegin(scpp_hip_ctx *c, int kind, long long inst)
+void spanBegin(scpp_hip_ctx *c, int kind, long long inst, hipStream_t st)
 {
     scpp_hip_ctx::Span s;
     s.a = getEvent(c);
     s.b = getEvent(c);
     s.kind = kind;
     s.inst = inst;
-    (void)hipEventRecord(s.a, c->stream);
+    (void)hipEventRecord(s.a, st);
     c->spans.push_back(s);
 }
-void spanEnd(scpp_hip_ctx *c) { (void)hipEventRecord(c->spans.back().b, c->stream); }
+void spanEnd(scpp_hip_ctx *c, hipStream_t st) { (void)hipEventRecord(c->spans.back().b, st); }
+
+// contiguous instance range processed by one launch, and the stream it is issued on
+struct Range
+{
+    long first;
+    int count;
+    hipStream_t stream;
+};
+Range fullRange(scpp_hip_ctx *c) { return Range{0, c->B, c->stream}; }
 void collectTiming(scpp_hip_ctx *c)
 {
     (void)hipStreamSynchronize(c->stream);
@@ -122,33 +135,47 @@ void collectTiming(scpp_hip_ctx *c)
 }
 
 template <class Model>
-int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
+int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par0, int stride, const int *active0, long long ninst, Range r)
 {
-    const int B = c->B, K = c->K;
+    const int B = r.count, K = c->K;
     const long groups = ((long(B) + 7) / 8) * (K - 1);
     const unsigned grid = unsigned(groups * 8);
-    spanBegin(c, 0, ninst);
+    const size_t f = size_t(r.first), nx = size_t(c->nx), nu = size_t(c->nu), seg = size_t(K - 1);
+    const double *par = par0 + f * size_t(stride);
+    const int *active = active0 ? active0 + f : nullptr;
+    // instance-major buffers: a range is a pointer offset
+    struct
+    {
+        double *X, *U, *sigma, *A, *Bm, *C, *S, *Z;
+        hipStream_t stream;
+    } v{c->X + f * K * nx, c->U + f * K * nu, c->sigma + f, c->A + f * seg * nx * nx, c->Bm + f * seg * nx * nu,
+        c->C + f * seg * nx * nu, c->S + f * seg * nx, c->Z + f * seg * nx, r.stream};
+    spanBegin(c, 0, ninst, r.stream);
     if (mode == (SCPP_MODE_FOH | SCPP_MODE_VT))
-        hipLaunchKernelGGL((discretize_kernel<Model, true, true>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
-                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+        hipLaunchKernelGGL((discretize_kernel<Model, true, true>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
     else if (mode == SCPP_MODE_FOH)
-        hipLaunchKernelGGL((discretize_kernel<Model, true, false>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
-                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+        hipLaunchKernelGGL((discretize_kernel<Model, true, false>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
     else if (mode == SCPP_MODE_VT)
-        hipLaunchKernelGGL((discretize_kernel<Model, false, true>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
-                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
+        hipLaunchKernelGGL((discretize_kernel<Model, false, true>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
     else
-        hipLaunchKernelGGL((discretize_kernel<Model, false, false>), dim3(grid), dim3(WAVE), 0, c->stream, B, K, c->X, c->U,
-                           c->sigma, par, stride, active, c->A, c->Bm, c->C, c->S, c->Z);
-    spanEnd(c);
+        hipLaunchKernelGGL((discretize_kernel<Model, false, false>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
+    spanEnd(c, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 
-int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
+int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst, Range r)
 {
     if (c->model == SCPP_MODEL_ROCKETQUAT)
-        return launchDiscretize<RocketQuatModel>(c, mode, par, stride, active, ninst);
-    return launchDiscretize<Rocket2dModel>(c, mode, par, stride, active, ninst);
+        return launchDiscretize<RocketQuatModel>(c, mode, par, stride, active, ninst, r);
+    return launchDiscretize<Rocket2dModel>(c, mode, par, stride, active, ninst, r);
+}
+int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
+{
+    return discretizeDispatch(c, mode, par, stride, active, ninst, fullRange(c));
 }
 
 SCBuffers scBuffers(scpp_hip_ctx *c)
@@ -174,35 +201,36 @@ SCBuffers scBuffers(scpp_hip_ctx *c)
     return b;
 }
 
-int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = false)
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0)
 {
     ipm::KernelArgs a;
-    a.B = c->B;
+    const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1;
+    a.B = r.count;
     a.K = c->K;
-    a.X = c->X;
-    a.U = c->U;
-    a.sigma = c->sigma;
-    a.A = c->A;
-    a.Bm = c->Bm;
-    a.C = c->C;
-    a.S = c->S;
-    a.Z = c->Z;
-    a.ip = c->ip;
-    a.uhat = c->uhat;
-    a.ws = c->ws;
-    a.wtrx = c->wtrx;
-    a.active = (do_sc_update || masked) ? c->active : nullptr;
-    a.converged = c->converged;
-    a.sc_iters = c->sc_iters;
-    a.ipm_iters = c->ipm_iters;
-    a.status = c->status;
-    a.norm1_nu = c->norm1_nu;
-    a.sum_delta = c->sum_delta;
-    a.delta_sigma = c->delta_sigma;
+    a.X = c->X + f * K * 14;
+    a.U = c->U + f * K * 4;
+    a.sigma = c->sigma + f;
+    a.A = c->A + f * seg * 14 * 14;
+    a.Bm = c->Bm + f * seg * 14 * 4;
+    a.C = c->C + f * seg * 14 * 4;
+    a.S = c->S + f * seg * 14;
+    a.Z = c->Z + f * seg * 14;
+    a.ip = c->ip + f * ipm::IP_N;
+    a.uhat = c->uhat + f * K * 3;
+    a.ws = c->ws + f * ipm::workspaceDoubles(c->K);
+    a.wtrx = c->wtrx + f;
+    a.active = (do_sc_update || masked) ? c->active + f : nullptr;
+    a.converged = c->converged + f;
+    a.sc_iters = c->sc_iters + f;
+    a.ipm_iters = c->ipm_iters + f;
+    a.status = c->status + f;
+    a.norm1_nu = c->norm1_nu + f;
+    a.sum_delta = c->sum_delta + f;
+    a.delta_sigma = c->delta_sigma + f;
     a.nu_tol = c->sc.nu_tol;
     a.delta_tol = c->sc.delta_tol;
     a.max_sc_iterations = c->sc.max_iterations;
-    a.warm = c->ipm_warm;
+    a.warm = c->ipm_warm + f;
     a.do_sc_update = do_sc_update;
     a.opt.feastol = c->socp.feastol;
     a.opt.abstol = c->socp.abstol;
@@ -210,11 +238,16 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = 
     a.opt.gamma = 0.99;
     a.opt.maxit = c->socp.maxit;
     a.opt.use_mfma = c->socp.use_mfma;
-    a.dbg = c->dbg;
-    spanBegin(c, 1, ninst);
-    hipLaunchKernelGGL(ipm::ipm_kernel, dim3(unsigned(c->B)), dim3(WAVE), 0, c->stream, a);
-    spanEnd(c);
+    a.dbg = c->dbg + f * 32;
+    spanBegin(c, 1, ninst, r.stream);
+    // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
+    hipLaunchKernelGGL(ipm::ipm_kernel, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+    spanEnd(c, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = false)
+{
+    return launchIpm(c, do_sc_update, ninst, masked, fullRange(c));
 }
 
 int countActive(scpp_hip_ctx *c, int *n)
@@ -335,6 +368,12 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
     }
     for (auto e : c->pool)
         (void)hipEventDestroy(e);
+    if (c->ev_skew)
+        (void)hipEventDestroy(c->ev_skew);
+    if (c->ev_join)
+        (void)hipEventDestroy(c->ev_join);
+    if (c->stream2)
+        (void)hipStreamDestroy(c->stream2);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -520,13 +559,66 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
 {
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
-    int n_active = c->last_active;
-    for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
+    const int B = c->B;
+    if (B < 1024 || c->last_active != B)
     {
-        int rc = scpp_hip_sc_iterate(c, &n_active);
+        // small or partially masked batches: one stream, stop as soon as every instance has terminated
+        int n_active = c->last_active;
+        for (int it = 0; it < c->sc.max_iterations && n_active > 0; it++)
+        {
+            int rc = scpp_hip_sc_iterate(c, &n_active);
+            if (rc)
+                return rc;
+        }
+        return scpp_hip_sc_finish(c, n_converged);
+    }
+    // Large batches: the two halves run the loop on two streams, skewed by one kernel, so that the memory-bound
+    // interior-point kernel of one half overlaps the ALU/LDS-bound discretisation of the other half (with two resident
+    // waves per SIMD the second ipm wave buys nothing, a discretisation wave does).  No host synchronisation inside
+    // the loop: instances that have terminated return at the top of both kernels.
+    if (!c->stream2)
+    {
+        if (const char *e = std::getenv("SCPP_IPM_LDS_PAD"))
+            c->ipm_lds_pad = unsigned(std::atoi(e));
+        CHECK_HIP(hipStreamCreate(&c->stream2));
+        CHECK_HIP(hipEventCreate(&c->ev_skew));
+        CHECK_HIP(hipEventCreate(&c->ev_join));
+    }
+    const int h0 = (B / 2 + 7) & ~7; // keep the XCD groups of 8 instances intact
+    const Range r0{0, h0, c->stream}, r1{h0, B - h0, c->stream2};
+    // everything enqueued so far (set-up kernels, uploads) is on the main stream
+    CHECK_HIP(hipEventRecord(c->ev_skew, c->stream));
+    CHECK_HIP(hipStreamWaitEvent(c->stream2, c->ev_skew, 0));
+    for (int it = 0; it < c->sc.max_iterations; it++)
+    {
+        int rc = discretizeDispatch(c, c->mode, c->ip + ipm::IP_PAR, ipm::IP_N, c->active, r0.count, r0);
+        if (rc)
+            return rc;
+        if (it == 0)
+        {
+            // skew: the second half starts when the first half's first discretisation is done
+            CHECK_HIP(hipEventRecord(c->ev_skew, c->stream));
+            CHECK_HIP(hipStreamWaitEvent(c->stream2, c->ev_skew, 0));
+        }
+        rc = discretizeDispatch(c, c->mode, c->ip + ipm::IP_PAR, ipm::IP_N, c->active, r1.count, r1);
+        if (rc)
+            return rc;
+        // optional occupancy limiter (SCPP_IPM_LDS_PAD bytes of untouched dynamic LDS per ipm workgroup); default 0
+        const unsigned pad = c->ipm_lds_pad;
+        rc = launchIpm(c, 1, r0.count, false, r0, pad);
+        if (rc)
+            return rc;
+        rc = launchIpm(c, 1, r1.count, false, r1, pad);
         if (rc)
             return rc;
     }
+    CHECK_HIP(hipEventRecord(c->ev_join, c->stream2));
+    CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    int n = 0;
+    int rc = countActive(c, &n);
+    if (rc)
+        return rc;
+    c->last_active = n;
     return scpp_hip_sc_finish(c, n_converged);
 }
 

@@ -323,6 +323,7 @@ inline hipError_t hipStreamCreate(hipStream_t *s)
     return 0;
 }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; } // emulated streams run in issue order
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }

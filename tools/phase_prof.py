@@ -5,10 +5,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import scpp_amd
 lib = sys.argv[1]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+NIT = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # profile the NIT-th SC iteration (>= 2: warm-started solve)
 m = scpp_amd.RocketQuat().loadParameters()
 alg = scpp_amd.SCAlgorithm(m, K=50, batch_max=B, library=os.path.abspath(lib)).initialize()
 x0 = m.randomized_initial_states(B)
 alg.ctx.sc_setup(m.p, alg.opts, x0)
+for _ in range(NIT - 1):
+    alg.ctx.sc_iterate()
+prev = alg.ctx.download()["ipm_iters"].copy() if NIT > 1 else 0
+alg.ctx.timing(reset=True)
 alg.ctx.sc_iterate()
 info = alg.ctx.socp_info()
 names = ["init", "residuals", "scalings", "  factorFused(in 5)", "rhs(t,bx)+kktPrep", "sweeps+kktFinish", "dz/ds/step", "update", "prepareFactor", "  bwdSweeps(in 5)", "  fwdSweep(in 5)", "kernel_total"]
