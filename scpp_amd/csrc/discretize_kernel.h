@@ -77,6 +77,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     __shared__ __attribute__((aligned(16))) double Ys[(NCOLS + NG) * NX]; // stage values of V (column-major: col*NX + row)
     __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major
     __shared__ double fv[NX];                                              // f(x,u) (unscaled)
+    // The stage slopes with the longest lifetimes (k1, k4, k5, k6: needed until stage 13) live in LDS, the others in
+    // registers: all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceed the 256-VGPR budget of two waves
+    // per SIMD and the spills went to scratch inside the AD chain.
+    __shared__ double Kl[4][EPL][WAVE];
 
     const int lane = threadIdx.x;
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
@@ -130,7 +134,12 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 
     double kk[RK_S][EPL];
+    constexpr int KSLOT[RK_S] = {0, -1, -1, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1}; // LDS slot of stage j, -1: registers
     const double h = dt / 5.;
+#ifdef DISC_PROFILE
+    long long tA = 0, tB = 0, tC = 0;
+    const long long tk0 = clock64();
+#endif
 
     for (int step = 0; step < 5; step++)
     {
@@ -141,6 +150,9 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
         forEachStage([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // ---- stage value ys = y + h * sum_j a_sj k_j ----
+#ifdef DISC_PROFILE
+            const long long p0 = clock64();
+#endif
             const double ts = t0 + RK_C[s] * h;
 #pragma unroll
             for (int m = 0; m < EPL; m++)
@@ -149,12 +161,16 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
                 for (int j = 0; j < s; j++)
                     if (RK_A[s][j] != 0.)
-                        acc += RK_A[s][j] * kk[j][m];
+                        acc += RK_A[s][j] * (KSLOT[j] >= 0 ? Kl[KSLOT[j] >= 0 ? KSLOT[j] : 0][m][lane] : kk[j][m]);
                 const double ys = y[m] + h * acc;
                 if (eon[m])
                     Ys[(m * NG + g) * NX + row] = ys;
             }
             WAVE_SYNC();
+#ifdef DISC_PROFILE
+            const long long p1 = clock64();
+            tA += p1 - p0;
+#endif
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
             const double frac = FOH ? ts / dt : 0.;
             if (lane < NJ)
@@ -178,6 +194,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 }
             }
             WAVE_SYNC();
+#ifdef DISC_PROFILE
+            const long long p2 = clock64();
+            tB += p2 - p1;
+#endif
             // ---- derivative of the owned entries: d(row, c) = J[row,:] V[:,c] + forcing(row, c), branch-free ----
             {
                 double jr[NJ];
@@ -211,10 +231,16 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                         d = (c == L::COL_S) ? d + fr : d;
                     if (m == 0)
                         d = (c == 0) ? tscale * fr : d;
-                    kk[s][m] = d;
+                    if (KSLOT[s] >= 0)
+                        Kl[KSLOT[s] >= 0 ? KSLOT[s] : 0][m][lane] = d;
+                    else
+                        kk[s][m] = d;
                 }
             }
             WAVE_SYNC();
+#ifdef DISC_PROFILE
+            tC += clock64() - p2;
+#endif
         });
         // ---- y += h * sum_s b_s k_s ----
 #pragma unroll
@@ -224,11 +250,15 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
             for (int s = 0; s < RK_S; s++)
                 if (RK_B[s] != 0.)
-                    acc += RK_B[s] * kk[s][m];
+                    acc += RK_B[s] * (KSLOT[s] >= 0 ? Kl[KSLOT[s] >= 0 ? KSLOT[s] : 0][m][lane] : kk[s][m]);
             y[m] += h * acc;
         }
     }
 
+#ifdef DISC_PROFILE
+    if (blockIdx.x == 4096 && lane == 0)
+        printf("disc profile (cycles/segment): stage-value %lld  AD %lld  product %lld  total %lld\n", tA, tB, tC, (long long)(clock64() - tk0));
+#endif
     // ---- write A_k, B_k, C_k, s_k ; z_k from the affine identity ----
     const long seg = inst * nseg + k;
 #pragma unroll
