@@ -77,7 +77,6 @@ def main():
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--scvx-batch", type=int, default=2048,
                     help="size of the extra SCvx-mode run reported under config.scvx_mode (0 = skip)")
     args = ap.parse_args()
@@ -102,7 +101,6 @@ def main():
     model = scpp_amd.RocketQuat().loadParameters()
     alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, device=dev.index).initialize()
     ctx = alg.ctx
-    ctx.set_socp_opts(use_mfma=0 if args.no_mfma else 1)
     pX, pU, pS = ctx.device_ptrs()
     dX = torch.as_tensor(_DevArray(pX, (B, K, 14)), device=dev)
     dU = torch.as_tensor(_DevArray(pU, (B, K, 4)), device=dev)
@@ -230,7 +228,7 @@ def main():
                 "mean_ipm_iterations_per_trajectory": ipm_it / total if total else 0.0,
                 "solver_failures": fails,
                 "median_final_virtual_control_norm1": float(np.median(stats["nu"])) if stats["nu"] else None,
-                "mfma": not args.no_mfma,
+                "mfma": True,
                 "scvx_mode": scvx_report,
             },
             "roofline": {

@@ -87,7 +87,7 @@ extern "C"
     {
         double feastol, abstol, reltol;
         int maxit;
-        int use_mfma; /* 1: v_mfma_f64_16x16x4_f64 tile products, 0: plain FMA (same results to round-off) */
+        int use_mfma; /* kept for ABI stability; ignored: every tile product runs on v_mfma_f64_16x16x4_f64 */
     } scpp_socp_opts;
 
     /* accumulated device time per kernel family, measured with hipEvents on the context stream */

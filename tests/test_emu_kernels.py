@@ -27,11 +27,9 @@ def test_emu_discretize_matches_oracle(oracle, model, emu_lib):
             assert np.abs(a - o).max() <= 1e-11 * max(1.0, np.abs(o).max())
 
 
-@pytest.mark.parametrize("use_mfma", [0, 1])
-def test_emu_socp_matches_structured_twin(oracle, model, emu_lib, use_mfma):
+def test_emu_socp_matches_structured_twin(oracle, model, emu_lib):
     K, B = 8, 2
     alg, x0 = _setup(model, emu_lib, K, B)
-    alg.ctx.set_socp_opts(use_mfma=use_mfma)
     alg.ctx.sc_setup(model.p, alg.opts, x0)
     alg.ctx.sc_iterate()
     out = alg.ctx.download()

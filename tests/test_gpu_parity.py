@@ -91,12 +91,10 @@ def test_simulate_matches_oracle(oracle, model, hip_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("use_mfma", [1, 0])
-def test_subproblem_matches_structured_twin(oracle, model, alg, use_mfma):
+def test_subproblem_matches_structured_twin(oracle, model, alg):
     """One SCAlgorithm::iterate (discretize + SOCP + update): iterate-for-iterate identical to the twin."""
     B = 8
     x0 = model.randomized_initial_states(B)
-    alg.ctx.set_socp_opts(use_mfma=use_mfma)
     alg.ctx.sc_setup(model.p, alg.opts, x0)
     alg.ctx.sc_iterate()
     out = alg.ctx.download()
@@ -107,7 +105,6 @@ def test_subproblem_matches_structured_twin(oracle, model, alg, use_mfma):
         assert out["status"][b] == 0 and out["ipm_iters"][b] == int(inf[4])
         assert abs(out["nu_norm"][b] - inf[0]) < 1e-8 and abs(out["sum_delta"][b] - inf[1]) < 1e-8
         assert np.abs(out["X"][b] - X1).max() < 1e-8 and np.abs(out["U"][b] - U1).max() < 1e-8 and abs(out["sigma"][b] - t1) < 1e-8
-    alg.ctx.set_socp_opts(use_mfma=1)
 
 
 def test_subproblem_matches_literal_ecos_style_solver(oracle, model, alg):
