@@ -6,16 +6,6 @@
 
 #include "sc_algorithm.hpp"
 
-inline trajectory_data_t sc_dynamic(std::shared_ptr<Model> model)
-{
-    scpp::SCAlgorithm solver(model);
-    solver.initialize();
-    trajectory_data_t td;
-    solver.solve();
-    solver.getSolution(td);
-    return td;
-}
-
 // B instances that differ in their initial state
 inline std::vector<trajectory_data_t> sc_dynamic(std::shared_ptr<Model> model, const std::vector<Model::state_vector_t> &x_inits)
 {
@@ -24,4 +14,10 @@ inline std::vector<trajectory_data_t> sc_dynamic(std::shared_ptr<Model> model, c
     scpp::batch_result_t r;
     solver.solveBatch(x_inits, r);
     return r.td;
+}
+
+// the reference's single-instance form: the model's configured initial state
+inline trajectory_data_t sc_dynamic(std::shared_ptr<Model> model)
+{
+    return sc_dynamic(model, std::vector<Model::state_vector_t>{model->p.x_init}).front();
 }
