@@ -81,6 +81,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     // registers: all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceed the 256-VGPR budget of two waves
     // per SIMD and the spills went to scratch inside the AD chain.
     __shared__ double Kl[4][EPL][WAVE];
+    // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 AD evaluations need.
+    // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
+    // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the AD phase.
+    __shared__ double cst[NP + 2 * NU];
 
     const int lane = threadIdx.x;
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
@@ -110,6 +114,19 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
         u1[i] = FOH ? U[(inst * K + k + 1) * NU + i] : u0[i];
     }
 
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            cst[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < NU; i++)
+        {
+            cst[NP + i] = u0[i];
+            cst[NP + NU + i] = u1[i];
+        }
+    }
+    WAVE_SYNC();
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
     // stage (kept in registers for all its columns) and one column of V per entry.
     const bool lane_on = lane < NG * NX;
@@ -176,13 +193,27 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             if (lane < NJ)
             {
                 Dual1 xd[NX], ud[NU], fd[NX];
+                // opaque zero offset: keeps the compiler from hoisting these LDS reads out of the stage loop (and
+                // spilling the values again)
+                int zo = 0;
+#ifndef SCPP_HIP_EMU
+                asm volatile("" : "+v"(zo));
+#endif
+                const double *cv = cst + zo;
+                double pl[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i++)
+                    pl[i] = cv[i];
 #pragma unroll
                 for (int i = 0; i < NX; i++)
                     xd[i] = Dual1(Ys[i], (lane == i) ? 1. : 0.);
 #pragma unroll
                 for (int i = 0; i < NU; i++)
-                    ud[i] = Dual1(u0[i] + frac * (u1[i] - u0[i]), (lane == NX + i) ? 1. : 0.);
-                Model::template systemFlowMap<Dual1>(xd, ud, p, fd);
+                {
+                    const double a0 = cv[NP + i], a1 = cv[NP + NU + i];
+                    ud[i] = Dual1(a0 + frac * (a1 - a0), (lane == NX + i) ? 1. : 0.);
+                }
+                Model::template systemFlowMap<Dual1>(xd, ud, pl, fd);
 #pragma unroll
                 for (int i = 0; i < NX; i++)
                     Jm[i * NJP + lane] = tscale * fd[i].d;
