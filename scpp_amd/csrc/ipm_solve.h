@@ -479,8 +479,9 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     stv<OFF, D>(st, F_TZ, t);
 }
 // dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
+// store_final = false (predictor pass): only the scaled directions are needed afterwards (corrector term)
 template <int OFF, int D>
-__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall)
+__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final)
 {
     double w[D], Ld[D], aa[D], t[D], rz[D], dz[D], ds[D], dss[D], dzs[D], ls[D];
     const double eta = st[F_ETA + cix];
@@ -500,8 +501,11 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
     }
     cone::applyWinvS<D>(eta, w, ds, dss);
     cone::applyWS<D>(eta, w, dz, dzs);
-    stv<OFF, D>(st, F_DZ, dz);
-    stv<OFF, D>(st, F_DS, ds);
+    if (store_final)
+    {
+        stv<OFF, D>(st, F_DZ, dz);
+        stv<OFF, D>(st, F_DS, ds);
+    }
     stv<OFF, D>(st, F_DSS, dss);
     stv<OFF, D>(st, F_DZS, dzs);
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
@@ -1319,7 +1323,7 @@ PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
 template <int I0, int N>
-__device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double &ainv, double &sumdnb)
+__device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
 {
     double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
     double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
@@ -1357,9 +1361,12 @@ __device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double 
         m1 = m1 > m3 ? m1 : m3;
         ainv = m1 > ainv ? m1 : ainv;
     }
-    stf<N>(sg, G_DLAM * NL + I0, dlam);
-    stf<N>(sg, G_DNU * NL + I0, dnu);
-    stf<N>(sg, G_DNUB * NL + I0, dnub);
+    if (store_final)
+    {
+        stf<N>(sg, G_DLAM * NL + I0, dlam);
+        stf<N>(sg, G_DNU * NL + I0, dnu);
+        stf<N>(sg, G_DNUB * NL + I0, dnub);
+    }
     stf<N>(sg, G_DZ1 * NL + I0, dz1);
     stf<N>(sg, G_DS1 * NL + I0, ds1);
     stf<N>(sg, G_DZ2 * NL + I0, dz2);
@@ -1430,30 +1437,33 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
                 finite_chk += dw[j] * 0.; // NaN / Inf -> NaN
             }
             const double ddl = (ip[IP_SCVX] != 0.) ? 0. : (bxd - acc) / hdd;
-            stf<NV>(st, F_DW, dw);
-            st[F_DDL] = ddl;
+            if (pass != 0) // the predictor's dw / ddelta are consumed in this phase only
+            {
+                stf<NV>(st, F_DW, dw);
+                st[F_DDL] = ddl;
+            }
             Lmul(ip, act, dw, ddl, uh, Ld);
         }
-        double a0 = coneDir<C1, 17>(st, 0, om, Ld);
+        double a0 = coneDir<C1, 17>(st, 0, om, Ld, pass != 0);
         ainv = a0 > ainv ? a0 : ainv;
         if (act & 2u)
         {
-            a0 = coneDir<C2, 3>(st, 1, om, Ld);
+            a0 = coneDir<C2, 3>(st, 1, om, Ld, pass != 0);
             ainv = a0 > ainv ? a0 : ainv;
         }
         if (act & 4u)
         {
-            a0 = coneDir<C3, 3>(st, 2, om, Ld);
+            a0 = coneDir<C3, 3>(st, 2, om, Ld, pass != 0);
             ainv = a0 > ainv ? a0 : ainv;
         }
         if (act & 8u)
         {
-            a0 = coneDir<C4, 3>(st, 3, om, Ld);
+            a0 = coneDir<C4, 3>(st, 3, om, Ld, pass != 0);
             ainv = a0 > ainv ? a0 : ainv;
         }
-        a0 = coneDir<C5, 4>(st, 4, om, Ld);
+        a0 = coneDir<C5, 4>(st, 4, om, Ld, pass != 0);
         ainv = a0 > ainv ? a0 : ainv;
-        a0 = coneDir<C6, 3>(st, 5, om, Ld);
+        a0 = coneDir<C6, 3>(st, 5, om, Ld, pass != 0);
         ainv = a0 > ainv ? a0 : ainv;
         {
             double sv[2], zv[2], rz[2], tz[2], dzv[2], dsv[2];
@@ -1478,9 +1488,9 @@ PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int pas
     double sumdnb = 0.;
     if (v.vsg)
     {
-        dirSegChunk<0, 5>(sg, om, g.dsig, ainv, sumdnb);
-        dirSegChunk<5, 5>(sg, om, g.dsig, ainv, sumdnb);
-        dirSegChunk<10, 4>(sg, om, g.dsig, ainv, sumdnb);
+        dirSegChunk<0, 5>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        dirSegChunk<5, 5>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        dirSegChunk<10, 4>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
     }
     sumdnb = wave_sum(sumdnb);
     // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
