@@ -252,6 +252,18 @@ class RQStructuredSocp
         setupStages();
         RQSocpOutput out;
         out.status = run(out);
+        if (out.status != 0 && warm_start)
+        {
+            // a warm start that breaks down is repeated from ECOS's cold initialisation
+            warm_start = false;
+            restored_best = false;
+            alloc();
+            setupStages();
+            const int warm_iters = out.iters;
+            out = RQSocpOutput();
+            out.status = run(out);
+            out.iters += warm_iters;
+        }
         out.X.assign(size_t(K) * NX, 0.);
         out.U.assign(size_t(K) * NU, 0.);
         out.nu = nu;

@@ -1675,7 +1675,12 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
 
     PROF_T(tp0);
-    const int warm = (a.warm && a.warm[inst] != 0) ? 1 : 0;
+    int warm = (a.warm && a.warm[inst] != 0) ? 1 : 0;
+    int status = -1, iter = 0, iter_total = 0;
+    bool use_backup = false;
+    // a warm start that breaks down is repeated from ECOS's cold initialisation (attempt 1)
+    for (int attempt = 0; attempt < 2; attempt++)
+    {
     phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
     if (warm)
     {
@@ -1704,8 +1709,12 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
 
-    int status = -1, iter = 0;
-    bool inacc_ok = false, bk_prev = false, use_backup = false;
+    status = -1;
+    iter = 0;
+    use_backup = false;
+    it.bk_valid = 0;
+    it.bad = 0;
+    bool inacc_ok = false, bk_prev = false;
     double pres_prev = 0.;
     for (iter = 0;; iter++)
     {
@@ -1796,6 +1805,12 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         PROF_ADD(7, tu0, tu1);
     }
 
+    iter_total += iter;
+    if (status == 0 || !warm)
+        break;
+    warm = 0;
+    }
+    iter = iter_total;
     // =============== outputs: readSolution + SC bookkeeping ===============
     const bool vst = k < K;
     const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0), c.pitch);
