@@ -18,14 +18,22 @@ emu, total, K, outdir = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.arg
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 model = scpp_amd.RocketQuat().loadParameters()
 lo, hi = shard_range(total, dist.get_world_size(), dist.get_rank())
-alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=hi - lo, library=emu).initialize()
+mode = sys.argv[6] if len(sys.argv) > 6 else "sc"
+if mode == "scvx":
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=hi - lo, library=emu, max_iterations=4).initialize()
+else:
+    alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=hi - lo, library=emu).initialize()
 res = solve_sharded(alg, model, total, 20260927, dist=dist)
 np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **res)
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_world2_gloo_sharded_solve_matches_single_process(emu_lib, model, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("mode,port", [("sc", "29541"), ("scvx", "29542")])
+def test_world2_gloo_sharded_solve_matches_single_process(emu_lib, model, tmp_path, mode, port):
     import scpp_amd
     from scpp_amd.distributed import shard_range, solve_sharded
 
@@ -33,14 +41,17 @@ def test_world2_gloo_sharded_solve_matches_single_process(emu_lib, model, tmp_pa
     assert shard_range(total, 2, 0) == (0, 3) and shard_range(total, 2, 1) == (3, 5)
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, emu_lib, str(total), str(K), str(tmp_path)], env=e))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, emu_lib, str(total), str(K), str(tmp_path), mode], env=e))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=total, library=emu_lib).initialize()
+    if mode == "scvx":
+        alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=total, library=emu_lib, max_iterations=4).initialize()
+    else:
+        alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=total, library=emu_lib).initialize()
     single = solve_sharded(alg, model, total, 20260927)
     for r in range(2):
         got = np.load(tmp_path / f"rank{r}.npz")
