@@ -48,3 +48,27 @@ def test_weight_doubling_rule(oracle):
     inf = sc.info()
     n_double = int((inf[:, 0] < 1e-5).sum())
     assert abs(sc.scales()[2] - 1.0 * 2.0 ** n_double) < 1e-12
+
+
+def test_warm_started_ipm_reproduces_cold_start_trajectories(oracle, monkeypatch):
+    """The interior-point iteration is warm-started across SC iterations by default; ORACLE_WARM=0 forces ECOS-style cold
+    starts.  Sub-problem optima are unique, so both must give the same SC run to solver tolerance -- with far fewer
+    interior-point iterations."""
+    runs = {}
+    for warm in ("0", "1"):
+        monkeypatch.setenv("ORACLE_WARM", warm)
+        out = []
+        for b in range(3):
+            sc = oracle.SC(oracle.ROCKETQUAT, K=30)
+            sc.randomize(20260927, b)
+            sc.set_solver(1)
+            assert sc.solve() == 0
+            X, U, t = sc.solution()
+            out.append((X, U, t, sc.info()[:, 4].sum(), sc.info()[:, 0]))
+        runs[warm] = out
+    for cold, warm in zip(runs["0"], runs["1"]):
+        assert np.abs(cold[0] - warm[0]).max() <= 1e-5 * np.abs(cold[0]).max()
+        assert np.abs(cold[1] - warm[1]).max() <= 1e-5 * np.abs(cold[1]).max()
+        assert abs(cold[2] - warm[2]) <= 1e-6 * cold[2]
+        assert np.allclose(cold[4], warm[4], rtol=1e-4, atol=1e-8)   # virtual-control norm per SC iteration
+        assert warm[3] < 0.6 * cold[3]                                # interior-point iterations
