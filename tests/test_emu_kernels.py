@@ -110,3 +110,32 @@ def test_emu_scvx_matches_oracle(oracle, model, emu_lib):
         assert out["sigma"][b] == t  # fixed final time
         compared += 1
     assert compared >= 2
+
+
+def test_emu_config_variants(oracle, emu_lib, tmp_path):
+    """Configuration switches of the model file that change the sub-problem: `exact_minimum_thrust false` (the minimum
+    thrust becomes U_z >= T_min instead of the linearised direction, rocketQuat.cpp:117-133) and a smaller trust-region
+    weight (early per-instance convergence masks)."""
+    import os
+    import shutil
+
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    p = cfg / "RocketQuat" / "model.info"
+    p.write_text(p.read_text().replace("exact_minimum_thrust    true", "exact_minimum_thrust    false"))
+    q = cfg / "RocketQuat" / "SC.info"
+    q.write_text(q.read_text().replace("weight_trust_region_trajectory      50.", "weight_trust_region_trajectory      0.5"))
+    K, B = 10, 4
+    m2 = scpp_amd.RocketQuat(str(cfg)).loadParameters()
+    assert m2.p.exact_minimum_thrust == 0
+    a2 = scpp_amd.SCAlgorithm(m2, K=K, batch_max=B, library=emu_lib).initialize()
+    x0 = m2.randomized_initial_states(B)
+    nconv = a2.solve(x0)
+    out = a2.getSolution()
+    ref = oracle.sc_batch(K, 20260927, 0, B, nthreads=2, solver=1, config_root=str(cfg))
+    ok = ref["status"] == 0 if "status" in ref else np.ones(B, dtype=bool)
+    assert (out["sc_iters"][ok] == ref["iters"][ok]).all() and (out["converged"][ok] == ref["converged"][ok]).all()
+    assert nconv == int(out["converged"].sum())
+    for b in np.nonzero(ok)[0]:
+        assert np.abs(out["X"][b] - ref["X"][b]).max() <= 1e-6 * np.abs(ref["X"][b]).max()
+        assert np.abs(out["U"][b] - ref["U"][b]).max() <= 1e-5 * np.abs(ref["U"][b]).max()
