@@ -284,17 +284,19 @@ __device__ inline Tile finishNt(const Tile &raw, unsigned fmn, int lane)
     return t;
 }
 
-struct FactorIn
+// Stage inputs of the factor sweep.  Only the Hessian inputs (needed at the very start of a stage) are prefetched one
+// stage ahead; the coupling tiles and right-hand sides are requested at the START of their own stage and consumed after
+// the first inverse-factor elimination, whose dependent chain (thousands of cycles) hides their latency -- which keeps
+// 34 VGPRs of prefetch buffer out of the elimination's live set.
+struct FactorRest
 {
-    HRaw h;
     Tile mt, n, rl, rwn;
     double einv;
 };
-__device__ inline FactorIn loadFactorIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+__device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
     const int i = lane & 15;
-    FactorIn f;
-    f.h = loadHRaw(c, k, lane);
+    FactorRest f;
     if (k < c.K - 1)
     {
         f.mt = loadMtRaw(c, k, lane);
@@ -322,24 +324,19 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
     const double dual_reg = scvx ? 1e-9 : 0.;
     Tile Z = tileZero(), G = loadRhsW(c, sp, 0, lane);
-    FactorIn cur = loadFactorIn(c, sp, 0, lane);
+    HRaw hcur = loadHRaw(c, 0, lane);
     for (int k = 0; k < K; k++)
     {
-        FactorIn nxt = cur;
+        const FactorRest cur = loadFactorRest(c, sp, k, lane); // arrives during the first elimination below
+        HRaw hnxt = hcur;
         if (k + 1 < K)
-            nxt = loadFactorIn(c, sp, k + 1, lane); // prefetch: overlaps the elimination chain below
+            hnxt = loadHRaw(c, k + 1, lane); // prefetch
         double *fk = c.fac + size_t(k) * FACREC;
         double *svk = c.sv + size_t(k) * SVREC;
-        Tile Phi = buildHTile(cur.h, k, K, lane, scvx);
+        Tile Phi = buildHTile(hcur, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
-        const Tile Li = invCholFactor<NV>(Phi, sh, lane);
-#ifdef SCPP_HIP_EMU
-        if (getenv("SCPP_EMU_DEBUG"))
-            for (int r = 0; r < 4; r++)
-                if (!(Li.v[r] == Li.v[r]) || fabs(Li.v[r]) > 1e150 || !(Phi.v[r] == Phi.v[r]))
-                    printf("[emu] stage %d lane %d r %d Li %g Phi %g\n", k, lane, r, Li.v[r], Phi.v[r]);
-#endif
+        const Tile Li = INVCHOL<NV>(Phi, sh, lane);
         storeTri<NV>(fk + FAC_LI, lane, Li);
         const Tile Lit = transposeTile(Li, sh, lane);
         const Tile a = mm(Lit, G);
@@ -357,13 +354,7 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
             if (row == i)
                 Th.v[r] = (row < NL) ? Th.v[r] + cur.einv + dual_reg : 1.;
         }
-        const Tile Ti = invCholFactor<NL>(Th, sh, lane);
-#ifdef SCPP_HIP_EMU
-        if (getenv("SCPP_EMU_DEBUG"))
-            for (int r = 0; r < 4; r++)
-                if (!(Ti.v[r] == Ti.v[r]) || fabs(Ti.v[r]) > 1e150 || !(Th.v[r] == Th.v[r]))
-                    printf("[emu] stage %d lane %d r %d Ti %g Th %g einv %g\n", k, lane, r, Ti.v[r], Th.v[r], cur.einv);
-#endif
+        const Tile Ti = INVCHOL<NL>(Th, sh, lane);
         storeTri<NL>(fk + FAC_TI, lane, Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
         Z = mm(Tit, finishN(cur.n, fmn, lane));
@@ -371,7 +362,7 @@ SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &sp
         const Tile cc = mm(Tit, gl);
         saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
         G = tileAdd(cur.rwn, mm(Z, cc));
-        cur = nxt;
+        hcur = hnxt;
     }
     WAVE_SYNC();
 }
