@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scvx-batch", type=int, default=2048,
+    ap.add_argument("--scvx-batch", type=int, default=8192,
                     help="size of the extra SCvx-mode run reported under config.scvx_mode (0 = skip)")
     args = ap.parse_args()
 
