@@ -279,3 +279,21 @@ def test_scvx_mode_matches_oracle(oracle, model, hip_lib):
         assert _rel(out["X"][b], X) < 1e-6 and _rel(out["U"][b], U) < 1e-4
         assert out["sigma"][b] == t
     a.ctx.close()
+
+
+def test_pipelined_loop_equals_single_stream_loop(model, hip_lib):
+    """scpp_hip_sc_solve runs batches >= 1024 as two halves on two skewed streams without host synchronisation; smaller
+    batches run the plain loop.  The same instances must give bitwise identical results either way (no cross-instance
+    coupling, same kernels)."""
+    x0 = model.randomized_initial_states(1024, first=7000)
+    big = scpp_amd.SCAlgorithm(model, K=50, batch_max=1024, library=hip_lib).initialize()
+    big.solve(x0)
+    a = big.getSolution()
+    big.ctx.close()
+    small = scpp_amd.SCAlgorithm(model, K=50, batch_max=512, library=hip_lib).initialize()
+    for lo in (0, 512):
+        small.solve(x0[lo:lo + 512])
+        b = small.getSolution()
+        for key in ("X", "U", "sigma", "sc_iters", "ipm_iters", "status", "converged"):
+            assert np.array_equal(a[key][lo:lo + 512], b[key]), (lo, key)
+    small.ctx.close()
