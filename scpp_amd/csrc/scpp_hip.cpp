@@ -201,6 +201,30 @@ SCBuffers scBuffers(scpp_hip_ctx *c)
     return b;
 }
 
+// instance-major per-instance arrays: a range is a pointer offset
+SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
+{
+    SCBuffers b = scBuffers(c);
+    const size_t f = size_t(r.first), K = size_t(c->K);
+    b.B = r.count;
+    b.x_init_dim += f * 14;
+    b.X += f * K * 14;
+    b.U += f * K * 4;
+    b.sigma += f;
+    b.ip += f * ipm::IP_N;
+    b.uhat += f * K * 3;
+    b.wtrx += f;
+    b.active += f;
+    b.converged += f;
+    b.sc_iters += f;
+    b.ipm_iters += f;
+    b.status += f;
+    b.norm1_nu += f;
+    b.sum_delta += f;
+    b.delta_sigma += f;
+    return b;
+}
+
 int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0)
 {
     ipm::KernelArgs a;
@@ -701,37 +725,66 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
 }
 
+namespace
+{
+SCvxBuffers scvxBuffersRange(scpp_hip_ctx *c, Range r)
+{
+    SCvxBuffers v = scvxBuffers(c);
+    const size_t f = size_t(r.first), K = size_t(c->K);
+    v.Xold += f * K * 14;
+    v.Uold += f * K * 4;
+    v.tr += f;
+    v.last_cost += f;
+    v.cost += f;
+    v.info += f * 4;
+    v.has_last += f;
+    v.needs_disc += f;
+    v.solves += f;
+    return v;
+}
+
+// one SCvx round (one sub-problem solve of every active instance) of an instance range on its stream: instances whose
+// previous candidate was rejected re-solve on their old discretisation (needs_disc = 0), the others start a new iteration
+int scvxRound(scpp_hip_ctx *c, Range r)
+{
+    const size_t K = size_t(c->K), f = size_t(r.first), n = size_t(r.count);
+    int rc = discretizeDispatch(c, SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, r.count, r);
+    if (rc)
+        return rc;
+    CHECK_HIP(hipMemcpyAsync(c->vx_Xold + f * K * 14, c->X + f * K * 14, n * K * 14 * sizeof(double), hipMemcpyDeviceToDevice, r.stream));
+    CHECK_HIP(hipMemcpyAsync(c->vx_Uold + f * K * 4, c->U + f * K * 4, n * K * 4 * sizeof(double), hipMemcpyDeviceToDevice, r.stream));
+    rc = launchIpm(c, 0, r.count, true, r);
+    if (rc)
+        return rc;
+    const SCBuffers b = scBuffersRange(c, r);
+    const SCvxBuffers v = scvxBuffersRange(c, r);
+    hipLaunchKernelGGL((scvx_cost_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v,
+                       c->scvx.interpolate_input);
+    hipLaunchKernelGGL(scvx_update_kernel, dim3(unsigned((r.count + 63) / 64)), dim3(64), 0, r.stream, b, v, c->scvx);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+} // namespace
+
 int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
 {
     if (!c || !c->scvx_ready)
         return SCPP_E_STATE;
-    SCBuffers b = scBuffers(c);
-    SCvxBuffers v = scvxBuffers(c);
-    const size_t K = size_t(c->K), B = size_t(c->B);
     int n_active = c->last_active;
-    // every round = one sub-problem solve of every active instance; instances whose previous candidate was rejected
-    // re-solve on their old discretisation (needs_disc = 0), the others start a new SCvx iteration
     const long max_rounds = long(c->scvx.max_iterations) * 64;
+    // one stream: measured, the two-stream skewed pipeline of scpp_hip_sc_solve loses here (1914 vs 2174 converged
+    // trajectories/s at 8192): rounds late in the run have few active instances and are latency-bound either way
     for (long round = 0; round < max_rounds && n_active > 0; round++)
     {
-        int rc = discretizeDispatch(c, SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, n_active);
+        int rc = scvxRound(c, fullRange(c));
         if (rc)
             return rc;
-        CHECK_HIP(hipMemcpyAsync(c->vx_Xold, c->X, B * K * 14 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        CHECK_HIP(hipMemcpyAsync(c->vx_Uold, c->U, B * K * 4 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        rc = launchIpm(c, 0, n_active, true);
-        if (rc)
-            return rc;
-        hipLaunchKernelGGL((scvx_cost_kernel<RocketQuatModel>), dim3(unsigned(c->B)), dim3(WAVE), 0, c->stream, b, v,
-                           c->scvx.interpolate_input);
-        hipLaunchKernelGGL(scvx_update_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b, v, c->scvx);
         rc = countActive(c, &n_active);
         if (rc)
             return rc;
         c->last_active = n_active;
     }
     if (c->scvx.nondimensionalize)
-        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
+        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
     CHECK_HIP(hipStreamSynchronize(c->stream));
     if (n_converged)
     {

@@ -297,3 +297,4 @@ def test_pipelined_loop_equals_single_stream_loop(model, hip_lib):
         for key in ("X", "U", "sigma", "sc_iters", "ipm_iters", "status", "converged"):
             assert np.array_equal(a[key][lo:lo + 512], b[key]), (lo, key)
     small.ctx.close()
+
