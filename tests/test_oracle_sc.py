@@ -72,3 +72,19 @@ def test_warm_started_ipm_reproduces_cold_start_trajectories(oracle, monkeypatch
         assert abs(cold[2] - warm[2]) <= 1e-6 * cold[2]
         assert np.allclose(cold[4], warm[4], rtol=1e-4, atol=1e-8)   # virtual-control norm per SC iteration
         assert warm[3] < 0.6 * cold[3]                                # interior-point iterations
+
+
+def test_literal_ecos_style_solver_tracks_the_structured_twin_through_the_whole_sc_run(oracle):
+    """Independent check of the structured formulation INCLUDING its warm starts: the literal standard-form problem solved
+    cold by the ECOS-style solver, 15 SC iterations at the reference's shipped K = 15, against the warm-started twin.
+    The two solvers stop at different accuracies and the SC map amplifies that, hence the loose tolerances."""
+    a = oracle.SC(oracle.ROCKETQUAT, K=15); a.set_solver(0); a.set_tolerances(1e-8, 1e-7, 1e-7, 100)
+    b = oracle.SC(oracle.ROCKETQUAT, K=15); b.set_solver(1)
+    assert a.solve() == 0 and b.solve() == 0
+    ia, ib = a.info(), b.info()
+    assert len(ia) == len(ib) == 15
+    assert np.allclose(ia[:, 0], ib[:, 0], rtol=5e-3)   # virtual-control norm per SC iteration
+    assert np.allclose(ia[:, 3], ib[:, 3], rtol=5e-4)   # final time per SC iteration
+    Xa, Ua, ta = a.solution()
+    Xb, Ub, tb = b.solution()
+    assert np.abs(Xa - Xb).max() <= 2e-3 * np.abs(Xb).max()
