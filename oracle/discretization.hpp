@@ -7,6 +7,7 @@
 // Follows the reference formulation literally: augmented state V = [x | Phi | V_B | V_C | V_s | V_z],
 // Phi^-1 by partial-pivot LU each RHS evaluation (Eigen's fixed-size inverse), RKF78 x 5 steps,
 // post-multiplication by Phi(dt).
+// Parity status: PINNED by tests/golden/rocketquat_dd_K15/K50.npz (scipy DOP853, rtol 1e-13, independent ODE formulation).
 #pragma once
 #include <cmath>
 #include <vector>

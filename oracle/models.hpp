@@ -7,6 +7,8 @@
 // Reference quirks are reproduced on purpose: w.cross(w)==0, k/K interpolation,
 // (T_max-T_min)/2 initial thrust for RocketQuat, un-normalised quaternion rotation matrix,
 // thrust_const refreshed once per solve().
+// Parity status: PINNED for the flow maps and their Jacobians by tests/golden/*_jacobians.npz (sympy, independent of this
+// code, 1e-13); configuration loading and the quirks are restated from the source only.
 #pragma once
 #include <cmath>
 #include <cstdint>

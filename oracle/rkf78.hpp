@@ -7,6 +7,8 @@
 // i.e. N fixed steps of dt/N:
 //   scpp_core/include/discretizationImplementation.hpp:141,154 (N=5)
 //   scpp_core/src/simulation.cpp:37,41 (N=20)
+// Parity status: PINNED by the Fehlberg 7(8) order conditions and an 8th-order convergence test (tests/test_oracle_rkf78.py);
+// Boost.Odeint itself is absent.
 #pragma once
 #include <vector>
 

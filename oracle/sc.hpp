@@ -5,6 +5,8 @@
 //                                  scpp_core/src/SCAlgorithm.cpp:22-210
 // The sub-problem is re-assembled into standard form every iteration (the reference binds
 // Epigraph `dynpar` pointers into td/dd instead; same numbers).
+// Parity status: UNPINNED (the reference cannot be built or run here and ships no outputs); trajectory initialisation,
+// weight doubling and convergence logic are tested against the statements of the reference source they restate.
 #pragma once
 #include <cstdlib>
 #include <functional>

@@ -9,13 +9,16 @@
 //   - standard form  min c'x  s.t. Ax=b, Gx+s=h, s in K = R+^l x Q^{q1} x ... ;
 //   - homogeneous self-dual embedding (tau, kappa), Nesterov-Todd scaling,
 //     Mehrotra predictor-corrector, step factor 0.99, sigma=(1-alpha_aff)^3;
-//   - ONE sparse LDL' of the regularised KKT matrix per iteration (static reg 7e-8),
+//   - ONE sparse LDL' of the regularised KKT matrix per iteration (ECOS: static reg 7e-8; here 1e-9 plus a sign-aware
+//     dynamic regularisation),
 //     iterative refinement against the un-regularised system;
 //   - termination feastol=abstol=reltol=1e-8 (ECOS upstream defaults).
 // Differences from ECOS that do not change the optimum: no Ruiz equilibration, dense W^2
 // blocks instead of ECOS's sparse cone expansion, elimination order supplied by the
 // problem builder (stage-interleaved) instead of AMD.
 // PARITY UNPINNED at this boundary: no ECOS binary/golden vector exists to pin against.
+// Parity status: UNPINNED -- no ECOS binary, source or reference output exists in this environment; pinned only against
+// problems with known optima (tests/test_oracle_socp.py) and against the independent structured solver.
 #pragma once
 #include <algorithm>
 #include <cassert>

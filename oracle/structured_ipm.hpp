@@ -13,6 +13,8 @@
 // WITHOUT the self-dual embedding (sub-problems are feasible by construction: virtual control).
 // Used (a) as the numerically robust CPU oracle for full SC solves and (b) as the line-by-line
 // parity reference of the HIP kernel.
+// Parity status: UNPINNED at the ECOS boundary (see socp.hpp); cross-checked against the literal standard-form solver
+// (first sub-problem 2e-6, whole SC run at K = 15) and used as the iterate-level twin of the HIP kernel.
 #pragma once
 #include <algorithm>
 #include <cmath>
