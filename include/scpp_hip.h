@@ -22,6 +22,13 @@
  *   buildSCvxProblem
  *   SC_sim closed loop (warm start, plant  scpp/src/SC_sim.cpp:28-66            scpp_hip_sc_setup(warm_start=1),
  *   step, stop rule)                                                            scpp_hip_simulate, scpp_hip_sc_set_active
+ *   MPCAlgorithm::initialize               scpp_core/src/MPCAlgorithm.cpp:34-69  scpp_hip_mpc_setup, scpp_hip_mpc_get_model
+ *     exactLinearDiscretization           scpp_core/src/discretization.cpp:9-40
+ *   MPCAlgorithm::setInitialState/        scpp_core/src/MPCAlgorithm.cpp:71-139 scpp_hip_mpc_solve, scpp_hip_mpc_download
+ *     setFinalState/solve/getSolution on  MPCProblem.cpp:6-87,
+ *     buildMPCProblem + Rocket2d          scpp_models/src/rocket2d.cpp:40-84
+ *     constraints
+ *   MPC_sim closed loop                    scpp/src/MPC_sim.cpp:16-86            scpp_hip_mpc_sim, scpp_hip_mpc_sim_download
  *
  * Conventions: every function returns 0 on success or a negative SCPP_E_* code; nothing throws or
  * exits.  One context per GPU, one host thread per context.  All host buffers are caller-owned,
@@ -51,6 +58,23 @@ extern "C"
 #define SCPP_E_STATE -4
 
     typedef struct scpp_hip_ctx scpp_hip_ctx;
+
+    /* MPC.info (MPCAlgorithm.cpp:17-32) + the Rocket2d data the controller reads (rocket2d.cpp:40-84), SI units, radians */
+    typedef struct
+    {
+        int32_t K;                 /* 3..8: the eliminated problem has 2(K-1)+2 <= 16 variables (one FP64 MFMA tile) */
+        int32_t nondimensionalize; /* must be 0 (shipped; the reference discretises before it would rescale) */
+        int32_t constant_dynamics; /* must be 1 (shipped) */
+        int32_t intermediate_cost_active; /* must be 0 (shipped; MPCProblem.cpp:67 is out of bounds otherwise) */
+        double time_horizon;
+        double state_weights_intermediate[6], state_weights_terminal[6], input_weights[2];
+        double x_eq[6], u_eq[2];   /* getOperatingPoint (rocket2d.cpp:40-44) */
+        double tan_gamma_gs, theta_max, w_B_max, gimbal_max, T_min, T_max; /* addApplicationConstraints (rocket2d.cpp:62-83);
+                                      constrain_initial_final must be off for MPC (model.info:55-58) */
+        double x_scale_ref;        /* position magnitude used to scale the error-cost variable, e.g. |r_init| */
+        double feastol, abstol, reltol; /* <= 0: 1e-8 (ECOS defaults) */
+        int32_t maxit;                  /* <= 0: 50 */
+    } scpp_mpc_opts;
 
     /* RocketQuat::Parameters after loadFromFile (rocketQuat.cpp:234-289): SI units, angles in radians */
     typedef struct
@@ -137,6 +161,27 @@ extern "C"
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                           int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);
     int scpp_hip_download_socp_info(scpp_hip_ctx *ctx, double *info /* [B][32]: pcost,gap,pres,dres,iters,status,norm1_nu,sum_delta, then 24 profiling slots */);
+
+    /* ---- MPCAlgorithm boundary (Rocket2D, linear MPC with constant dynamics).  mpc_setup = MPCAlgorithm::initialize:
+       exact discretisation at the operating point on the host (one 8x8 matrix exponential) and elimination of the states;
+       mpc_solve = setInitialState + setFinalState + solve for B independent controllers, one wavefront each.
+       status: 0 optimal, 1 reduced accuracy (ECOS "close to optimal"), -1 iteration limit, -2 numerics, -3 the given state
+       violates its own glide-slope / tilt / rate constraint (the reference problem is then infeasible).  A failed solve
+       leaves that instance's X / U untouched. ---- */
+    int scpp_hip_mpc_setup(scpp_hip_ctx *ctx, const scpp_mpc_opts *opts, const double *flow_par /* [6] rocket2d.cpp:143-148 */);
+    int scpp_hip_mpc_get_model(scpp_hip_ctx *ctx, double *A /* [6][6] */, double *B /* [6][2] */, double *z /* [6] */);
+    int scpp_hip_mpc_solve(scpp_hip_ctx *ctx, const double *x_init /* [B][6] */, const double *x_final /* [B][6] */, int B,
+                           int *n_solved /* status >= 0 */);
+    int scpp_hip_mpc_download(scpp_hip_ctx *ctx, double *X /* [B][K][6] */, double *U /* [B][K-1][2] */,
+                              double *cost /* [B][2]: input_cost, error_cost */, int32_t *status, int32_t *iters);
+    /* MPC_sim.cpp:49-86 for B closed loops, entirely on the device: solve at the current state, advance the plant by
+       time_step under the PREVIOUS input (scpp::simulate), then apply u = U[0] (a failed solve holds the previous input);
+       a loop retires when |x - x_final| < stop_tol or its clock reaches sim_time.  The reference advances by the measured
+       solve time floored at 10 ms (MPC_sim.cpp:62-67); here the step is the given constant.  max_steps <= 0: no cap. */
+    int scpp_hip_mpc_sim(scpp_hip_ctx *ctx, const double *x_start /* [B][6] */, const double *x_final /* [B][6] */, int B,
+                         double time_step, double sim_time, double stop_tol, int max_steps, int *n_reached);
+    int scpp_hip_mpc_sim_download(scpp_hip_ctx *ctx, double *x /* [B][6] */, double *u /* [B][2] */, double *t /* [B] */,
+                                  int32_t *steps, int32_t *failed_solves, int32_t *ipm_iters, int32_t *reached);
 
     /* ---- plumbing ---- */
     int scpp_hip_get_timing(scpp_hip_ctx *ctx, scpp_timing *out, int reset);

@@ -11,6 +11,7 @@
 #include "sc.hpp"
 #include "sc_sim.hpp"
 #include "scvx.hpp"
+#include "mpc.hpp"
 #include "socp.hpp"
 
 using namespace oracle;
@@ -631,5 +632,96 @@ int oracle_scvx_get_info(void *h, double *rows, int max_rows)
         r[8] = f.exitflag;
     }
     return n;
+}
+}
+
+// ---- linear MPC (oracle/mpc.hpp) ----
+namespace
+{
+struct MPCHandle
+{
+    std::shared_ptr<Rocket2d> model;
+    std::unique_ptr<MPCAlgorithm> alg;
+};
+} // namespace
+extern "C"
+{
+// exp(A), n x n row-major
+void oracle_expm(int n, const double *A, double *E)
+{
+    const std::vector<double> r = expm(n, std::vector<double>(A, A + size_t(n) * n));
+    std::memcpy(E, r.data(), r.size() * sizeof(double));
+}
+void *oracle_mpc_create(const char *config_root)
+{
+    try
+    {
+        auto h = new MPCHandle;
+        const std::string folder = std::string(config_root) + "/Rocket2D";
+        h->model = std::make_shared<Rocket2d>();
+        h->model->loadParameters(folder);
+        h->model->p.constrain_initial_final = false; // model.info: "enable for SC and disable for MPC/LQR"
+        h->alg.reset(new MPCAlgorithm(h->model, folder));
+        h->alg->initialize();
+        return h;
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_mpc_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void oracle_mpc_destroy(void *h) { delete static_cast<MPCHandle *>(h); }
+int oracle_mpc_K(void *h) { return int(static_cast<MPCHandle *>(h)->alg->K); }
+void oracle_mpc_get_model(void *h, double *A, double *B, double *z, double *x_init, double *x_final)
+{
+    auto &a = *static_cast<MPCHandle *>(h)->alg;
+    std::memcpy(A, a.A, sizeof a.A);
+    std::memcpy(B, a.B, sizeof a.B);
+    std::memcpy(z, a.z, sizeof a.z);
+    std::memcpy(x_init, a.model->p.x_init, 6 * sizeof(double));
+    std::memcpy(x_final, a.model->p.x_final, 6 * sizeof(double));
+}
+void oracle_mpc_set_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
+{
+    static_cast<MPCHandle *>(h)->alg->setTolerances(feastol, abstol, reltol, maxit);
+}
+// one solve; kind 0 literal (reference formulation, generic solver), 1 condensed twin.  info: [iters, pres, dres, gap, pcost, input_cost, error_cost]
+int oracle_mpc_solve(void *h, int kind, const double *x_init, const double *x_final, double *X, double *U, double *info)
+{
+    auto &a = *static_cast<MPCHandle *>(h)->alg;
+    a.solver_kind = kind;
+    a.setInitialState(x_init);
+    a.setFinalState(x_final);
+    const int st = a.solve();
+    if (st >= 0)
+    {
+        std::memcpy(X, a.X.data(), a.X.size() * sizeof(double));
+        std::memcpy(U, a.U.data(), a.U.size() * sizeof(double));
+    }
+    info[0] = a.last.iters;
+    info[1] = a.last.pres;
+    info[2] = a.last.dres;
+    info[3] = a.last.gap;
+    info[4] = a.last.pcost;
+    info[5] = a.input_cost;
+    info[6] = a.error_cost;
+    return st;
+}
+// closed loop (MPC_sim.cpp:49-86, deterministic step); out: x [6], u [2], meta [steps, failed, ipm_iters, reached]
+void oracle_mpc_sim(void *h, int kind, const double *x_start, double sim_time, double time_step, int max_steps, double *x,
+                    double *u, int *meta)
+{
+    auto &a = *static_cast<MPCHandle *>(h)->alg;
+    a.solver_kind = kind;
+    const MPCSimResult r = runMPCSim(a, x_start, sim_time, time_step, max_steps > 0 ? max_steps : (1 << 30));
+    for (int i = 0; i < 6; i++)
+        x[i] = r.steps ? r.X_sim[size_t(r.steps - 1) * 6 + i] : x_start[i];
+    for (int i = 0; i < 2; i++)
+        u[i] = r.steps ? r.U_sim[size_t(r.steps - 1) * 2 + i] : 0.;
+    meta[0] = r.steps;
+    meta[1] = r.failed_solves;
+    meta[2] = r.ipm_iters;
+    meta[3] = int(r.reached);
 }
 }

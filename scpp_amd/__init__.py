@@ -17,7 +17,9 @@ from ._lib import (  # noqa: F401
     load_library,
 )
 from .parameter_server import ParameterServer  # noqa: F401
-from .models import RocketQuat, counter_uniform  # noqa: F401
+from .models import Rocket2D, RocketQuat, counter_uniform  # noqa: F401
 from .sc_algorithm import SCAlgorithm, load_sc_opts  # noqa: F401
 from .sc_sim import SCSim, interpolated_input  # noqa: F401
 from .scvx_algorithm import SCvxAlgorithm, load_scvx_opts  # noqa: F401
+from .mpc_algorithm import MPCAlgorithm, MPCSim  # noqa: F401
+from ._lib import MpcOpts  # noqa: F401

@@ -63,6 +63,19 @@ class SCvxOpts(C.Structure):
     ]
 
 
+class MpcOpts(C.Structure):
+    """scpp_mpc_opts (MPC.info, MPCAlgorithm.cpp:17-32, + the Rocket2d data of rocket2d.cpp:40-84)"""
+    _fields_ = [
+        ("K", C.c_int32), ("nondimensionalize", C.c_int32), ("constant_dynamics", C.c_int32), ("intermediate_cost_active", C.c_int32),
+        ("time_horizon", C.c_double),
+        ("state_weights_intermediate", C.c_double * 6), ("state_weights_terminal", C.c_double * 6), ("input_weights", C.c_double * 2),
+        ("x_eq", C.c_double * 6), ("u_eq", C.c_double * 2),
+        ("tan_gamma_gs", C.c_double), ("theta_max", C.c_double), ("w_B_max", C.c_double), ("gimbal_max", C.c_double),
+        ("T_min", C.c_double), ("T_max", C.c_double), ("x_scale_ref", C.c_double),
+        ("feastol", C.c_double), ("abstol", C.c_double), ("reltol", C.c_double), ("maxit", C.c_int32),
+    ]
+
+
 class SocpOpts(C.Structure):
     _fields_ = [
         ("feastol", C.c_double),
@@ -93,6 +106,8 @@ SYMBOLS = [
     "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
+    "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
+    "scpp_hip_mpc_sim_download",
 ]
 
 
@@ -222,6 +237,49 @@ class Context:
         tr, cost, solves, dec = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
         _chk(self.lib.scpp_hip_scvx_download_state(self.h, _p(tr), _p(cost), _p(solves), _p(dec)), "scvx_download_state")
         return dict(trust_region=tr, nonlinear_cost=cost, solves=solves, last_decision=dec)
+
+    # ---- MPC boundary (Rocket2D) ----
+    def mpc_setup(self, opts, flow_par):
+        flow_par = np.ascontiguousarray(flow_par, dtype=np.float64).reshape(6)
+        self._mpc_K = int(opts.K)
+        _chk(self.lib.scpp_hip_mpc_setup(self.h, C.byref(opts), _p(flow_par)), "mpc_setup")
+
+    def mpc_model(self):
+        A, Bm, z = np.zeros((6, 6)), np.zeros((6, 2)), np.zeros(6)
+        _chk(self.lib.scpp_hip_mpc_get_model(self.h, _p(A), _p(Bm), _p(z)), "mpc_get_model")
+        return A, Bm, z
+
+    def mpc_solve(self, x_init, x_final):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 6)
+        B = x_init.shape[0]
+        x_final = np.ascontiguousarray(np.broadcast_to(np.asarray(x_final, dtype=np.float64).reshape(-1, 6), (B, 6)))
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_mpc_solve(self.h, _p(x_init), _p(x_final), int(B), C.byref(n)), "mpc_solve")
+        self._mpc_B = B
+        return n.value
+
+    def mpc_download(self):
+        B, K = self._mpc_B, self._mpc_K
+        out = dict(X=np.zeros((B, K, 6)), U=np.zeros((B, K - 1, 2)), cost=np.zeros((B, 2)), status=np.zeros(B, dtype=np.int32),
+                   iters=np.zeros(B, dtype=np.int32))
+        _chk(self.lib.scpp_hip_mpc_download(self.h, _p(out["X"]), _p(out["U"]), _p(out["cost"]), _p(out["status"]), _p(out["iters"])),
+             "mpc_download")
+        return out
+
+    def mpc_sim(self, x_start, x_final, time_step=0.010, sim_time=15.0, stop_tol=0.02, max_steps=0):
+        x_start = np.ascontiguousarray(x_start, dtype=np.float64).reshape(-1, 6)
+        B = x_start.shape[0]
+        x_final = np.ascontiguousarray(np.broadcast_to(np.asarray(x_final, dtype=np.float64).reshape(-1, 6), (B, 6)))
+        n = C.c_int(0)
+        _chk(self.lib.scpp_hip_mpc_sim(self.h, _p(x_start), _p(x_final), int(B), C.c_double(time_step), C.c_double(sim_time),
+                                       C.c_double(stop_tol), int(max_steps), C.byref(n)), "mpc_sim")
+        self._mpc_B = B
+        out = dict(x=np.zeros((B, 6)), u=np.zeros((B, 2)), t=np.zeros(B), steps=np.zeros(B, dtype=np.int32),
+                   failed_solves=np.zeros(B, dtype=np.int32), ipm_iters=np.zeros(B, dtype=np.int32), reached=np.zeros(B, dtype=np.int32))
+        _chk(self.lib.scpp_hip_mpc_sim_download(self.h, _p(out["x"]), _p(out["u"]), _p(out["t"]), _p(out["steps"]),
+                                                _p(out["failed_solves"]), _p(out["ipm_iters"]), _p(out["reached"])), "mpc_sim_download")
+        out["n_reached"] = n.value
+        return out
 
     def sc_finish(self):
         n = C.c_int(0)

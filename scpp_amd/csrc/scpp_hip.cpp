@@ -2,7 +2,9 @@
 // -DSCPP_HIP_EMU, by g++ against tests/emu/hip_emu.h (CPU-side kernel unit tests only).
 #include "../../include/scpp_hip.h"
 
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -12,6 +14,8 @@
 #include "model_rocketquat.h"
 #include "sc_kernels.h"
 #include "scvx_kernels.h"
+#include "mpc_kernel.h"
+#include "mpc_setup.h"
 
 using namespace scpp;
 
@@ -44,6 +48,13 @@ struct scpp_hip_ctx
     int *vx_has_last = nullptr, *vx_needs_disc = nullptr, *vx_solves = nullptr;
     scpp_scvx_opts scvx{};
     bool scvx_ready = false;
+    // linear MPC state (allocated on first mpc_setup)
+    mpc::MpcConst *mpc_const = nullptr;
+    mpc::MpcConst *mpc_host = nullptr;
+    double *mpc_xf = nullptr, *mpc_x0 = nullptr, *mpc_U = nullptr, *mpc_X = nullptr, *mpc_cost = nullptr, *mpc_uheld = nullptr, *mpc_t = nullptr;
+    int *mpc_status = nullptr, *mpc_iters = nullptr, *mpc_steps = nullptr, *mpc_failed = nullptr, *mpc_ipm = nullptr, *mpc_reached = nullptr;
+    bool mpc_ready = false;
+    int mpc_B = 0;
     // simulate scratch
     double *sim_dt = nullptr, *sim_u0 = nullptr, *sim_u1 = nullptr, *sim_x = nullptr;
     scpp_sc_opts sc{};
@@ -381,7 +392,11 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
     void *ptrs[] = {c->X, c->U, c->sigma, c->par, c->A, c->Bm, c->C, c->S, c->Z, c->x_init, c->ip, c->uhat, c->wtrx, c->ws,
                     c->dbg, c->active, c->converged, c->sc_iters, c->ipm_iters, c->status, c->counter, c->norm1_nu,
                     c->sum_delta, c->delta_sigma, c->sim_dt, c->sim_u0, c->sim_u1, c->sim_x, c->vx_Xold, c->vx_Uold, c->vx_tr,
-                    c->vx_last, c->vx_cost, c->vx_info, c->vx_has_last, c->vx_needs_disc, c->vx_solves, c->ipm_warm};
+                    c->vx_last, c->vx_cost, c->vx_info, c->vx_has_last, c->vx_needs_disc, c->vx_solves, c->ipm_warm,
+                    c->mpc_const, c->mpc_xf, c->mpc_x0, c->mpc_U, c->mpc_X, c->mpc_cost, c->mpc_uheld, c->mpc_t, c->mpc_status,
+                    c->mpc_iters, c->mpc_steps, c->mpc_failed, c->mpc_ipm, c->mpc_reached};
+    delete c->mpc_host;
+    c->mpc_host = nullptr;
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -862,6 +877,220 @@ int scpp_hip_download_socp_info(scpp_hip_ctx *c, double *info)
     CHECK_HIP(hipMemcpy(info, c->dbg, size_t(c->B) * 32 * sizeof(double), hipMemcpyDeviceToHost));
     return SCPP_OK;
 }
+
+// ---- linear MPC (Rocket2D): MPCAlgorithm.cpp:34-139, MPC_sim.cpp:49-86 ----
+int scpp_hip_mpc_setup(scpp_hip_ctx *c, const scpp_mpc_opts *o, const double *flow_par)
+{
+    if (!c || !o || !flow_par)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKET2D)
+        return SCPP_E_UNSUPPORTED;
+    if (!c->mpc_host)
+        c->mpc_host = new (std::nothrow) mpc::MpcConst;
+    if (!c->mpc_host)
+        return SCPP_E_HIP;
+    c->mpc_ready = false;
+    const int rc = mpc::buildMpcConst(*o, flow_par, *c->mpc_host);
+    if (rc != SCPP_OK)
+        return rc;
+    if (!c->mpc_const)
+    {
+        const size_t B = size_t(c->Bmax);
+        int a = 0;
+        a |= devAlloc(&c->mpc_const, 1);
+        a |= devAlloc(&c->mpc_xf, B * mpc::NX);
+        a |= devAlloc(&c->mpc_x0, B * mpc::NX);
+        a |= devAlloc(&c->mpc_U, B * mpc::NMAX * mpc::NU);
+        a |= devAlloc(&c->mpc_X, B * mpc::KMAX * mpc::NX);
+        a |= devAlloc(&c->mpc_cost, B * 2);
+        a |= devAlloc(&c->mpc_uheld, B * mpc::NU);
+        a |= devAlloc(&c->mpc_t, B);
+        a |= devAlloc(&c->mpc_status, B);
+        a |= devAlloc(&c->mpc_iters, B);
+        a |= devAlloc(&c->mpc_steps, B);
+        a |= devAlloc(&c->mpc_failed, B);
+        a |= devAlloc(&c->mpc_ipm, B);
+        a |= devAlloc(&c->mpc_reached, B);
+        if (a)
+            return SCPP_E_HIP;
+    }
+    CHECK_HIP(hipMemcpyAsync(c->mpc_const, c->mpc_host, sizeof(mpc::MpcConst), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->par, flow_par, size_t(c->np) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->par_from_ip = false;
+    c->mpc_ready = true;
+    c->mpc_B = 0;
+    return SCPP_OK;
+}
+
+int scpp_hip_mpc_get_model(scpp_hip_ctx *c, double *A, double *B, double *z)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    if (!c->mpc_ready)
+        return SCPP_E_STATE;
+    if (A)
+        std::memcpy(A, c->mpc_host->A, sizeof c->mpc_host->A);
+    if (B)
+        std::memcpy(B, c->mpc_host->B, sizeof c->mpc_host->B);
+    if (z)
+        std::memcpy(z, c->mpc_host->z, sizeof c->mpc_host->z);
+    return SCPP_OK;
+}
+
+namespace
+{
+void launchMpcSolve(scpp_hip_ctx *c, const double *x0, const int *active, int B)
+{
+    hipLaunchKernelGGL(mpc::mpc_solve_kernel, dim3(unsigned(B)), dim3(64), 0, c->stream, (const mpc::MpcConst *)c->mpc_const, x0,
+                       (const double *)c->mpc_xf, c->mpc_U, c->mpc_X, c->mpc_cost, c->mpc_status, c->mpc_iters, active, B);
+}
+} // namespace
+
+int scpp_hip_mpc_solve(scpp_hip_ctx *c, const double *x_init, const double *x_final, int B, int *n_solved)
+{
+    if (!c || !x_init || !x_final || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (!c->mpc_ready)
+        return SCPP_E_STATE;
+    CHECK_HIP(hipMemcpyAsync(c->mpc_x0, x_init, size_t(B) * mpc::NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->mpc_xf, x_final, size_t(B) * mpc::NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->mpc_B != B)
+    {
+        // a failed solve leaves X / U untouched: define them for the first use
+        CHECK_HIP(hipMemsetAsync(c->mpc_U, 0, size_t(B) * mpc::NMAX * mpc::NU * sizeof(double), c->stream));
+        CHECK_HIP(hipMemsetAsync(c->mpc_X, 0, size_t(B) * mpc::KMAX * mpc::NX * sizeof(double), c->stream));
+        CHECK_HIP(hipMemsetAsync(c->mpc_cost, 0, size_t(B) * 2 * sizeof(double), c->stream));
+        c->mpc_B = B;
+    }
+    spanBegin(c, 1, B, c->stream);
+    launchMpcSolve(c, c->mpc_x0, nullptr, B);
+    spanEnd(c, c->stream);
+    CHECK_HIP(hipGetLastError());
+    if (n_solved)
+    {
+        const size_t nb = size_t(B);
+        std::vector<int> st(nb);
+        CHECK_HIP(hipMemcpyAsync(st.data(), c->mpc_status, size_t(B) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        CHECK_HIP(hipStreamSynchronize(c->stream));
+        int n = 0;
+        for (int v : st)
+            n += v >= 0;
+        *n_solved = n;
+    }
+    return SCPP_OK;
+}
+
+int scpp_hip_mpc_download(scpp_hip_ctx *c, double *X, double *U, double *cost, int32_t *status, int32_t *iters)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    if (!c->mpc_ready || c->mpc_B < 1)
+        return SCPP_E_STATE;
+    const int B = c->mpc_B, K = c->mpc_host->K, N = K - 1;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (X)
+        CHECK_HIP(hipMemcpy2D(X, size_t(K) * mpc::NX * sizeof(double), c->mpc_X, size_t(mpc::KMAX) * mpc::NX * sizeof(double),
+                              size_t(K) * mpc::NX * sizeof(double), size_t(B), hipMemcpyDeviceToHost));
+    if (U)
+        CHECK_HIP(hipMemcpy2D(U, size_t(N) * mpc::NU * sizeof(double), c->mpc_U, size_t(mpc::NMAX) * mpc::NU * sizeof(double),
+                              size_t(N) * mpc::NU * sizeof(double), size_t(B), hipMemcpyDeviceToHost));
+    if (cost)
+        CHECK_HIP(hipMemcpy(cost, c->mpc_cost, size_t(B) * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (status)
+        CHECK_HIP(hipMemcpy(status, c->mpc_status, size_t(B) * sizeof(int), hipMemcpyDeviceToHost));
+    if (iters)
+        CHECK_HIP(hipMemcpy(iters, c->mpc_iters, size_t(B) * sizeof(int), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
+int scpp_hip_mpc_sim(scpp_hip_ctx *c, const double *x_start, const double *x_final, int B, double time_step, double sim_time,
+                     double stop_tol, int max_steps, int *n_reached)
+{
+    if (!c || !x_start || !x_final || B < 1 || B > c->Bmax || !(time_step > 0.) || !(sim_time > 0.))
+        return SCPP_E_ARG;
+    if (!c->mpc_ready)
+        return SCPP_E_STATE;
+    const size_t nb = size_t(B);
+    CHECK_HIP(hipMemcpyAsync(c->sim_x, x_start, nb * mpc::NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->mpc_xf, x_final, nb * mpc::NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    {
+        std::vector<double> dtv(nb, time_step);
+        std::vector<int> one(nb, 1);
+        CHECK_HIP(hipMemcpyAsync(c->sim_dt, dtv.data(), nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CHECK_HIP(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    CHECK_HIP(hipMemsetAsync(c->mpc_uheld, 0, nb * mpc::NU * sizeof(double), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->mpc_t, 0, nb * sizeof(double), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->mpc_U, 0, nb * mpc::NMAX * mpc::NU * sizeof(double), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->mpc_X, 0, nb * mpc::KMAX * mpc::NX * sizeof(double), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->mpc_cost, 0, nb * 2 * sizeof(double), c->stream));
+    for (int *p : {c->mpc_steps, c->mpc_failed, c->mpc_ipm, c->mpc_reached, c->mpc_status, c->mpc_iters})
+        CHECK_HIP(hipMemsetAsync(p, 0, nb * sizeof(int), c->stream));
+    c->mpc_B = B;
+    const unsigned grid = unsigned((B + 63) / 64);
+    const long cap = max_steps > 0 ? long(max_steps) : long(std::ceil(sim_time / time_step)) + 2;
+    for (long step = 0; step < cap; step++)
+    {
+        launchMpcSolve(c, c->sim_x, c->active, B);
+        hipLaunchKernelGGL((simulate_kernel<Rocket2dModel>), dim3(grid), dim3(64), 0, c->stream, B, (const double *)c->par, 0,
+                           (const double *)c->sim_dt, (const double *)c->mpc_uheld, (const double *)c->mpc_uheld, c->sim_x,
+                           (const int *)c->active);
+        CHECK_HIP(hipMemsetAsync(c->counter, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(mpc::mpc_sim_advance_kernel, dim3(grid), dim3(64), 0, c->stream, B, (const double *)c->mpc_U,
+                           (const int *)c->mpc_status, (const int *)c->mpc_iters, (const double *)c->sim_x,
+                           (const double *)c->mpc_xf, c->mpc_uheld, c->active, c->mpc_steps, c->mpc_failed, c->mpc_ipm,
+                           c->mpc_reached, c->mpc_t, time_step, sim_time, stop_tol, c->counter);
+        if ((step & 15) == 15 || step + 1 == cap)
+        {
+            int n = 0;
+            CHECK_HIP(hipMemcpyAsync(&n, c->counter, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            CHECK_HIP(hipStreamSynchronize(c->stream));
+            if (n == 0)
+                break;
+        }
+    }
+    CHECK_HIP(hipGetLastError());
+    if (n_reached)
+    {
+        std::vector<int> r(nb);
+        CHECK_HIP(hipMemcpyAsync(r.data(), c->mpc_reached, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        CHECK_HIP(hipStreamSynchronize(c->stream));
+        int n = 0;
+        for (int v : r)
+            n += v;
+        *n_reached = n;
+    }
+    return SCPP_OK;
+}
+
+int scpp_hip_mpc_sim_download(scpp_hip_ctx *c, double *x, double *u, double *t, int32_t *steps, int32_t *failed_solves,
+                              int32_t *ipm_iters, int32_t *reached)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    if (!c->mpc_ready || c->mpc_B < 1)
+        return SCPP_E_STATE;
+    const size_t nb = size_t(c->mpc_B);
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (x)
+        CHECK_HIP(hipMemcpy(x, c->sim_x, nb * mpc::NX * sizeof(double), hipMemcpyDeviceToHost));
+    if (u)
+        CHECK_HIP(hipMemcpy(u, c->mpc_uheld, nb * mpc::NU * sizeof(double), hipMemcpyDeviceToHost));
+    if (t)
+        CHECK_HIP(hipMemcpy(t, c->mpc_t, nb * sizeof(double), hipMemcpyDeviceToHost));
+    if (steps)
+        CHECK_HIP(hipMemcpy(steps, c->mpc_steps, nb * sizeof(int), hipMemcpyDeviceToHost));
+    if (failed_solves)
+        CHECK_HIP(hipMemcpy(failed_solves, c->mpc_failed, nb * sizeof(int), hipMemcpyDeviceToHost));
+    if (ipm_iters)
+        CHECK_HIP(hipMemcpy(ipm_iters, c->mpc_ipm, nb * sizeof(int), hipMemcpyDeviceToHost));
+    if (reached)
+        CHECK_HIP(hipMemcpy(reached, c->mpc_reached, nb * sizeof(int), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
 
 int scpp_hip_get_timing(scpp_hip_ctx *c, scpp_timing *out, int reset)
 {

@@ -107,3 +107,69 @@ class RocketQuat:
         r_s = float(np.linalg.norm(x[1:4])) if nondimensionalize else 1.0
         p = self.p
         return np.array([p.alpha_m * r_s] + [g / r_s for g in p.g_I] + [j / (m_s * r_s * r_s) for j in p.J_B] + [r / r_s for r in p.r_T_B])
+
+
+class Rocket2DParameters:
+    """Rocket2d::Parameters after loadFromFile (rocket2d.cpp:150-198): SI units, radians."""
+
+
+class Rocket2D:
+    """Host-side configuration half of the Rocket2d plugin (scpp_models/src/rocket2d.cpp:40-44,143-198); the flow map is
+    device code (csrc/model_rocketquat.h: Rocket2dModel)."""
+    modelName = "Rocket2D"
+    state_dim, input_dim, param_dim = 6, 2, 6
+
+    def __init__(self, param_folder=CONFIG_ROOT):
+        self.param_folder = param_folder
+        self.p = None
+
+    def getParameterFolder(self):
+        return os.path.join(self.param_folder, self.modelName)
+
+    def loadParameters(self):
+        ps = ParameterServer(os.path.join(self.getParameterFolder(), "model.info"))
+        d2r = math.pi / 180.0
+        p = Rocket2DParameters()
+        p.g_I = ps.load_vector("g_I", 2)
+        p.J_B = ps.load_scalar("J_B")
+        p.r_T_B = ps.load_vector("r_T_B", 2)
+        p.m = ps.load_scalar("m")
+        p.T_min, p.T_max = ps.load_scalar("T_min"), ps.load_scalar("T_max")
+        p.gamma_gs = ps.load_scalar("gamma_gs") * d2r
+        p.gimbal_max = ps.load_scalar("gimbal_max") * d2r
+        p.theta_max = ps.load_scalar("theta_max") * d2r
+        p.w_B_max = ps.load_scalar("w_B_max") * d2r
+        p.final_time = ps.load_scalar("final_time")
+        p.constrain_initial_final = ps.load_scalar("constrain_initial_final", bool)
+        p.add_slack_variables = ps.load_scalar("add_slack_variables", bool)
+        p.x_init = np.array(ps.load_vector("r_init", 2) + ps.load_vector("v_init", 2)
+                            + [ps.load_scalar("eta_init") * d2r, ps.load_scalar("w_init") * d2r])
+        p.x_final = np.array(ps.load_vector("r_final", 2) + ps.load_vector("v_final", 2)
+                             + [ps.load_scalar("eta_final") * d2r, ps.load_scalar("w_final") * d2r])
+        p.tan_gamma_gs = math.tan(p.gamma_gs)
+        self.p = p
+        return self
+
+    def flow_params(self):
+        """getNewModelParameters (rocket2d.cpp:143-148): par = [m, J_B, g_I, r_T_B]"""
+        p = self.p
+        return np.array([p.m, p.J_B, p.g_I[0], p.g_I[1], p.r_T_B[0], p.r_T_B[1]])
+
+    def getOperatingPoint(self):
+        """rocket2d.cpp:40-44.  The reference streams `0, -p.g_I * p.m` (a scalar and a 2-vector) into a 2-vector, which
+        asserts / overruns; the evident intent -- hover thrust (0, -g_y m) -- is what is returned."""
+        return np.zeros(6), np.array([0.0, -self.p.g_I[1] * self.p.m])
+
+    def randomized_initial_states(self, batch, seed=20260927, first=0, spread=1.0):
+        """Synthetic closed-loop start states around the shipped x_init (build-defined; the reference has no recipe for
+        Rocket2D): lateral position and velocity scaled by U(-1,1), descent rate by 1 + 0.2 U, tilt by U(-1,1)."""
+        out = np.zeros((batch, 6))
+        for b in range(batch):
+            i = first + b
+            x = self.p.x_init.copy()
+            x[0] *= spread * counter_uniform(seed, i, 0)
+            x[2] = 0.05 * abs(x[3]) * counter_uniform(seed, i, 1)
+            x[3] *= 1.0 + 0.2 * counter_uniform(seed, i, 2)
+            x[4] *= counter_uniform(seed, i, 3)
+            out[b] = x
+        return out

@@ -311,6 +311,19 @@ inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int)
     return 0;
 }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { return hipMemcpy(d, s, n, 0); }
+inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, int)
+{
+    for (size_t r = 0; r < height; r++)
+        std::memcpy(static_cast<char *>(d) + r * dpitch, static_cast<const char *>(s) + r * spitch, width);
+    return 0;
+}
+// lanes run as fibers of one host thread: a plain read-modify-write is atomic
+inline int atomicAdd(int *p, int v)
+{
+    const int o = *p;
+    *p = o + v;
+    return o;
+}
 inline hipError_t hipMemset(void *d, int v, size_t n)
 {
     std::memset(d, v, n);

@@ -300,3 +300,48 @@ def sc_batch(K, seed, first, count, nthreads=1, solver=1, config_root=CONFIG_ROO
     if rc != 0:
         raise RuntimeError("oracle_sc_batch failed")
     return dict(X=X, U=U, t=t, iters=iters, converged=conv, nu=nu, ipm_iters=ipm)
+
+
+class MPC:
+    """oracle/mpc.hpp: linear MPC on the shipped Rocket2D configuration (kind 0 literal formulation, 1 condensed twin)."""
+
+    def __init__(self, config_root=CONFIG_ROOT):
+        L = lib()
+        L.oracle_mpc_create.restype = C.c_void_p
+        self.h = C.c_void_p(L.oracle_mpc_create(config_root.encode()))
+        if not self.h:
+            raise RuntimeError("oracle_mpc_create failed")
+        self.K = L.oracle_mpc_K(self.h)
+        self.A, self.B, self.z = np.zeros((6, 6)), np.zeros((6, 2)), np.zeros(6)
+        self.x_init, self.x_final = np.zeros(6), np.zeros(6)
+        L.oracle_mpc_get_model(self.h, _p(self.A), _p(self.B), _p(self.z), _p(self.x_init), _p(self.x_final))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_mpc_destroy(self.h)
+            self.h = None
+
+    def set_tolerances(self, feastol=1e-8, abstol=1e-8, reltol=1e-8, maxit=50):
+        lib().oracle_mpc_set_tolerances(self.h, C.c_double(feastol), C.c_double(abstol), C.c_double(reltol), int(maxit))
+
+    def solve(self, x_init, x_final=None, kind=1):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64)
+        x_final = np.ascontiguousarray(self.x_final if x_final is None else x_final, dtype=np.float64)
+        X, U, info = np.zeros((self.K, 6)), np.zeros((self.K - 1, 2)), np.zeros(7)
+        st = lib().oracle_mpc_solve(self.h, int(kind), _p(x_init), _p(x_final), _p(X), _p(U), _p(info))
+        return dict(status=st, X=X, U=U, iters=int(info[0]), pres=info[1], dres=info[2], gap=info[3], pcost=info[4],
+                    input_cost=info[5], error_cost=info[6])
+
+    def sim(self, x_start, sim_time=15.0, time_step=0.010, max_steps=0, kind=1):
+        x_start = np.ascontiguousarray(x_start, dtype=np.float64)
+        x, u, meta = np.zeros(6), np.zeros(2), np.zeros(4, dtype=np.int32)
+        lib().oracle_mpc_sim(self.h, int(kind), _p(x_start), C.c_double(sim_time), C.c_double(time_step), int(max_steps), _p(x), _p(u), _p(meta))
+        return dict(x=x, u=u, steps=int(meta[0]), failed_solves=int(meta[1]), ipm_iters=int(meta[2]), reached=int(meta[3]))
+
+
+def expm(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    E = np.zeros_like(A)
+    lib().oracle_expm(int(n), _p(A), _p(E))
+    return E
