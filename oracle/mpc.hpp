@@ -998,7 +998,7 @@ class MPCAlgorithm
         SocpSolver solver(socp);
         solver.opt.verbose = std::getenv("ORACLE_MPC_VERBOSE") != nullptr;
         SocpResult r = solver.solve();
-        last.status = r.exitflag == 0 ? 0 : (r.exitflag == 1 ? -3 : r.exitflag);
+        last.status = r.exitflag == 0 ? 0 : r.exitflag == 10 ? 1 : r.exitflag == 1 ? -3 : (r.exitflag < 0 ? r.exitflag : -2);
         last.iters = r.iter;
         last.pres = r.pres;
         last.dres = r.dres;

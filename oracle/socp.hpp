@@ -137,7 +137,7 @@ struct SocpSettings
 struct SocpResult
 {
     std::vector<double> x, y, z, s;
-    int exitflag = -1; // 0 optimal, 1 primal infeasible, 2 dual infeasible, -1 maxit, -2 numerics
+    int exitflag = -1; // 0 optimal, 10 optimal to reduced accuracy (ECOS_OPTIMAL + ECOS_INACC_OFFSET), 1 primal infeasible, 2 dual infeasible, -1 maxit, -2 numerics
     int iter = 0;
     double pcost = 0, dcost = 0, pres = 0, dres = 0, gap = 0, relgap = 0, mu = 0;
 };
@@ -937,9 +937,13 @@ inline SocpResult SocpSolver::solve()
                 }
             }
         }
+        // ECOS's reduced-accuracy exit (feastol_inacc 1e-4, abstol_inacc = reltol_inacc = 5e-5): when the iteration limit or a
+        // numerical breakdown is hit at an iterate that already satisfies the relaxed tolerances, ECOS returns it as
+        // "close to optimal" (exitflag ECOS_OPTIMAL + ECOS_INACC_OFFSET = 10) instead of failing
+        const bool inacc_ok = (-cx > 0. || -by - hz >= -5e-5) && pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
         if (iter >= opt.maxit)
         {
-            R.exitflag = -1;
+            R.exitflag = inacc_ok ? 10 : -1;
             break;
         }
 
@@ -951,7 +955,7 @@ inline SocpResult SocpSolver::solve()
         {
             if (opt.verbose)
                 std::printf("numerics: %s\n", e.what());
-            R.exitflag = -2;
+            R.exitflag = inacc_ok ? 10 : -2;
             break;
         }
         delta_dyn = 2 * 1e-9;
@@ -960,7 +964,7 @@ inline SocpResult SocpSolver::solve()
         {
             if (opt.verbose)
                 std::printf("numerics: factorisation failed\n");
-            R.exitflag = -2;
+            R.exitflag = inacc_ok ? 10 : -2;
             break;
         }
 
