@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mpc-batch", type=int, default=32768,
+                    help="size of the extra linear-MPC run (Rocket2D) reported under config.mpc_mode (0 = skip)")
     ap.add_argument("--scvx-batch", type=int, default=8192,
                     help="size of the extra SCvx-mode run reported under config.scvx_mode (0 = skip)")
     args = ap.parse_args()
@@ -192,6 +194,47 @@ def main():
         except Exception as e:  # the headline number must not depend on the extra run
             scvx_report = {"error": str(e)}
 
+    # ---- linear MPC path (Rocket2D, MPCAlgorithm / MPC_sim) on rank 0: one wavefront per controller ----
+    mpc_report = None
+    if rank == 0 and args.mpc_batch > 0:
+        try:
+            m2 = scpp_amd.Rocket2D().loadParameters()
+            m2.p.constrain_initial_final = False  # model.info: "enable for SC and disable for MPC/LQR"
+            Bm = args.mpc_batch
+            malg = scpp_amd.MPCAlgorithm(m2, batch_max=Bm, device=dev.index).initialize()
+            xm = m2.randomized_initial_states(Bm, seed=args.seed)
+            malg.setInitialState(xm); malg.setFinalState(m2.p.x_final)
+            malg.solve()  # warm-up
+            malg.ctx.timing(reset=True)
+            torch.cuda.synchronize()
+            tm0 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                nok = malg.solve()
+            tmw = (time.perf_counter() - tm0) / reps
+            mt = malg.ctx.timing(reset=True)
+            mout = malg.getSolution()
+            Bl, steps_l = min(4096, Bm), 300
+            tl0 = time.perf_counter()
+            lr = scpp_amd.MPCSim(malg, max_steps=steps_l).run(xm[:Bl])
+            tl = time.perf_counter() - tl0
+            mpc_report = {
+                "algorithm": "MPCAlgorithm (scpp_core/src/MPCAlgorithm.cpp) on the shipped Rocket2D MPC.info, K=%d, "
+                             "constant dynamics, cold start per solve" % malg.K,
+                "batch": int(Bm),
+                "solves_per_s": Bm / tmw,
+                "solves_per_s_kernel_only": Bm / (mt["ms_socp"] / mt["n_socp"]) * 1e3,
+                "avg_launch_ms": mt["ms_socp"] / mt["n_socp"],
+                "solved_fraction": nok / Bm,
+                "mean_ipm_iterations": float(mout["iters"].mean()),
+                "closed_loop": {"loops": int(Bl), "steps": steps_l, "controller_steps_per_s": float(lr["steps"].sum()) / tl,
+                                "failed_solves": int(lr["failed_solves"].sum())},
+                "note": "host buffers in, host buffers out (x_init upload and status download inside the wall-clock rate)",
+            }
+            malg.ctx.close()
+        except Exception as e:
+            mpc_report = {"error": str(e)}
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,6 +289,7 @@ def main():
                 "median_final_virtual_control_norm1": float(np.median(stats["nu"])) if stats["nu"] else None,
                 "mfma": True,
                 "scvx_mode": scvx_report,
+                "mpc_mode": mpc_report,
             },
             "roofline": {
                 "kernel": "ipm_kernel (batched structured IPM, one wavefront per instance)",

@@ -14,7 +14,7 @@
 //   slot 1: lanes 2c, 2c+1 glide-slope cone of stage c+1 | lanes 16..22 error cone | lanes 32..32+2N input cone
 //           (every cone inside one group of 16 lanes: cone sums are 4 xor-shuffles)
 // G rows stay in registers (2 x 16 doubles per lane); vectors of variables travel through 16 doubles of LDS; W^-1 G is
-// staged through LDS into MFMA operand layout for H (24-28 x v_mfma_f64_16x16x4_f64).  No HBM traffic besides
+// staged through LDS (64 rows at a time) into MFMA operand layout for H (24-28 x v_mfma_f64_16x16x4_f64).  No HBM traffic besides
 // x_init in / U, X out.  Scalar twin: oracle/mpc.hpp (MpcCondensedIpm).
 #pragma once
 #include "tile_engine.h"
@@ -44,9 +44,10 @@ struct MpcConst
 struct Shared
 {
     ipm::TileShared ts;
-    double gt[LROWS * GP];
+    double gt[64 * GP]; // W^-1 G rows of one slot at a time
     double vec[NV];
     double bk[NV];
+    double red[NV];
 };
 
 using ipm::Tile;
@@ -213,7 +214,10 @@ __device__ inline void bring2cone(const Rows &R, double &v0, double &v1)
 
 // status: 0 optimal, 1 reduced accuracy (ECOS "close to optimal"), -1 iteration limit, -2 numerics,
 //         -3 the given state violates its own (stage-0) constraints
-__global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restrict__ Cg, const double *__restrict__ x0g,
+#ifndef MPC_WAVES_PER_SIMD
+#define MPC_WAVES_PER_SIMD 2 // measured (B = 32768): 1 -> 3.3 M solves/s, 2 -> 5.3 M, 3 (83 VGPRs spilled) -> 3.9 M, 4 -> 2.5 M
+#endif
+__global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const MpcConst *__restrict__ Cg, const double *__restrict__ x0g,
                                                         const double *__restrict__ xfg, double *__restrict__ Uout,
                                                         double *__restrict__ Xout, double *__restrict__ cost,
                                                         int *__restrict__ status, int *__restrict__ iters,
@@ -264,12 +268,11 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
         h1 += C.P[64 + lane][i] * x0[i] + C.Q[64 + lane][i] * xf[i];
     }
     const int g = lane >> 4, li = lane & 15;
-    double cv[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++)
-        cv[j] = C.c[j];
+    // vectors of variables live one entry per lane in lanes 0..15 (0 elsewhere) and are broadcast through sh.vec
+    const bool vl = lane < NV;
+    const double cl = vl ? C.c[li] : 0.;
     // ---- initial point (ECOS init with W = I): x = argmin |Gx - h|, s = bring2cone(h - Gx); z = bring2cone(G x'), G'G x' = -c
-    double s0, s1, z0, z1;
+    double s0, s1, z0, z1, xl;
     {
         Tile Li = ipm::loadTile(C.Li0, lane), LiT = ipm::loadTile(C.Li0T, lane);
         mulGT(R, h0, h1, sh);
@@ -279,35 +282,28 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
         s0 = h0 - g0;
         s1 = h1 - g1;
         bring2cone(R, s0, s1);
-        double xs[NV];
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-            xs[j] = sh.vec[j];
+        xl = vl ? sh.vec[li] : 0.;
         WAVE_SYNC();
-        if (lane < NV)
-            sh.vec[lane] = -C.c[lane];
+        if (vl)
+            sh.vec[lane] = -cl;
         WAVE_SYNC();
         tileSolve(Li, LiT, sh, lane);
         mulG(R, sh, z0, z1);
         bring2cone(R, z0, z1);
-        WAVE_SYNC();
-        if (lane == 0)
-        {
-#pragma unroll
-            for (int j = 0; j < NV; j++)
-                sh.vec[j] = xs[j];
-        }
-        WAVE_SYNC();
     }
-    double xv[NV]; // current primal point (same in every lane)
-#pragma unroll
-    for (int j = 0; j < NV; j++)
-        xv[j] = sh.vec[j];
-    double ncst = 0.;
-#pragma unroll
-    for (int j = 0; j < NV; j++)
-        ncst += cv[j] * cv[j];
-    const double resz0 = fmax(1., sqrt(wave_sum(h0 * h0 + h1 * h1))), resx0 = fmax(1., sqrt(ncst));
+    double resz0, resx0;
+    {
+        double p[NV] = {};
+        p[0] = h0 * h0 + h1 * h1;
+        p[1] = cl * cl;
+        const double d = waveReduce16(p, lane);
+        WAVE_SYNC();
+        if ((lane & 3) == 0)
+            sh.red[lane >> 2] = d;
+        WAVE_SYNC();
+        resz0 = fmax(1., sqrt(sh.red[0]));
+        resx0 = fmax(1., sqrt(sh.red[1]));
+    }
     const double Ddeg = double(nlp + N + 2);
     bool bk_valid = false;
     double pres_prev = 0.;
@@ -317,28 +313,38 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
         it = iter;
         // ---- residuals ----
         WAVE_SYNC();
-        if (lane == 0)
-        {
-#pragma unroll
-            for (int j = 0; j < NV; j++)
-                sh.vec[j] = xv[j];
-        }
+        if (vl)
+            sh.vec[lane] = xl;
         WAVE_SYNC();
         double g0, g1;
         mulG(R, sh, g0, g1);
         const double rz0 = R.act0 ? s0 + g0 - h0 : 0., rz1 = R.act1 ? s1 + g1 - h1 : 0.;
         mulGT(R, z0, z1, sh);
-        double rx[NV], nrx = 0., nxx = 0., pcost = 0.;
-#pragma unroll
-        for (int j = 0; j < NV; j++)
+        const double rxl = vl ? sh.vec[li] + cl : 0.;
+        double gap, nrz, nzz, nss, nrx, nxx, pcost;
         {
-            rx[j] = sh.vec[j] + cv[j];
-            nrx += rx[j] * rx[j];
-            nxx += xv[j] * xv[j];
-            pcost += cv[j] * xv[j];
+            // seven wave totals in one transposing reduction
+            double p[NV] = {};
+            p[0] = s0 * z0 + s1 * z1;
+            p[1] = rz0 * rz0 + rz1 * rz1;
+            p[2] = z0 * z0 + z1 * z1;
+            p[3] = s0 * s0 + s1 * s1;
+            p[4] = rxl * rxl;
+            p[5] = xl * xl;
+            p[6] = cl * xl;
+            const double d = waveReduce16(p, lane);
+            WAVE_SYNC();
+            if ((lane & 3) == 0)
+                sh.red[lane >> 2] = d;
+            WAVE_SYNC();
+            gap = sh.red[0];
+            nrz = sh.red[1];
+            nzz = sh.red[2];
+            nss = sh.red[3];
+            nrx = sh.red[4];
+            nxx = sh.red[5];
+            pcost = sh.red[6];
         }
-        const double gap = wave_sum(s0 * z0 + s1 * z1), nrz = wave_sum(rz0 * rz0 + rz1 * rz1),
-                     nzz = wave_sum(z0 * z0 + z1 * z1), nss = wave_sum(s0 * s0 + s1 * s1);
         const double mu = gap / Ddeg;
         const double pres = sqrt(nrz) / fmax(resz0 + sqrt(nxx) + sqrt(nss), 1.);
         const double dres = sqrt(nrx) / fmax(resx0 + sqrt(nzz), 1.);
@@ -351,9 +357,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
                 st = -2;
                 break;
             }
-#pragma unroll
-            for (int j = 0; j < NV; j++)
-                xv[j] = sh.bk[j];
+            xl = vl ? sh.bk[li] : 0.;
             st = 1;
             break;
         }
@@ -366,14 +370,8 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
         const bool inacc_ok = pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
         if (inacc_ok)
         {
-            WAVE_SYNC();
-            if (lane == 0)
-            {
-#pragma unroll
-                for (int j = 0; j < NV; j++)
-                    sh.bk[j] = xv[j];
-            }
-            WAVE_SYNC();
+            if (vl)
+                sh.bk[lane] = xl; // only read back by the same lane
             bk_valid = true;
         }
         if (iter >= C.maxit)
@@ -385,7 +383,6 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
         bool ok = !R.act0 || (s0 > 0. && z0 > 0.);
         const double zos = R.act0 ? z0 / s0 : 0.; // W^-2 of the LP rows
         ConeScal cs;
-        double lam1;
         {
             const double sh_ = headv(s1, R.hd), zh_ = headv(z1, R.hd);
             const double s2 = csum(R.head ? 0. : s1 * s1, lane), z2 = csum(R.head ? 0. : z1 * z1, lane);
@@ -405,29 +402,42 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
             st = inacc_ok ? 1 : -2;
             break;
         }
-        lam1 = applyW(cs, R, z1);
-        // ---- H = Gt' Gt, Gt = W^-1 G ----
+        const double lam1 = applyW(cs, R, z1);
+        // ---- H = Gt' Gt, Gt = W^-1 G: rows staged through LDS into MFMA operand layout, 64 rows at a time ----
         Tile Li, LiT;
         {
+            d4_t acc = {0., 0., 0., 0.};
             const double iw = R.act0 ? sqrt(zos) : 0.;
             WAVE_SYNC();
 #pragma unroll
             for (int j = 0; j < NV; j++)
                 sh.gt[lane * GP + j] = R.G0[j] * iw;
+            WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                if (16 * t >= nlp)
+                    continue;
+                double v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    v[r] = sh.gt[(16 * t + g + 4 * r) * GP + li];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r], v[r], acc, 0, 0, 0);
+            }
+            double gt1[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++)
-            {
-                const double o = applyWinv(cs, R, R.G1[j]);
-                if (lane < LROWS - 64)
-                    sh.gt[(64 + lane) * GP + j] = R.act1 ? o : 0.;
-            }
+                gt1[j] = applyWinv(cs, R, R.G1[j]);
             WAVE_SYNC();
-            d4_t acc = {0., 0., 0., 0.};
 #pragma unroll
-            for (int t = 0; t < LROWS / 16; t++)
+            for (int j = 0; j < NV; j++)
+                sh.gt[lane * GP + j] = gt1[j];
+            WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < 3; t++)
             {
-                if (t < 4 && 16 * t >= nlp)
-                    continue;
                 double v[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++)
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
             Li = ipm::invCholFactor<NV>(H, sh.ts, lane);
             LiT = ipm::transposeTile(Li, sh.ts, lane);
         }
-        double sigma_c = 0., alpha = 1., ds0 = 0., ds1 = 0., dz0 = 0., dz1 = 0., dsS1 = 0., dzS1 = 0., dxv[NV];
+        double sigma_c = 0., alpha = 1., ds0 = 0., ds1 = 0., dz0 = 0., dz1 = 0., dsS1 = 0., dzS1 = 0., dxl = 0.;
         bool broke = false;
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++)
@@ -470,24 +480,15 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
             // H dx = -om rx - G't
             mulGT(R, t0, t1, sh);
             {
-                double bj = 0.;
-#pragma unroll
-                for (int j = 0; j < NV; j++)
-                    bj = (lane == j) ? -om * rx[j] - sh.vec[j] : bj;
+                const double bj = (vl && lane < nv) ? -om * rxl - sh.vec[li] : 0.;
                 WAVE_SYNC();
-                if (lane < NV)
-                    sh.vec[lane] = lane < nv ? bj : 0.;
+                if (vl)
+                    sh.vec[lane] = bj;
                 WAVE_SYNC();
             }
             tileSolve(Li, LiT, sh, lane);
-            double chk = 0.;
-#pragma unroll
-            for (int j = 0; j < NV; j++)
-            {
-                dxv[j] = sh.vec[j];
-                chk += dxv[j] * 0.;
-            }
-            if (!(chk == 0.))
+            dxl = vl ? sh.vec[li] : 0.;
+            if (wave_or((dxl - dxl == 0.) ? 0 : 1))
             {
                 broke = true;
                 break;
@@ -524,9 +525,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
             st = inacc_ok ? 1 : -2;
             break;
         }
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-            xv[j] += alpha * dxv[j];
+        xl += alpha * dxl;
         s0 += alpha * ds0;
         z0 += alpha * dz0;
         s1 += alpha * ds1;
@@ -541,12 +540,8 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(const MpcConst *__restric
     if (st < 0)
         return;
     WAVE_SYNC();
-    if (lane == 0)
-    {
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-            sh.vec[j] = C.D[j] * xv[j];
-    }
+    if (vl)
+        sh.vec[lane] = C.D[li] * xl;
     WAVE_SYNC();
     if (lane < NU * N)
         Uout[size_t(b) * NMAX * NU + lane] = sh.vec[lane];
