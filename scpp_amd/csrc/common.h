@@ -77,6 +77,65 @@ __device__ __forceinline__ double fastRsqrt(double d)
 }
 #endif
 
+// ---- cross-lane moves on the VALU data path (DPP / v_readlane): no LDS crossbar round trip (ds_bpermute) ----
+// rowXor1 / rowXor2: partner inside the quad; rowHalfMirror / rowMirror: lane 7-i of the half row / lane 15-i of the row of
+// 16 lanes -- a SYMMETRIC butterfly, so that every lane of a row ends up with the bitwise identical sum (rotations would
+// give each lane its own rounding, and per-lane copies of one cone scalar must agree exactly); rowRor8 = partner lane ^ 8;
+// pairHead: the even lane of each pair; readLane: one lane's value for the whole wave.
+#ifdef SCPP_HIP_EMU
+inline double rowXor1(double v) { return __shfl_xor(v, 1); }
+inline double rowXor2(double v) { return __shfl_xor(v, 2); }
+inline double rowHalfMirror(double v) { const int l = threadIdx.x & 63; return __shfl(v, (l & ~7) | (7 - (l & 7))); }
+inline double rowMirror(double v) { const int l = threadIdx.x & 63; return __shfl(v, (l & ~15) | (15 - (l & 15))); }
+inline double rowRor8(double v) { return __shfl_xor(v, 8); }
+inline double pairHead(double v) { const int l = threadIdx.x & 63; return __shfl(v, l & ~1); }
+inline double readLane(double v, int src) { return __shfl(v, src); }
+inline bool anyLane(bool p) { int v = p ? 1 : 0; for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m); return v != 0; }
+#else
+template <int CTRL>
+__device__ __forceinline__ double dppMove(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(rhi, rlo);
+}
+__device__ __forceinline__ double rowXor1(double v) { return dppMove<0xB1>(v); } // quad_perm:[1,0,3,2]
+__device__ __forceinline__ double rowXor2(double v) { return dppMove<0x4E>(v); } // quad_perm:[2,3,0,1]
+__device__ __forceinline__ double rowHalfMirror(double v) { return dppMove<0x141>(v); } // row_half_mirror
+__device__ __forceinline__ double rowMirror(double v) { return dppMove<0x140>(v); }     // row_mirror
+__device__ __forceinline__ double rowRor8(double v) { return dppMove<0x128>(v); } // row_ror:8
+__device__ __forceinline__ double pairHead(double v) { return dppMove<0xA0>(v); } // quad_perm:[0,0,2,2]
+__device__ __forceinline__ double readLane(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool anyLane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+#endif
+// sum / max over the row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ double rowSum16(double v)
+{
+    v += rowXor1(v);
+    v += rowXor2(v);
+    v += rowHalfMirror(v);
+    v += rowMirror(v);
+    return v;
+}
+__device__ __forceinline__ double rowMax16(double v)
+{
+    v = fmax(v, rowXor1(v));
+    v = fmax(v, rowXor2(v));
+    v = fmax(v, rowHalfMirror(v));
+    v = fmax(v, rowMirror(v));
+    return v;
+}
+__device__ __forceinline__ double waveMaxDpp(double v)
+{
+    v = rowMax16(v);
+    return fmax(fmax(readLane(v, 0), readLane(v, 16)), fmax(readLane(v, 32), readLane(v, 48)));
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1)

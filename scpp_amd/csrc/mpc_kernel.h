@@ -52,14 +52,15 @@ struct Shared
 
 using ipm::Tile;
 
-// sum over the lanes of my cone (slot 1); v must be 0 on lanes that hold no row
+// sum over the lanes of my cone (slot 1); v must be 0 on lanes that hold no row.  Glide-slope pairs sit in the first row
+// of 16 lanes, the error and input cones own a row each.
 __device__ __forceinline__ double csum(double v, int lane)
 {
-    const double p1 = v + __shfl_xor(v, 1);
-    const double p2 = p1 + __shfl_xor(p1, 2);
-    const double p4 = p2 + __shfl_xor(p2, 4);
-    const double p8 = p4 + __shfl_xor(p4, 8);
-    return lane < 16 ? p1 : p8;
+    const double p1 = v + rowXor1(v);
+    double r = p1 + rowXor2(p1);
+    r += rowHalfMirror(r);
+    r += rowMirror(r);
+    return lane < 16 ? p1 : r; // symmetric butterfly: bitwise the same sum in every lane of the cone
 }
 
 // 16 per-lane partial sums -> the wave total of entry j ends up in lanes 4j .. 4j+3 (17 shuffles instead of 96)
@@ -83,12 +84,12 @@ __device__ inline double waveReduce16(const double (&p)[NV], int lane)
     for (int q = 0; q < 2; q++)
     {
         const double mine = b3 ? b[2 + q] : b[q], send = b3 ? b[q] : b[2 + q];
-        c[q] = mine + __shfl_xor(send, 8);
+        c[q] = mine + rowRor8(send); // rotation by 8 in a row of 16 = partner lane ^ 8
     }
     const double mine = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
     double d = mine + __shfl_xor(send, 4);
-    d += __shfl_xor(d, 2);
-    d += __shfl_xor(d, 1);
+    d += rowXor2(d);
+    d += rowXor1(d);
     return d;
 }
 
@@ -153,42 +154,47 @@ struct ConeScal
 {
     double w, w0, eta;
 };
-__device__ inline double headv(double v, int hd) { return __shfl(v, hd); }
+// value of my cone's head lane (pairs: the even lane; error cone: lane 16; input cone: lane 32)
+__device__ inline double headv(double v, int lane)
+{
+    const double pr = pairHead(v), e = readLane(v, ERR_LANE), i = readLane(v, INP_LANE);
+    return lane < 16 ? pr : lane < 32 ? e : lane < 48 ? i : v;
+}
 
 __device__ inline double applyW(const ConeScal &c, const Rows &R, double v)
 {
-    const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.hd);
+    const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
     const double f = v0 + zeta / (1. + c.w0);
     return !R.act1 ? 0. : R.head ? c.eta * (c.w0 * v0 + zeta) : c.eta * (v + f * c.w);
 }
 __device__ inline double applyWinv(const ConeScal &c, const Rows &R, double v)
 {
-    const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.hd);
+    const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
     const double f = -v0 + zeta / (1. + c.w0);
     return !R.act1 ? 0. : R.head ? (c.w0 * v0 - zeta) / c.eta : (v + f * c.w) / c.eta;
 }
 __device__ inline double applyWinv2(const ConeScal &c, const Rows &R, double v)
 {
-    const double tv = csum(R.head ? c.w * v : -c.w * v, R.lane), v0 = headv(v, R.hd);
+    const double tv = csum(R.head ? c.w * v : -c.w * v, R.lane), v0 = headv(v, R.lane);
     const double e2 = 1. / (c.eta * c.eta);
     return !R.act1 ? 0. : R.head ? e2 * (2. * c.w0 * tv - v0) : e2 * (-2. * c.w * tv + v);
 }
 __device__ inline double conicProduct(const Rows &R, double u, double v)
 {
-    const double s0 = csum(u * v, R.lane), u0 = headv(u, R.hd), v0 = headv(v, R.hd);
+    const double s0 = csum(u * v, R.lane), u0 = headv(u, R.lane), v0 = headv(v, R.lane);
     return !R.act1 ? 0. : R.head ? s0 : u0 * v + v0 * u;
 }
 __device__ inline double conicDivision(const Rows &R, double lam, double dd)
 {
     const double l1d1 = csum(R.head ? 0. : lam * dd, R.lane), l1l1 = csum(R.head ? 0. : lam * lam, R.lane);
-    const double lam0 = headv(lam, R.hd), dd0 = headv(dd, R.hd);
+    const double lam0 = headv(lam, R.lane), dd0 = headv(dd, R.lane);
     const double rho = lam0 * lam0 - l1l1;
     const double u0 = (lam0 * dd0 - l1d1) / rho;
     return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * lam) / lam0;
 }
 __device__ inline double stepInv(const Rows &R, double lam, double v)
 {
-    const double l1 = csum(R.head ? 0. : lam * lam, R.lane), lam0 = headv(lam, R.hd), v0 = headv(v, R.hd);
+    const double l1 = csum(R.head ? 0. : lam * lam, R.lane), lam0 = headv(lam, R.lane), v0 = headv(v, R.lane);
     const double ln = sqrt(lam0 * lam0 - l1);
     const double lbJv = csum(R.head ? lam * v : -lam * v, R.lane) / ln;
     const double rho0 = lbJv / ln;
@@ -202,11 +208,11 @@ __device__ inline double stepInv(const Rows &R, double lam, double v)
 __device__ inline void bring2cone(const Rows &R, double &v0, double &v1)
 {
     const double n2 = csum(R.head ? 0. : v1 * v1, R.lane);
-    const double cand1 = sqrt(n2) - headv(v1, R.hd);
+    const double cand1 = sqrt(n2) - headv(v1, R.lane);
     double a = -0.99;
     a = R.act0 ? fmax(a, -v0) : a;
     a = R.act1 ? fmax(a, cand1) : a;
-    a = wave_max(a);
+    a = waveMaxDpp(a);
     const double sh = 1. + a;
     v0 = R.act0 ? v0 + sh : 0.;
     v1 = (R.act1 && R.head) ? v1 + sh : v1;
@@ -384,7 +390,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
         const double zos = R.act0 ? z0 / s0 : 0.; // W^-2 of the LP rows
         ConeScal cs;
         {
-            const double sh_ = headv(s1, R.hd), zh_ = headv(z1, R.hd);
+            const double sh_ = headv(s1, R.lane), zh_ = headv(z1, R.lane);
             const double s2 = csum(R.head ? 0. : s1 * s1, lane), z2 = csum(R.head ? 0. : z1 * z1, lane);
             const double sres = sh_ * sh_ - s2, zres = zh_ * zh_ - z2;
             ok = ok && (!R.act1 || (sres > 0. && zres > 0.));
@@ -394,10 +400,10 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             const double a = 0.5 / gamma;
             cs.w = R.act1 ? (R.head ? a * (s1 / sn + z1 / zn) : a * (s1 / sn - z1 / zn)) : 0.;
             cs.eta = R.act1 ? sqrt(sn / zn) : 1.;
-            const double hw = headv(cs.w, R.hd); // (shuffles are never issued under a lane-dependent condition)
+            const double hw = headv(cs.w, R.lane); // (shuffles are never issued under a lane-dependent condition)
             cs.w0 = R.act1 ? hw : 1.;
         }
-        if (wave_or(ok ? 0 : 1))
+        if (anyLane(!ok))
         {
             st = inacc_ok ? 1 : -2;
             break;
@@ -488,7 +494,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             }
             tileSolve(Li, LiT, sh, lane);
             dxl = vl ? sh.vec[li] : 0.;
-            if (wave_or((dxl - dxl == 0.) ? 0 : 1))
+            if (anyLane(!(dxl - dxl == 0.)))
             {
                 broke = true;
                 break;
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             dzS1 = applyW(cs, R, dz1);
             const double si = stepInv(R, lam1, dsS1), zi = stepInv(R, lam1, dzS1);
             ainv = R.act1 ? fmax(ainv, fmax(si, zi)) : ainv;
-            ainv = wave_max(ainv);
+            ainv = waveMaxDpp(ainv);
             if (pass == 0)
             {
                 const double alpha_a = ainv > 0. ? fmin(1. / ainv, 1.) : 1.;
