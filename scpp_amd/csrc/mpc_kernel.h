@@ -93,19 +93,22 @@ __device__ inline double waveReduce16(const double (&p)[NV], int lane)
     return d;
 }
 
+// NC = number of variable columns actually carried (14 for the shipped K = 7, else the whole tile)
+template <int NC>
 struct Rows
 {
-    double G0[NV], G1[NV];
+    double G0[NC], G1[NC];
     bool act0, act1, head;
     int hd, lane;
 };
 
 // G' (t0, t1) -> sh.vec
-__device__ inline void mulGT(const Rows &R, double t0, double t1, Shared &sh)
+template <int NC>
+__device__ inline void mulGT(const Rows<NC> &R, double t0, double t1, Shared &sh)
 {
-    double p[NV];
+    double p[NV] = {};
 #pragma unroll
-    for (int j = 0; j < NV; j++)
+    for (int j = 0; j < NC; j++)
         p[j] = R.G0[j] * t0 + R.G1[j] * t1;
     const double d = waveReduce16(p, R.lane);
     WAVE_SYNC();
@@ -114,11 +117,12 @@ __device__ inline void mulGT(const Rows &R, double t0, double t1, Shared &sh)
     WAVE_SYNC();
 }
 // G sh.vec -> (o0, o1)
-__device__ inline void mulG(const Rows &R, const Shared &sh, double &o0, double &o1)
+template <int NC>
+__device__ inline void mulG(const Rows<NC> &R, const Shared &sh, double &o0, double &o1)
 {
     double a0 = 0., a1 = 0.;
 #pragma unroll
-    for (int j = 0; j < NV; j++)
+    for (int j = 0; j < NC; j++)
     {
         const double x = sh.vec[j];
         a0 += R.G0[j] * x;
@@ -150,9 +154,46 @@ __device__ inline void tileSolve(const Tile &Li, const Tile &LiT, Shared &sh, in
 
 // Nesterov-Todd scaling of the slot-1 cones, one component per lane.  Lanes that hold no row are their own "head" with
 // zero data: they contribute 0 to every cone sum and every helper returns 0 for them.
+// A/B switches.  MPC_NEW_*: shared reciprocals (one division per cone and iteration, multiplications at the uses) instead of a
+// division per use -- measured on 256 states against the twin: W, DIV, STEP, LP keep identical statuses and iteration
+// counts and take the kernel from 6.5 M to 8.0 M solves/s; SCAL does not (8 of 256 counts differ) and stays off.
+// MPC_FAST_*: hardware seed + Newton (fastRcp / fastRsqrt) instead of correctly rounded reciprocals: +1 %, left off.
+#ifndef MPC_NEW_W
+#define MPC_NEW_W 1
+#endif
+#ifndef MPC_NEW_DIV
+#define MPC_NEW_DIV 1
+#endif
+#ifndef MPC_NEW_STEP
+#define MPC_NEW_STEP 1
+#endif
+#ifndef MPC_NEW_SCAL
+#define MPC_NEW_SCAL 0 // measured: the normalised-vector form of the NT scaling loses the iterate-for-iterate agreement with the twin
+#endif
+#ifndef MPC_NEW_LP
+#define MPC_NEW_LP 1
+#endif
+#ifndef MPC_FAST_SCAL
+#define MPC_FAST_SCAL 0
+#endif
+#ifndef MPC_FAST_LAM
+#define MPC_FAST_LAM 0
+#endif
+#ifndef MPC_FAST_LP
+#define MPC_FAST_LP 0
+#endif
+__device__ __forceinline__ double rcpSel(double d, bool fast) { return fast ? fastRcp(d) : 1. / d; }
+__device__ __forceinline__ double rsqrtSel(double d, bool fast) { return fast ? fastRsqrt(d) : 1. / sqrt(d); }
+
 struct ConeScal
 {
     double w, w0, eta;
+    double ieta, iw01; // 1/eta, 1/(1 + w0): shared reciprocals instead of one IEEE division per use
+};
+// scaled variable lambda = W z of my cone: what every step-length computation of an iteration shares
+struct LamInfo
+{
+    double lam, lam0, iln, f_den, ln2; // component, head, 1/||lambda||_J, 1/(lam0/||lambda||_J + 1), ||lambda||_J^2
 };
 // value of my cone's head lane (pairs: the even lane; error cone: lane 16; input cone: lane 32)
 __device__ inline double headv(double v, int lane)
@@ -161,51 +202,97 @@ __device__ inline double headv(double v, int lane)
     return lane < 16 ? pr : lane < 32 ? e : lane < 48 ? i : v;
 }
 
-__device__ inline double applyW(const ConeScal &c, const Rows &R, double v)
+template <class RowsT>
+__device__ inline double applyW(const ConeScal &c, const RowsT &R, double v)
 {
     const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
+#if MPC_NEW_W
+    const double f = v0 + zeta * c.iw01;
+#else
     const double f = v0 + zeta / (1. + c.w0);
+#endif
     return !R.act1 ? 0. : R.head ? c.eta * (c.w0 * v0 + zeta) : c.eta * (v + f * c.w);
 }
-__device__ inline double applyWinv(const ConeScal &c, const Rows &R, double v)
+template <class RowsT>
+__device__ inline double applyWinv(const ConeScal &c, const RowsT &R, double v)
 {
     const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
+#if MPC_NEW_W
+    const double f = -v0 + zeta * c.iw01;
+    return !R.act1 ? 0. : R.head ? (c.w0 * v0 - zeta) * c.ieta : (v + f * c.w) * c.ieta;
+#else
     const double f = -v0 + zeta / (1. + c.w0);
     return !R.act1 ? 0. : R.head ? (c.w0 * v0 - zeta) / c.eta : (v + f * c.w) / c.eta;
+#endif
 }
-__device__ inline double applyWinv2(const ConeScal &c, const Rows &R, double v)
+template <class RowsT>
+__device__ inline double applyWinv2(const ConeScal &c, const RowsT &R, double v)
 {
     const double tv = csum(R.head ? c.w * v : -c.w * v, R.lane), v0 = headv(v, R.lane);
+#if MPC_NEW_W
+    const double e2 = c.ieta * c.ieta;
+#else
     const double e2 = 1. / (c.eta * c.eta);
+#endif
     return !R.act1 ? 0. : R.head ? e2 * (2. * c.w0 * tv - v0) : e2 * (-2. * c.w * tv + v);
 }
-__device__ inline double conicProduct(const Rows &R, double u, double v)
+template <class RowsT>
+__device__ inline double conicProduct(const RowsT &R, double u, double v)
 {
     const double s0 = csum(u * v, R.lane), u0 = headv(u, R.lane), v0 = headv(v, R.lane);
     return !R.act1 ? 0. : R.head ? s0 : u0 * v + v0 * u;
 }
-__device__ inline double conicDivision(const Rows &R, double lam, double dd)
+template <class RowsT>
+__device__ inline LamInfo lamInfo(const RowsT &R, double lam)
 {
-    const double l1d1 = csum(R.head ? 0. : lam * dd, R.lane), l1l1 = csum(R.head ? 0. : lam * lam, R.lane);
-    const double lam0 = headv(lam, R.lane), dd0 = headv(dd, R.lane);
-    const double rho = lam0 * lam0 - l1l1;
-    const double u0 = (lam0 * dd0 - l1d1) / rho;
-    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * lam) / lam0;
+    LamInfo L;
+    L.lam = lam;
+    L.lam0 = headv(lam, R.lane);
+    const double l1 = csum(R.head ? 0. : lam * lam, R.lane);
+    const double ln2 = L.lam0 * L.lam0 - l1;
+    L.ln2 = ln2;
+    L.iln = rsqrtSel(ln2, MPC_FAST_LAM);
+    L.f_den = rcpSel(L.lam0 * L.iln + 1., MPC_FAST_LAM);
+    return L;
 }
-__device__ inline double stepInv(const Rows &R, double lam, double v)
+// lam \ dd
+template <class RowsT>
+__device__ inline double conicDivision(const RowsT &R, const LamInfo &L, double dd)
 {
-    const double l1 = csum(R.head ? 0. : lam * lam, R.lane), lam0 = headv(lam, R.lane), v0 = headv(v, R.lane);
-    const double ln = sqrt(lam0 * lam0 - l1);
-    const double lbJv = csum(R.head ? lam * v : -lam * v, R.lane) / ln;
+    const double l1d1 = csum(R.head ? 0. : L.lam * dd, R.lane), dd0 = headv(dd, R.lane);
+    // rho = lam0^2 - |lam1|^2 = 1 / iln^2
+#if MPC_NEW_DIV
+    const double u0 = (L.lam0 * dd0 - l1d1) * (L.iln * L.iln);
+    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * L.lam) * rcpSel(L.lam0, MPC_FAST_LAM);
+#else
+    const double u0 = (L.lam0 * dd0 - l1d1) / L.ln2;
+    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * L.lam) / L.lam0;
+#endif
+}
+// 1 / (largest step keeping lam + alpha v in the cone)   (ECOS lineSearch)
+template <class RowsT>
+__device__ inline double stepInv(const RowsT &R, const LamInfo &L, double v)
+{
+    const double v0 = headv(v, R.lane);
+#if MPC_NEW_STEP
+    const double lbJv = csum(R.head ? L.lam * v : -L.lam * v, R.lane) * L.iln;
+    const double rho0 = lbJv * L.iln;
+    const double f = (lbJv + v0) * L.f_den;
+    const double ri = R.head ? 0. : (v - f * L.lam * L.iln) * L.iln;
+#else
+    const double ln = sqrt(L.ln2);
+    const double lbJv = csum(R.head ? L.lam * v : -L.lam * v, R.lane) / ln;
     const double rho0 = lbJv / ln;
-    const double f = (lbJv + v0) / (lam0 / ln + 1.);
-    const double ri = R.head ? 0. : (v - f * lam / ln) / ln;
+    const double f = (lbJv + v0) / (L.lam0 / ln + 1.);
+    const double ri = R.head ? 0. : (v - f * L.lam / ln) / ln;
+#endif
     const double r1 = csum(ri * ri, R.lane);
     return R.act1 ? sqrt(r1) - rho0 : 0.;
 }
 
 // ECOS bring2cone on (v0 | v1)
-__device__ inline void bring2cone(const Rows &R, double &v0, double &v1)
+template <class RowsT>
+__device__ inline void bring2cone(const RowsT &R, double &v0, double &v1)
 {
     const double n2 = csum(R.head ? 0. : v1 * v1, R.lane);
     const double cand1 = sqrt(n2) - headv(v1, R.lane);
@@ -223,6 +310,7 @@ __device__ inline void bring2cone(const Rows &R, double &v0, double &v1)
 #ifndef MPC_WAVES_PER_SIMD
 #define MPC_WAVES_PER_SIMD 2 // measured (B = 32768): 1 -> 3.3 M solves/s, 2 -> 5.3 M, 3 (83 VGPRs spilled) -> 3.9 M, 4 -> 2.5 M
 #endif
+template <int NC>
 __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const MpcConst *__restrict__ Cg, const double *__restrict__ x0g,
                                                         const double *__restrict__ xfg, double *__restrict__ Uout,
                                                         double *__restrict__ Xout, double *__restrict__ cost,
@@ -253,7 +341,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
         }
         return;
     }
-    Rows R;
+    Rows<NC> R;
     R.lane = lane;
     R.act0 = lane < nlp;
     const bool glide = lane < 2 * N, err = lane >= ERR_LANE && lane < ERR_LANE + 1 + NX, inp = lane >= INP_LANE && lane < INP_LANE + 1 + NU * N;
@@ -262,7 +350,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
     R.head = lane == R.hd;
     double h0 = C.c0[lane], h1 = C.c0[64 + lane];
 #pragma unroll
-    for (int j = 0; j < NV; j++)
+    for (int j = 0; j < NC; j++)
     {
         R.G0[j] = C.G[lane][j];
         R.G1[j] = C.G[64 + lane][j];
@@ -387,28 +475,46 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
         }
         // ---- scalings ----
         bool ok = !R.act0 || (s0 > 0. && z0 > 0.);
-        const double zos = R.act0 ? z0 / s0 : 0.; // W^-2 of the LP rows
+        const double is0 = rcpSel(s0, MPC_FAST_LP), iz0 = rcpSel(z0, MPC_FAST_LP);
+#if MPC_NEW_LP
+        const double zos = R.act0 ? z0 * is0 : 0.; // W^-2 of the LP rows
+#else
+        const double zos = R.act0 ? z0 / s0 : 0.;
+#endif
         ConeScal cs;
         {
-            const double sh_ = headv(s1, R.lane), zh_ = headv(z1, R.lane);
+            const double sh_ = headv(s1, lane), zh_ = headv(z1, lane);
             const double s2 = csum(R.head ? 0. : s1 * s1, lane), z2 = csum(R.head ? 0. : z1 * z1, lane);
             const double sres = sh_ * sh_ - s2, zres = zh_ * zh_ - z2;
             ok = ok && (!R.act1 || (sres > 0. && zres > 0.));
+#if MPC_NEW_SCAL
+            const double isn = rsqrtSel(sres, MPC_FAST_SCAL), izn = rsqrtSel(zres, MPC_FAST_SCAL); // 1/||s||_J, 1/||z||_J
+            const double sb = s1 * isn, zb = z1 * izn;
+            const double sz = csum(sb * zb, lane);
+            const double a = 0.5 * rsqrtSel(0.5 * (1. + sz), MPC_FAST_SCAL); // 1/(2 gamma)
+            cs.w = R.act1 ? (R.head ? a * (sb + zb) : a * (sb - zb)) : 0.;
+            const double e2 = (sres * isn) * izn; // ||s||_J / ||z||_J = eta^2
+            cs.ieta = R.act1 ? rsqrtSel(e2, MPC_FAST_SCAL) : 1.;
+            cs.eta = R.act1 ? e2 * cs.ieta : 1.;
+#else
             const double sn = sqrt(sres), zn = sqrt(zres);
             const double sz = csum(s1 * z1, lane) / (sn * zn);
             const double gamma = sqrt(0.5 * (1. + sz));
             const double a = 0.5 / gamma;
             cs.w = R.act1 ? (R.head ? a * (s1 / sn + z1 / zn) : a * (s1 / sn - z1 / zn)) : 0.;
             cs.eta = R.act1 ? sqrt(sn / zn) : 1.;
-            const double hw = headv(cs.w, R.lane); // (shuffles are never issued under a lane-dependent condition)
+            cs.ieta = 1. / cs.eta;
+#endif
+            const double hw = headv(cs.w, lane); // (shuffles are never issued under a lane-dependent condition)
             cs.w0 = R.act1 ? hw : 1.;
+            cs.iw01 = rcpSel(1. + cs.w0, MPC_FAST_SCAL);
         }
         if (anyLane(!ok))
         {
             st = inacc_ok ? 1 : -2;
             break;
         }
-        const double lam1 = applyW(cs, R, z1);
+        const LamInfo L1 = lamInfo(R, applyW(cs, R, z1));
         // ---- H = Gt' Gt, Gt = W^-1 G: rows staged through LDS into MFMA operand layout, 64 rows at a time ----
         Tile Li, LiT;
         {
@@ -416,7 +522,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             const double iw = R.act0 ? sqrt(zos) : 0.;
             WAVE_SYNC();
 #pragma unroll
-            for (int j = 0; j < NV; j++)
+            for (int j = 0; j < NC; j++)
                 sh.gt[lane * GP + j] = R.G0[j] * iw;
             WAVE_SYNC();
 #pragma unroll
@@ -432,13 +538,13 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
                 for (int r = 0; r < 4; r++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r], v[r], acc, 0, 0, 0);
             }
-            double gt1[NV];
+            double gt1[NC];
 #pragma unroll
-            for (int j = 0; j < NV; j++)
+            for (int j = 0; j < NC; j++)
                 gt1[j] = applyWinv(cs, R, R.G1[j]);
             WAVE_SYNC();
 #pragma unroll
-            for (int j = 0; j < NV; j++)
+            for (int j = 0; j < NC; j++)
                 sh.gt[lane * GP + j] = gt1[j];
             WAVE_SYNC();
 #pragma unroll
@@ -455,8 +561,8 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             Tile H;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                H.v[r] = (g + 4 * r == li && li >= nv) ? 1. : acc[r];
-            Li = ipm::invCholFactor<NV>(H, sh.ts, lane);
+                H.v[r] = (li >= nv || g + 4 * r >= nv) ? (g + 4 * r == li ? 1. : 0.) : acc[r]; // identity on the padding
+            Li = ipm::invCholFactor<NC>(H, sh.ts, lane);
             LiT = ipm::transposeTile(Li, sh.ts, lane);
         }
         double sigma_c = 0., alpha = 1., ds0 = 0., ds1 = 0., dz0 = 0., dz1 = 0., dsS1 = 0., dzS1 = 0., dxl = 0.;
@@ -468,7 +574,11 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             // t = W^-2 (om rz) + [ -z | W^-1( lam \ (sigma mu e - dsS o dzS) - lam ) ]
             double t0, t1;
             {
+#if MPC_NEW_LP
+                const double corr0 = (pass && R.act0) ? (sigma_c * mu - ds0 * dz0) * is0 : 0.;
+#else
                 const double corr0 = (pass && R.act0) ? (sigma_c * mu - ds0 * dz0) / s0 : 0.;
+#endif
                 t0 = R.act0 ? zos * om * rz0 - z0 + corr0 : 0.;
                 const double b2 = applyWinv2(cs, R, om * rz1);
                 if (pass == 0)
@@ -477,8 +587,8 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
                 {
                     double dsv = -conicProduct(R, dsS1, dzS1);
                     dsv += R.head ? sigma_c * mu : 0.;
-                    double u = conicDivision(R, lam1, dsv);
-                    u -= lam1;
+                    double u = conicDivision(R, L1, dsv);
+                    u -= L1.lam;
                     t1 = b2 + applyWinv(cs, R, u);
                 }
                 t1 = R.act1 ? t1 : 0.;
@@ -504,13 +614,17 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             // dz = W^-2 G dx + t ; ds = -om rz - G dx
             dz0 = R.act0 ? zos * gd0 + t0 : 0.;
             ds0 = R.act0 ? -om * rz0 - gd0 : 0.;
+#if MPC_NEW_LP
+            double ainv = R.act0 ? fmax(-ds0 * is0, -dz0 * iz0) : 0.;
+#else
             double ainv = R.act0 ? fmax(-ds0 / s0, -dz0 / z0) : 0.;
+#endif
             const double w2g = applyWinv2(cs, R, R.act1 ? gd1 : 0.);
             dz1 = R.act1 ? w2g + t1 : 0.;
             ds1 = R.act1 ? -om * rz1 - gd1 : 0.;
             dsS1 = applyWinv(cs, R, ds1);
             dzS1 = applyW(cs, R, dz1);
-            const double si = stepInv(R, lam1, dsS1), zi = stepInv(R, lam1, dzS1);
+            const double si = stepInv(R, L1, dsS1), zi = stepInv(R, L1, dzS1);
             ainv = R.act1 ? fmax(ainv, fmax(si, zi)) : ainv;
             ainv = waveMaxDpp(ainv);
             if (pass == 0)

@@ -942,8 +942,13 @@ namespace
 {
 void launchMpcSolve(scpp_hip_ctx *c, const double *x0, const int *active, int B)
 {
-    hipLaunchKernelGGL(mpc::mpc_solve_kernel, dim3(unsigned(B)), dim3(64), 0, c->stream, (const mpc::MpcConst *)c->mpc_const, x0,
-                       (const double *)c->mpc_xf, c->mpc_U, c->mpc_X, c->mpc_cost, c->mpc_status, c->mpc_iters, active, B);
+    // the shipped horizon (K = 7: 14 variables) carries 14 columns, any other the whole 16-column tile
+    if (c->mpc_host->nv == 14)
+        hipLaunchKernelGGL((mpc::mpc_solve_kernel<14>), dim3(unsigned(B)), dim3(64), 0, c->stream, (const mpc::MpcConst *)c->mpc_const,
+                           x0, (const double *)c->mpc_xf, c->mpc_U, c->mpc_X, c->mpc_cost, c->mpc_status, c->mpc_iters, active, B);
+    else
+        hipLaunchKernelGGL((mpc::mpc_solve_kernel<16>), dim3(unsigned(B)), dim3(64), 0, c->stream, (const mpc::MpcConst *)c->mpc_const,
+                           x0, (const double *)c->mpc_xf, c->mpc_U, c->mpc_X, c->mpc_cost, c->mpc_status, c->mpc_iters, active, B);
 }
 } // namespace
 
