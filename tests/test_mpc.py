@@ -159,7 +159,38 @@ def test_emu_other_horizons(oracle, rocket2d, emu_lib, tmp_path):
         a.ctx.close()
 
 
+def _check_golden(alg):
+    """Committed golden vectors (tests/golden/rocket2d_mpc.npz): independent discretisation, SLSQP optima, regression record."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rocket2d_mpc.npz"))
+    assert np.abs(alg.A - g["A"]).max() < 1e-13 and np.abs(alg.B - g["B"]).max() < 1e-13 and np.abs(alg.z - g["z"]).max() < 1e-12
+    x = np.vstack([g["x0"], g["reg_x0"]])
+    alg.setInitialState(x); alg.setFinalState(alg.model.p.x_final)
+    assert alg.solve() == x.shape[0]
+    out = alg.getSolution()
+    n = len(g["x0"])
+    tot = out["cost"].sum(axis=1)
+    assert (tot[:n] <= g["cost"] * (1 + 1e-6)).all() and np.abs(tot[:n] - g["cost"]).max() < 2e-5 * g["cost"].max()
+    assert np.array_equal(out["iters"][n:], g["reg_iters"])
+    assert np.abs(out["U"][n:] - g["reg_U"]).max() <= 1e-9 * np.abs(g["reg_U"]).max()
+    assert np.abs(out["cost"][n:] - g["reg_cost"]).max() <= 1e-9 * g["reg_cost"].max()
+
+
+def test_emu_mpc_against_golden_vectors(rocket2d, emu_lib):
+    a = _alg(rocket2d, emu_lib)
+    _check_golden(a)
+    a.ctx.close()
+
+
 # ---------------------------------------------------------------- real GPU ----
+@pytest.mark.gpu
+def test_gpu_mpc_against_golden_vectors(rocket2d, hip_lib):
+    a = _alg(rocket2d, hip_lib)
+    _check_golden(a)
+    a.ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_mpc_solve_parity(oracle, rocket2d, hip_lib):
     """256 controllers, one wavefront each, against the twin: same status, same iteration count, same optimum."""

@@ -155,3 +155,23 @@ def test_closed_loop_regression_record(oracle):
     r = o.sim(o.x_init)
     assert r["steps"] == 1501 and r["reached"] == 0
     assert 1100 <= r["failed_solves"] <= 1200
+
+
+def test_oracle_against_committed_golden_vectors(oracle):
+    """tests/golden/rocket2d_mpc.npz (generator: tests/golden/generate_mpc_goldens.py): G6 sympy + scipy discretisation and
+    SLSQP optima, G7 the self-generated regression record."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rocket2d_mpc.npz"))
+    o = oracle.MPC()
+    assert np.abs(o.A - g["A"]).max() < 1e-13 and np.abs(o.B - g["B"]).max() < 1e-13 and np.abs(o.z - g["z"]).max() < 1e-12
+    for x0, c, U in zip(g["x0"], g["cost"], g["U"]):
+        for kind in (1, 0):
+            r = o.solve(x0, kind=kind)
+            assert r["status"] in (0, 1)
+            ours = r["input_cost"] + r["error_cost"]
+            assert ours <= c * (1 + 1e-6) and abs(ours - c) < 2e-5 * c
+    for x0, U, c, it in zip(g["reg_x0"], g["reg_U"], g["reg_cost"], g["reg_iters"]):
+        r = o.solve(x0, kind=1)
+        assert r["status"] == 0 and r["iters"] == it
+        assert np.abs(r["U"] - U).max() <= 1e-9 * np.abs(U).max() and abs(r["input_cost"] - c[0]) <= 1e-9 * c[0]
