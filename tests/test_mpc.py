@@ -24,7 +24,10 @@ def _alg(rocket2d, library, batch_max=16, **kw):
     return scpp_amd.MPCAlgorithm(rocket2d, batch_max=batch_max, library=library).initialize(**kw)
 
 
-def _check_solves(oracle, alg, x0, rtolU=1e-9, atolX=1e-6):
+def _check_solves(oracle, alg, x0, rtolU=1e-7, atolX=1e-6):
+    """Same status and iteration count as the twin; plan and costs to 1e-7 relative -- one order above the interior-point
+    termination tolerance (1e-8): a plan whose thrust levels sit strictly inside their bounds is determined only to about
+    that accuracy, and kernel and twin round differently (shared reciprocals, FMA contraction, summation trees)."""
     o = oracle.MPC()
     alg.setInitialState(x0); alg.setFinalState(alg.model.p.x_final)
     n = alg.solve()
@@ -37,8 +40,8 @@ def _check_solves(oracle, alg, x0, rtolU=1e-9, atolX=1e-6):
             assert out["iters"][b] == r["iters"]
             assert np.abs(out["U"][b] - r["U"]).max() <= rtolU * np.abs(r["U"]).max()
             assert np.abs(out["X"][b] - r["X"]).max() <= atolX
-            assert abs(out["cost"][b][0] - r["input_cost"]) <= 1e-9 * r["input_cost"]
-            assert abs(out["cost"][b][1] - r["error_cost"]) <= 1e-9 * r["error_cost"]
+            assert abs(out["cost"][b][0] - r["input_cost"]) <= rtolU * r["input_cost"]
+            assert abs(out["cost"][b][1] - r["error_cost"]) <= rtolU * r["error_cost"]
     return out
 
 
