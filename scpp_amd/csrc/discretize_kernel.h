@@ -8,8 +8,11 @@
 // state V = [x | Phi | Psi_B | Psi_C | psi_s | psi_z] (NX x NCOLS, 14x25 = 350 entries for RocketQuat)
 // is spread over the lanes (<= 6 entries per lane, register resident incl. the 13 RKF78 stage
 // derivatives); stage values and the per-stage Jacobian tile [sigma*A | sigma*B] (NX x (NX+NU)) are
-// staged in LDS.  The Jacobian is produced SIMT-style by forward-mode AD: lane j < NX+NU evaluates the
-// model plugin's systemFlowMap<Dual1> with seed e_j (one Jacobian column per lane, no divergence).
+// staged in LDS.  Every lane owns entries of ONE row of V, so it needs one row of the Jacobian per stage: by default each
+// lane evaluates the non-zeros of its row from the model's generated analytic rows (Model::JacobianRows, the build-time
+// analogue of the reference's CppADCodeGen step; 61 non-zeros of 252 for RocketQuat).  -DDISC_AD_JACOBIAN selects the
+// generic path instead: forward-mode AD, lane j < NX+NU evaluates systemFlowMap<Dual1> with seed e_j (one Jacobian
+// column per lane) and the tile is exchanged through LDS.
 //
 // Integrator: the reference's RKF78 with 5 fixed steps per segment, applied to the
 // forward-sensitivity form  Psi' = A Psi + forcing  (algebraically identical to the reference's
@@ -84,7 +87,12 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 AD evaluations need.
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
     // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the AD phase.
-    __shared__ double cst[NP + 2 * NU];
+#ifndef DISC_AD_JACOBIAN
+    constexpr int NAUX = Model::JacobianRows::NAUX; // parameter-only sub-expressions of the analytic rows
+#else
+    constexpr int NAUX = 0;
+#endif
+    __shared__ double cst[NP + 2 * NU + NAUX + 1];
 
     const int lane = threadIdx.x;
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
@@ -125,6 +133,13 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             cst[NP + i] = u0[i];
             cst[NP + NU + i] = u1[i];
         }
+#ifndef DISC_AD_JACOBIAN
+        double aux0[NAUX];
+        Model::JacobianRows::prepare(p, aux0);
+#pragma unroll
+        for (int i = 0; i < NAUX; i++)
+            cst[NP + 2 * NU + i] = aux0[i];
+#endif
     }
     WAVE_SYNC();
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
@@ -188,8 +203,40 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             const long long p1 = clock64();
             tA += p1 - p0;
 #endif
-            // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
             const double frac = FOH ? ts / dt : 0.;
+            double jr[NJ]; // my row of [sigma*A | sigma*B]
+            double fr;     // f[row] (unscaled)
+#ifndef DISC_AD_JACOBIAN
+            {
+                // ---- analytic non-zeros of my Jacobian row at the stage point (no exchange through LDS) ----
+                int zo = 0; // opaque zero offset: keeps the LDS reads of the wave-uniform constants inside the stage (see cst)
+#ifndef SCPP_HIP_EMU
+                asm volatile("" : "+v"(zo));
+#endif
+                const double *cv = cst + zo;
+                double pl[NP], xs[NX], us[NU], ax[NAUX];
+#pragma unroll
+                for (int i = 0; i < NP; i++)
+                    pl[i] = cv[i];
+#pragma unroll
+                for (int i = 0; i < NAUX; i++)
+                    ax[i] = cv[NP + 2 * NU + i];
+#pragma unroll
+                for (int i = 0; i < NX; i++)
+                    xs[i] = Ys[i];
+#pragma unroll
+                for (int i = 0; i < NU; i++)
+                {
+                    const double a0 = cv[NP + i], a1 = cv[NP + NU + i];
+                    us[i] = a0 + frac * (a1 - a0);
+                }
+                fr = Model::JacobianRows::row(row, xs, us, pl, ax, jr);
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    jr[j] *= tscale;
+            }
+#else
+            // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
             if (lane < NJ)
             {
                 Dual1 xd[NX], ud[NU], fd[NX];
@@ -225,17 +272,17 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 }
             }
             WAVE_SYNC();
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                jr[j] = Jm[row * NJP + j];
+            fr = fv[row];
+#endif
 #ifdef DISC_PROFILE
             const long long p2 = clock64();
             tB += p2 - p1;
 #endif
             // ---- derivative of the owned entries: d(row, c) = J[row,:] V[:,c] + forcing(row, c), branch-free ----
             {
-                double jr[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; j++)
-                    jr[j] = Jm[row * NJP + j];
-                const double fr = fv[row];
                 const double alphaB = FOH ? (1. - frac) : 1.;
 #pragma unroll
                 for (int m = 0; m < EPL; m++)
@@ -256,7 +303,11 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                         const bool isC = FOH && c >= L::COL_C && c < L::COL_C + NU;
                         const int jj = isB ? c - L::COL_B : isC ? c - L::COL_C : 0;
                         const double w = isB ? alphaB : isC ? frac : 0.;
-                        d += w * Jm[row * NJP + NX + jj];
+                        double jb = jr[NX]; // J[row, NX + jj], jj is lane dependent
+#pragma unroll
+                        for (int q = 1; q < NU; q++)
+                            jb = (jj == q) ? jr[NX + q] : jb;
+                        d += w * jb;
                     }
                     if (VT && m * NG <= L::COL_S && m * NG + NG > L::COL_S)
                         d = (c == L::COL_S) ? d + fr : d;

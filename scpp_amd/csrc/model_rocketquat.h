@@ -7,6 +7,7 @@
 // (Eigen toRotationMatrix), gyroscopic term w x w == 0.
 #pragma once
 #include "common.h"
+#include "model_jacobian_rows.h"
 
 namespace scpp
 {
@@ -15,6 +16,9 @@ struct RocketQuatModel
 {
     static constexpr int NX = 14, NU = 4, NP = 10;
     static constexpr int MODEL_ID = 0;
+    // optional: analytic rows of [df/dx | df/du], generated from this flow map by tools/gen_model_jacobian.py (the
+    // reference's CppADCodeGen step at build time); kernels fall back to forward-mode AD of systemFlowMap<Dual1> without it
+    using JacobianRows = RocketQuatJacobianRows;
 
     // par = [alpha_m, g_I(3), J_B(3), r_T_B(3)]   rocketQuat.cpp:168-173
     template <class T>
@@ -57,6 +61,7 @@ struct Rocket2dModel
 {
     static constexpr int NX = 6, NU = 2, NP = 6;
     static constexpr int MODEL_ID = 1;
+    using JacobianRows = Rocket2dJacobianRows;
     template <class T>
     __host__ __device__ static void systemFlowMap(const T *x, const T *u, const double *par, T *f)
     {

@@ -1,0 +1,163 @@
+"""Generates scpp_amd/csrc/model_jacobian_rows.h: analytic rows of [df/dx | df/du] of the model plugins' flow maps.
+
+The reference obtains its Jacobians by taping systemFlowMap with CppAD and letting CppADCodeGen emit optimised (sparse) C
+source that is compiled and dlopen'ed at start-up (scpp_core/include/systemDynamics.hpp:109-168).  The build-time analogue
+here: the same flow maps written symbolically (sympy), differentiated, simplified by common-subexpression elimination and
+printed as one `case` per state row -- discretize_kernel keeps one Jacobian row per lane, so a lane evaluates only the
+handful of non-zeros of ITS row instead of taking part in an 18-direction forward-mode sweep of the whole map.
+The generated header is committed (hipcc needs no sympy); tests/test_oracle_model.py checks it against the sympy goldens
+and against forward-mode AD of systemFlowMap<Dual1>.
+
+    python tools/gen_model_jacobian.py            # rewrites scpp_amd/csrc/model_jacobian_rows.h
+"""
+import os
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "scpp_amd", "csrc", "model_jacobian_rows.h")
+
+
+class Printer(C99CodePrinter):
+    def _print_Pow(self, e):
+        b, ex = e.as_base_exp()
+        if ex.is_Integer and 2 <= int(ex) <= 3:
+            s = self.parenthesize(b, 100)
+            return "(" + "*".join([s] * int(ex)) + ")"
+        if ex.is_Integer and -3 <= int(ex) <= -1:
+            s = self.parenthesize(b, 100)
+            return "(1.0/(" + "*".join([s] * (-int(ex))) + "))"
+        return super()._print_Pow(e)
+
+    def _print_Rational(self, e):
+        return "(%d.0/%d.0)" % (e.p, e.q)
+
+
+def rocketquat():
+    """csrc/model_rocketquat.h: RocketQuatModel::systemFlowMap (rocketQuat.cpp:7-37, incl. the un-normalised rotation matrix)"""
+    x = sp.symbols("x0:14", real=True)
+    u = sp.symbols("u0:4", real=True)
+    p = sp.symbols("p0:10", real=True)
+    m = x[0]
+    qw, qx, qy, qz = x[7:11]
+    wx, wy, wz = x[11:14]
+    T = sp.Matrix(u[0:3])
+    R = sp.Matrix([
+        [1 - 2 * (qy**2 + qz**2), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+        [2 * (qx * qy + qw * qz), 1 - 2 * (qx**2 + qz**2), 2 * (qy * qz - qw * qx)],
+        [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx**2 + qy**2)],
+    ])
+    f = [None] * 14
+    f[0] = -p[0] * sp.sqrt(T.dot(T))
+    f[1], f[2], f[3] = x[4], x[5], x[6]
+    acc = R * T / m + sp.Matrix(p[1:4])
+    f[4], f[5], f[6] = acc
+    f[7] = sp.Rational(1, 2) * (-wx * qx - wy * qy - wz * qz)
+    f[8] = sp.Rational(1, 2) * (wx * qw + wz * qy - wy * qz)
+    f[9] = sp.Rational(1, 2) * (wy * qw - wz * qx + wx * qz)
+    f[10] = sp.Rational(1, 2) * (wz * qw + wy * qx - wx * qy)
+    rx, ry, rz = p[7:10]
+    f[11] = (ry * T[2] - rz * T[1]) / p[4]
+    f[12] = (rz * T[0] - rx * T[2]) / p[5]
+    f[13] = (rx * T[1] - ry * T[0] + u[3]) / p[6]
+    # wave-uniform, slow sub-expressions (a division or a square root each) evaluated ONCE before the row switch instead
+    # of inside its divergent cases: (C name, sympy expression)
+    # applied in this order; a later entry may be written in terms of an earlier symbol
+    TT = T.dot(T)
+    tn = sp.Symbol("t_norm", real=True)
+    hoist = [("inv_m", 1 / m), ("t_norm", sp.sqrt(TT)), ("inv_t_norm", 1 / tn),
+             ("inv_j0", 1 / p[4]), ("inv_j1", 1 / p[5]), ("inv_j2", 1 / p[6])]  # the last three depend on par only -> aux[]
+    return "RocketQuat", x, u, p, f, hoist
+
+
+def rocket2d():
+    """csrc/model_rocketquat.h: Rocket2dModel::systemFlowMap (rocket2d.cpp:7-38)"""
+    x = sp.symbols("x0:6", real=True)
+    u = sp.symbols("u0:2", real=True)
+    p = sp.symbols("p0:6", real=True)
+    TBx, TBy = -sp.sin(u[0]) * u[1], sp.cos(u[0]) * u[1]
+    ce, se = sp.cos(x[4]), sp.sin(x[4])
+    f = [x[2], x[3], (ce * TBx - se * TBy) / p[0] + p[2], (se * TBx + ce * TBy) / p[0] + p[3], x[5],
+         (p[4] * TBy - p[5] * TBx) / p[1]]
+    hoist = [("inv_m", 1 / p[0]), ("inv_j", 1 / p[1]), ("sin_g", sp.sin(u[0])), ("cos_g", sp.cos(u[0])),
+             ("sin_e", sp.sin(x[4])), ("cos_e", sp.cos(x[4]))]
+    return "Rocket2d", x, u, p, f, hoist
+
+
+def emit(model):
+    name, x, u, p, f, hoist = model
+    nx, nu = len(x), len(u)
+    pr = Printer()
+    subs = {**{x[i]: sp.Symbol("x[%d]" % i) for i in range(nx)}, **{u[i]: sp.Symbol("u[%d]" % i) for i in range(nu)},
+            **{p[i]: sp.Symbol("par[%d]" % i) for i in range(len(p))}}
+    v = list(x) + list(u)
+    lines = []
+    nnz = 0
+    lines.append("struct %sJacobianRows\n{" % name)
+    lines.append("    static constexpr int NX = %d, NU = %d;" % (nx, nu))
+    lines.append("    // jr[0 .. NX+NU): row `row` of [df/dx | df/du] at (x, u; par); returns f[row]")
+    lines.append("    // aux[NAUX]: sub-expressions of the parameters alone, computed once per kernel by prepare()")
+    lines.append("    __host__ __device__ static inline double row(int row, const double *x, const double *u, const double *par, const double *aux, double *jr)\n    {")
+    lines.append("        double fr = 0.;")
+    lines.append("#pragma unroll\n        for (int j = 0; j < NX + NU; j++)\n            jr[j] = 0.;")
+    hsym = [(sp.Symbol(n, real=True), e) for n, e in hoist]
+    psyms = set(p)
+    aux = [(n, e) for n, e in hoist if e.free_symbols and e.free_symbols <= psyms]  # functions of the parameters only
+    for n, e in hoist:
+        if (n, e) in aux:
+            lines.append("        const double %s = aux[%d];" % (n, aux.index((n, e))))
+        else:
+            lines.append("        const double %s = %s;" % (n, pr.doprint(e.subs(subs))))
+
+    def hoisted(e):
+        for sy, he in hsym:
+            if he.is_Pow and he.exp == -1:
+                # negative integer powers of the base become powers of the hoisted reciprocal (positive powers stay)
+                base = he.base
+                e = e.replace(lambda ex: ex.is_Pow and ex.base == base and ex.exp.is_Integer and ex.exp.is_negative,
+                              lambda ex: sy ** (-ex.exp))
+            else:
+                e = e.subs(he, sy)
+        return e
+
+    lines.append("        switch (row)\n        {")
+    for i in range(nx):
+        entries = [(j, sp.expand_trig(sp.diff(f[i], v[j])) if name == "Rocket2d" else sp.simplify(sp.diff(f[i], v[j]))) for j in range(nx + nu)]
+        entries = [(j, e) for j, e in entries if e != 0]
+        nnz += len(entries)
+        exprs = [hoisted(e) for e in [f[i]] + [e for _, e in entries]]
+        rep, red = sp.cse(exprs, symbols=sp.numbered_symbols("t%d_" % i), optimizations="basic")
+        lines.append("        case %d:\n        {" % i)
+        for s, e in rep:
+            lines.append("            const double %s = %s;" % (s, pr.doprint(e.subs(subs))))
+        lines.append("            fr = %s;" % pr.doprint(red[0].subs(subs)))
+        for (j, _), e in zip(entries, red[1:]):
+            lines.append("            jr[%d] = %s;" % (j, pr.doprint(e.subs(subs))))
+        lines.append("            break;\n        }")
+    lines.append("        default:\n            break;\n        }\n        return fr;\n    }")
+    lines.append("    static constexpr int NNZ = %d; // structural non-zeros of [df/dx | df/du]" % nnz)
+    lines.append("    static constexpr int NAUX = %d;" % max(1, len(aux)))
+    lines.append("    __host__ __device__ static inline void prepare(const double *par, double *aux)\n    {")
+    if not aux:
+        lines.append("        aux[0] = 0.;")
+    for k, (n, e) in enumerate(aux):
+        lines.append("        aux[%d] = %s; // %s" % (k, pr.doprint(e.subs(subs)), n))
+    lines.append("        (void)par;\n    }")
+    lines.append("};\n")
+    return "\n".join(lines)
+
+
+def main():
+    hdr = ["// GENERATED by tools/gen_model_jacobian.py (sympy %s) -- do not edit; regenerate after changing a flow map." % sp.__version__,
+           "// Analytic rows of [df/dx | df/du] of the model plugins (the build-time analogue of the reference's CppADCodeGen step,",
+           "// scpp_core/include/systemDynamics.hpp:109-168).  One `case` per state row: discretize_kernel keeps one Jacobian row per lane.",
+           "#pragma once", "#include \"common.h\"", "", "namespace scpp", "{", ""]
+    body = [emit(rocketquat()), emit(rocket2d())]
+    with open(OUT, "w") as fh:
+        fh.write("\n".join(hdr) + "\n".join(body) + "} // namespace scpp\n")
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
