@@ -5,7 +5,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_default
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --no-cpu-baseline --scvx-batch 0 > $OUT/trace.log 2>&1
+timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --no-cpu-baseline --scvx-batch 0 --mpc-batch 0 > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
 cd $ROOT
