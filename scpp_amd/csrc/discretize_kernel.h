@@ -56,7 +56,11 @@ struct DiscLayout
     // integrated psi_z to round-off (the defect ODE of that combination is exactly the reference's z ODE)
     static constexpr int NCOLS = 1 + NX + NU + (FOH ? NU : 0) + (VT ? 1 : 0);
     static constexpr int NENT = NX * NCOLS;
+#ifndef DISC_VALU_PRODUCT
+    static constexpr int NG = WAVE / 16;                                // lane groups: lane = g * 16 + row (MFMA operand rows)
+#else
     static constexpr int NG = WAVE / NX;                                // lane groups: lane = g * NX + row
+#endif
     static constexpr int EPL = (NCOLS + NG - 1) / NG;                   // columns per lane: col = m * NG + g
     // column order [x | psi_s | Phi | Psi_B | Psi_C]: with NG = 4 groups (RocketQuat) the B and the C columns each
     // fill one column slot m exactly, so their forcing terms need no per-lane selection
@@ -77,13 +81,25 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     using L = DiscLayout<Model, FOH, VT>;
     constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
 
+#ifndef DISC_VALU_PRODUCT
+    // (J V)' = V' J' on the matrix core: V' is the A operand of v_mfma_f64_16x16x4_f64, read straight from Ys (two column
+    // tiles; the contraction index runs to 16, so Ys is zero-filled once and padded to 32 columns), J' the B operand, taken
+    // from the Jacobian row each lane holds in registers.  No staging, no extra synchronisation.
+    static_assert(NX <= 16 && NCOLS + NG <= 32 && NG == 4, "one 16-row tile of states, two 16-column tiles of V");
+    __shared__ __attribute__((aligned(16))) double Ys[32 * NX + 2];
+#else
     __shared__ __attribute__((aligned(16))) double Ys[(NCOLS + NG) * NX]; // stage values of V (column-major: col*NX + row)
+#endif
     __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major
     __shared__ double fv[NX];                                              // f(x,u) (unscaled)
     // The stage slopes with the longest lifetimes (k1, k4, k5, k6: needed until stage 13) live in LDS, the others in
     // registers: all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceed the 256-VGPR budget of two waves
     // per SIMD and the spills went to scratch inside the AD chain.
+#ifdef DISC_KSLOTS_LDS
     __shared__ double Kl[4][EPL][WAVE];
+#else
+    __shared__ double Kl[1][1][1]; // unused: with the analytic rows and the MFMA product all 13 x EPL slopes fit in registers
+#endif
     // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 AD evaluations need.
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
     // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the AD phase.
@@ -95,6 +111,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     __shared__ double cst[NP + 2 * NU + NAUX + 1];
 
     const int lane = threadIdx.x;
+#ifndef DISC_VALU_PRODUCT
+    for (int i = lane; i < 32 * NX + 2; i += WAVE)
+        Ys[i] = 0.;
+#endif
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
     // give one XCD all K-1 segments of an instance (they re-read the same X/U/par lines).
     const int nseg = K - 1;
@@ -144,8 +164,15 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     WAVE_SYNC();
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
     // stage (kept in registers for all its columns) and one column of V per entry.
+#ifndef DISC_VALU_PRODUCT
+    // lane = g * 16 + row: the layout in which v_mfma_f64_16x16x4_f64 delivers (J V)' -- lane (g, row), accumulator register
+    // r holds the derivative of entry (row, col = g + 4 r), i.e. exactly the entries m = r this lane integrates
+    const int row = lane & 15, g = lane >> 4;
+    const bool lane_on = row < NX;
+#else
     const bool lane_on = lane < NG * NX;
     const int row = lane % NX, g = lane_on ? lane / NX : NG - 1;
+#endif
 #ifndef SCPP_HIP_EMU
     __builtin_assume(g >= 0 && g < NG);
 #endif
@@ -166,7 +193,11 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 
     double kk[RK_S][EPL];
+#ifdef DISC_KSLOTS_LDS
     constexpr int KSLOT[RK_S] = {0, -1, -1, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1}; // LDS slot of stage j, -1: registers
+#else
+    constexpr int KSLOT[RK_S] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}; // all stage slopes in registers
+#endif
     const double h = dt / 5.;
 #ifdef DISC_PROFILE
     long long tA = 0, tB = 0, tC = 0;
@@ -284,14 +315,33 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             // ---- derivative of the owned entries: d(row, c) = J[row,:] V[:,c] + forcing(row, c), branch-free ----
             {
                 const double alphaB = FOH ? (1. - frac) : 1.;
+#ifndef DISC_VALU_PRODUCT
+                d4_t acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const int kx = g + 4 * t; // contraction index = state j
+                    double b = (4 * t < NX) ? jr[4 * t < NX ? 4 * t : 0] : 0.; // J[row][kx]: pick jr[4t + g]; columns >= NX are the inputs' -> 0
+#pragma unroll
+                    for (int q = 1; q < 4; q++)
+                        b = (g == q) ? ((4 * t + q < NX) ? jr[4 * t + q < NX ? 4 * t + q : 0] : 0.) : b;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ys[row * NX + kx], b, acc0, 0, 0, 0);
+                    if (NCOLS > 16)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ys[(16 + row) * NX + kx], b, acc1, 0, 0, 0);
+                }
+#endif
 #pragma unroll
                 for (int m = 0; m < EPL; m++)
                 {
                     const int c = m * NG + g;
+#ifndef DISC_VALU_PRODUCT
+                    const double acc = m < 4 ? acc0[m < 4 ? m : 0] : acc1[m >= 4 ? m - 4 : 0];
+#else
                     double acc = 0.;
 #pragma unroll
                     for (int j = 0; j < NX; j++)
                         acc += jr[j] * Ys[c * NX + j];
+#endif
                     // forcing: B columns J[row, NX+j] * alpha ; C columns J[row, NX+j] * frac ; s column f ; x column: sigma f only.
                     // Which kinds can occur in slot m is a compile-time fact (m is a constant after unrolling).
                     double d = acc;
