@@ -104,7 +104,9 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
     // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the AD phase.
 #ifndef DISC_AD_JACOBIAN
-    constexpr int NAUX = Model::JacobianRows::NAUX; // parameter-only sub-expressions of the analytic rows
+    constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
+    constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
+    __shared__ double uh[5 * RK_S * (NUAUX + 1)]; // per stage time: input-only sub-expressions, then t / dt
 #else
     constexpr int NAUX = 0;
 #endif
@@ -161,6 +163,27 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             cst[NP + 2 * NU + i] = aux0[i];
 #endif
     }
+#ifndef DISC_AD_JACOBIAN
+    {
+        // the input is a known function of time: u(t) at each of the 5 x 13 stage times and what the rows need of it alone
+        // (|T|, 1/|T| for RocketQuat) are computed once here, one stage time per lane
+        const double hh = dt / 5.;
+        for (int e = lane; e < 5 * RK_S; e += WAVE)
+        {
+            const double tse = double(e / RK_S) * hh + RK_C[e % RK_S] * hh;
+            const double fre = FOH ? tse / dt : 0.;
+            double ue[NU], ua[NUAUX];
+#pragma unroll
+            for (int i = 0; i < NU; i++)
+                ue[i] = u0[i] + fre * (u1[i] - u0[i]);
+            Model::JacobianRows::prepareInput(ue, p, ua);
+#pragma unroll
+            for (int i = 0; i < NUAUX; i++)
+                uh[e * (NUAUX + 1) + i] = ua[i];
+            uh[e * (NUAUX + 1) + NUAUX] = fre;
+        }
+    }
+#endif
     WAVE_SYNC();
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
     // stage (kept in registers for all its columns) and one column of V per entry.
@@ -234,7 +257,11 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             const long long p1 = clock64();
             tA += p1 - p0;
 #endif
+#ifndef DISC_AD_JACOBIAN
+            const double frac = FOH ? uh[(step * RK_S + s) * (NUAUX + 1) + NUAUX] : 0.; // t / dt, tabulated with the input
+#else
             const double frac = FOH ? ts / dt : 0.;
+#endif
             double jr[NJ]; // my row of [sigma*A | sigma*B]
             double fr;     // f[row] (unscaled)
 #ifndef DISC_AD_JACOBIAN
@@ -245,7 +272,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 asm volatile("" : "+v"(zo));
 #endif
                 const double *cv = cst + zo;
-                double pl[NP], xs[NX], us[NU], ax[NAUX];
+                double pl[NP], xs[NX], us[NU], ax[NAUX], ux[NUAUX];
+#pragma unroll
+                for (int i = 0; i < NUAUX; i++)
+                    ux[i] = uh[(step * RK_S + s) * (NUAUX + 1) + i];
 #pragma unroll
                 for (int i = 0; i < NP; i++)
                     pl[i] = cv[i];
@@ -261,10 +291,12 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                     const double a0 = cv[NP + i], a1 = cv[NP + NU + i];
                     us[i] = a0 + frac * (a1 - a0);
                 }
-                fr = Model::JacobianRows::row(row, xs, us, pl, ax, jr);
+                fr = Model::JacobianRows::row(row, xs, us, pl, ax, ux, jr);
+#ifdef DISC_VALU_PRODUCT
 #pragma unroll
                 for (int j = 0; j < NJ; j++)
                     jr[j] *= tscale;
+#endif
             }
 #else
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
@@ -325,6 +357,9 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
                     for (int q = 1; q < 4; q++)
                         b = (g == q) ? ((4 * t + q < NX) ? jr[4 * t + q < NX ? 4 * t + q : 0] : 0.) : b;
+#ifndef DISC_AD_JACOBIAN
+                    b *= tscale; // sigma scaling of A applied to the four entries this lane contributes
+#endif
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ys[row * NX + kx], b, acc0, 0, 0, 0);
                     if (NCOLS > 16)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ys[(16 + row) * NX + kx], b, acc1, 0, 0, 0);
@@ -357,7 +392,11 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
                         for (int q = 1; q < NU; q++)
                             jb = (jj == q) ? jr[NX + q] : jb;
+#if !defined(DISC_VALU_PRODUCT) && !defined(DISC_AD_JACOBIAN)
+                        d += (w * tscale) * jb; // sigma scaling of B
+#else
                         d += w * jb;
+#endif
                     }
                     if (VT && m * NG <= L::COL_S && m * NG + NG > L::COL_S)
                         d = (c == L::COL_S) ? d + fr : d;

@@ -24,12 +24,13 @@ template <class M> int run()
         for (auto &v : x) if (scanf("%lf", &v) != 1) return 1;
         for (auto &v : u) if (scanf("%lf", &v) != 1) return 1;
         for (auto &v : p) if (scanf("%lf", &v) != 1) return 1;
-        double aux[M::JacobianRows::NAUX];
+        double aux[M::JacobianRows::NAUX], uaux[M::JacobianRows::NUAUX];
         M::JacobianRows::prepare(p, aux);
+        M::JacobianRows::prepareInput(u, p, uaux);
         for (int r = 0; r < NX; r++)
         {
             double jr[NJ];
-            const double f = M::JacobianRows::row(r, x, u, p, aux, jr);
+            const double f = M::JacobianRows::row(r, x, u, p, aux, uaux, jr);
             printf("%.17g", f);
             for (int j = 0; j < NJ; j++) printf(" %.17g", jr[j]);
             printf("\n");

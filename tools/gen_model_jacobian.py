@@ -98,15 +98,26 @@ def emit(model):
     lines.append("    static constexpr int NX = %d, NU = %d;" % (nx, nu))
     lines.append("    // jr[0 .. NX+NU): row `row` of [df/dx | df/du] at (x, u; par); returns f[row]")
     lines.append("    // aux[NAUX]: sub-expressions of the parameters alone, computed once per kernel by prepare()")
-    lines.append("    __host__ __device__ static inline double row(int row, const double *x, const double *u, const double *par, const double *aux, double *jr)\n    {")
+    lines.append("    // uaux[NUAUX]: sub-expressions of the input (and parameters) alone, tabulated per stage time by prepareInput()")
+    lines.append("    __host__ __device__ static inline double row(int row, const double *x, const double *u, const double *par, const double *aux, const double *uaux, double *jr)\n    {")
     lines.append("        double fr = 0.;")
     lines.append("#pragma unroll\n        for (int j = 0; j < NX + NU; j++)\n            jr[j] = 0.;")
     hsym = [(sp.Symbol(n, real=True), e) for n, e in hoist]
-    psyms = set(p)
+    psyms, usyms = set(p), set(u)
     aux = [(n, e) for n, e in hoist if e.free_symbols and e.free_symbols <= psyms]  # functions of the parameters only
+    # functions of the input (and parameters / earlier input-only hoists) alone: the input is a known function of time, so
+    # the kernel tabulates them once per (step, stage) instead of once per evaluation
+    uaux, unames = [], set()
+    for n, e in hoist:
+        fs = e.free_symbols
+        if (n, e) not in aux and fs and fs <= (psyms | usyms | {sp.Symbol(m, real=True) for m in unames}) and (fs - psyms):
+            uaux.append((n, e))
+            unames.add(n)
     for n, e in hoist:
         if (n, e) in aux:
             lines.append("        const double %s = aux[%d];" % (n, aux.index((n, e))))
+        elif (n, e) in uaux:
+            lines.append("        const double %s = uaux[%d];" % (n, uaux.index((n, e))))
         else:
             lines.append("        const double %s = %s;" % (n, pr.doprint(e.subs(subs))))
 
@@ -144,6 +155,14 @@ def emit(model):
     for k, (n, e) in enumerate(aux):
         lines.append("        aux[%d] = %s; // %s" % (k, pr.doprint(e.subs(subs)), n))
     lines.append("        (void)par;\n    }")
+    lines.append("    static constexpr int NUAUX = %d;" % max(1, len(uaux)))
+    lines.append("    __host__ __device__ static inline void prepareInput(const double *u, const double *par, double *uaux)\n    {")
+    if not uaux:
+        lines.append("        uaux[0] = 0.;")
+    for k, (n, e) in enumerate(uaux):
+        lines.append("        const double %s = %s;" % (n, pr.doprint(e.subs(subs))))
+        lines.append("        uaux[%d] = %s;" % (k, n))
+    lines.append("        (void)u;\n        (void)par;\n    }")
     lines.append("};\n")
     return "\n".join(lines)
 
