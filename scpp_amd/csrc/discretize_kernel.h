@@ -90,19 +90,19 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #else
     __shared__ __attribute__((aligned(16))) double Ys[(NCOLS + NG) * NX]; // stage values of V (column-major: col*NX + row)
 #endif
-    __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major
-    __shared__ double fv[NX];                                              // f(x,u) (unscaled)
-    // The stage slopes with the longest lifetimes (k1, k4, k5, k6: needed until stage 13) live in LDS, the others in
-    // registers: all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceed the 256-VGPR budget of two waves
-    // per SIMD and the spills went to scratch inside the AD chain.
+    __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major (-DDISC_AD_JACOBIAN only)
+    __shared__ double fv[NX];                                              // f(x,u) (unscaled)            (-DDISC_AD_JACOBIAN only)
+    // -DDISC_KSLOTS_LDS keeps the stage slopes with the longest lifetimes (k1, k4, k5, k6: needed until stage 13) in LDS:
+    // with the forward-mode AD path all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceeded the 256-VGPR
+    // budget of two waves per SIMD and spilled inside the AD chain.  The default path needs no such slots.
 #ifdef DISC_KSLOTS_LDS
     __shared__ double Kl[4][EPL][WAVE];
 #else
     __shared__ double Kl[1][1][1]; // unused: with the analytic rows and the MFMA product all 13 x EPL slopes fit in registers
 #endif
-    // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 AD evaluations need.
+    // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 row evaluations need.
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
-    // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the AD phase.
+    // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the evaluation phase.
 #ifndef DISC_AD_JACOBIAN
     constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
