@@ -106,7 +106,15 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #ifndef DISC_AD_JACOBIAN
     constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
-    __shared__ double uh[5 * RK_S * (NUAUX + 1)]; // per stage time: input-only sub-expressions, then t / dt
+    constexpr int UHP = NUAUX + 1 + NU;           // per stage time: input-only sub-expressions, t / dt, u(t)
+    __shared__ double uh[5 * RK_S * UHP];
+#if !defined(DISC_VALU_PRODUCT) && !defined(DISC_SWITCH_ROWS)
+#define DISC_TABLE_ROWS 1
+    // Jacobian entries as a lane-parallel table (Model::JacobianTable): one output per lane per pass instead of one divergent
+    // `case` per row; W holds the operands, the partial sums and the outputs [J | f]
+    using TB = typename Model::JacobianTable;
+    __shared__ __attribute__((aligned(16))) double Wt[TB::NW];
+#endif
 #else
     constexpr int NAUX = 0;
 #endif
@@ -179,12 +187,48 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             Model::JacobianRows::prepareInput(ue, p, ua);
 #pragma unroll
             for (int i = 0; i < NUAUX; i++)
-                uh[e * (NUAUX + 1) + i] = ua[i];
-            uh[e * (NUAUX + 1) + NUAUX] = fre;
+                uh[e * UHP + i] = ua[i];
+            uh[e * UHP + NUAUX] = fre;
+#pragma unroll
+            for (int i = 0; i < NU; i++)
+                uh[e * UHP + NUAUX + 1 + i] = ue[i];
         }
     }
 #endif
+#ifdef DISC_TABLE_ROWS
+    for (int i = lane; i < TB::NW; i += WAVE)
+        Wt[i] = (i == TB::W_ONE) ? 1. : 0.;
+#endif
     WAVE_SYNC();
+#ifdef DISC_TABLE_ROWS
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            Wt[TB::W_PAR + i] = p[i];
+#pragma unroll
+        for (int i = 0; i < NAUX; i++)
+            Wt[TB::W_AUX + i] = cst[NP + 2 * NU + i];
+    }
+    // this lane's two table slots: coefficients and the LDS byte offsets of the factors (two 16-bit offsets per word)
+    double tcf[2][TB::MAXMON];
+    unsigned tof[2][TB::MAXMON][2];
+    int ttg[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++)
+    {
+        const int slot = ps * 64 + lane;
+        ttg[ps] = TB::target(slot);
+#pragma unroll
+        for (int q = 0; q < TB::MAXMON; q++)
+        {
+            tcf[ps][q] = TB::coef(slot, q);
+            tof[ps][q][0] = unsigned(TB::factor(slot, q, 0) * 8) | (unsigned(TB::factor(slot, q, 1) * 8) << 16);
+            tof[ps][q][1] = unsigned(TB::factor(slot, q, 2) * 8) | (unsigned(TB::factor(slot, q, 3) * 8) << 16);
+        }
+    }
+    WAVE_SYNC();
+#endif
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
     // stage (kept in registers for all its columns) and one column of V per entry.
 #ifndef DISC_VALU_PRODUCT
@@ -251,6 +295,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 const double ys = y[m] + h * acc;
                 if (eon[m])
                     Ys[(m * NG + g) * NX + row] = ys;
+#ifdef DISC_TABLE_ROWS
+                if (m == 0 && g == 0 && lane_on)
+                    Wt[TB::W_X + row] = ys; // the state column is also operand x of the Jacobian table
+#endif
             }
             WAVE_SYNC();
 #ifdef DISC_PROFILE
@@ -258,13 +306,60 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             tA += p1 - p0;
 #endif
 #ifndef DISC_AD_JACOBIAN
-            const double frac = FOH ? uh[(step * RK_S + s) * (NUAUX + 1) + NUAUX] : 0.; // t / dt, tabulated with the input
+            const double frac = FOH ? uh[(step * RK_S + s) * UHP + NUAUX] : 0.; // t / dt, tabulated with the input
 #else
             const double frac = FOH ? ts / dt : 0.;
 #endif
             double jr[NJ]; // my row of [sigma*A | sigma*B]
             double fr;     // f[row] (unscaled)
-#ifndef DISC_AD_JACOBIAN
+#ifdef DISC_TABLE_ROWS
+            double bsel[4];
+            {
+                const int e = step * RK_S + s;
+                // operands that change with the stage: u(t), the input-only terms, the state-dependent terms
+                if (lane < NU)
+                    Wt[TB::W_U + lane] = uh[e * UHP + NUAUX + 1 + lane];
+                else if (lane < NU + NUAUX)
+                    Wt[TB::W_UAUX + lane - NU] = uh[e * UHP + lane - NU];
+                {
+                    double hh[TB::NH];
+                    TB::evalHoists(Ys, uh + e * UHP + NUAUX + 1, cst, cst + NP + 2 * NU, uh + e * UHP, hh);
+                    if (lane == 0)
+                    {
+#pragma unroll
+                        for (int i = 0; i < TB::NH; i++)
+                            Wt[TB::W_H + i] = hh[i];
+                    }
+                }
+                WAVE_SYNC();
+                const char *wb = reinterpret_cast<const char *>(Wt);
+#pragma unroll
+                for (int ps = 0; ps < 2; ps++)
+                {
+                    double val = 0.;
+#pragma unroll
+                    for (int q = 0; q < TB::MAXMON; q++)
+                    {
+                        const double f0 = *reinterpret_cast<const double *>(wb + (tof[ps][q][0] & 0xFFFFu));
+                        const double f1 = *reinterpret_cast<const double *>(wb + (tof[ps][q][0] >> 16));
+                        const double f2 = *reinterpret_cast<const double *>(wb + (tof[ps][q][1] & 0xFFFFu));
+                        const double f3 = *reinterpret_cast<const double *>(wb + (tof[ps][q][1] >> 16));
+                        val += ((tcf[ps][q] * f0) * f1) * (f2 * f3);
+                    }
+                    if (ttg[ps] >= 0)
+                        Wt[ttg[ps]] = val;
+                    WAVE_SYNC();
+                }
+                const int rowc = lane_on ? row : 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const double v = Wt[TB::W_J + rowc * NJ + (4 * t + g < NX ? 4 * t + g : 0)];
+                    bsel[t] = (4 * t + g < NX) ? v : 0.; // columns >= NX belong to the inputs
+                }
+                fr = Wt[TB::W_F + rowc];
+            }
+#elif !defined(DISC_AD_JACOBIAN)
             {
                 // ---- analytic non-zeros of my Jacobian row at the stage point (no exchange through LDS) ----
                 int zo = 0; // opaque zero offset: keeps the LDS reads of the wave-uniform constants inside the stage (see cst)
@@ -275,7 +370,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 double pl[NP], xs[NX], us[NU], ax[NAUX], ux[NUAUX];
 #pragma unroll
                 for (int i = 0; i < NUAUX; i++)
-                    ux[i] = uh[(step * RK_S + s) * (NUAUX + 1) + i];
+                    ux[i] = uh[(step * RK_S + s) * UHP + i];
 #pragma unroll
                 for (int i = 0; i < NP; i++)
                     pl[i] = cv[i];
@@ -353,10 +448,14 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 for (int t = 0; t < 4; t++)
                 {
                     const int kx = g + 4 * t; // contraction index = state j
+#ifdef DISC_TABLE_ROWS
+                    double b = bsel[t];
+#else
                     double b = (4 * t < NX) ? jr[4 * t < NX ? 4 * t : 0] : 0.; // J[row][kx]: pick jr[4t + g]; columns >= NX are the inputs' -> 0
 #pragma unroll
                     for (int q = 1; q < 4; q++)
                         b = (g == q) ? ((4 * t + q < NX) ? jr[4 * t + q < NX ? 4 * t + q : 0] : 0.) : b;
+#endif
 #ifndef DISC_AD_JACOBIAN
                     b *= tscale; // sigma scaling of A applied to the four entries this lane contributes
 #endif
@@ -388,10 +487,14 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                         const bool isC = FOH && c >= L::COL_C && c < L::COL_C + NU;
                         const int jj = isB ? c - L::COL_B : isC ? c - L::COL_C : 0;
                         const double w = isB ? alphaB : isC ? frac : 0.;
+#ifdef DISC_TABLE_ROWS
+                        const double jb = Wt[TB::W_J + (lane_on ? row : 0) * NJ + NX + jj]; // J[row, NX + jj], jj is lane dependent
+#else
                         double jb = jr[NX]; // J[row, NX + jj], jj is lane dependent
 #pragma unroll
                         for (int q = 1; q < NU; q++)
                             jb = (jj == q) ? jr[NX + q] : jb;
+#endif
 #if !defined(DISC_VALU_PRODUCT) && !defined(DISC_AD_JACOBIAN)
                         d += (w * tscale) * jb; // sigma scaling of B
 #else

@@ -19,6 +19,7 @@ struct RocketQuatModel
     // optional: analytic rows of [df/dx | df/du], generated from this flow map by tools/gen_model_jacobian.py (the
     // reference's CppADCodeGen step at build time); kernels fall back to forward-mode AD of systemFlowMap<Dual1> without it
     using JacobianRows = RocketQuatJacobianRows;
+    using JacobianTable = RocketQuatJacobianTable; // the same, one output per lane (discretize_kernel)
 
     // par = [alpha_m, g_I(3), J_B(3), r_T_B(3)]   rocketQuat.cpp:168-173
     template <class T>
@@ -62,6 +63,7 @@ struct Rocket2dModel
     static constexpr int NX = 6, NU = 2, NP = 6;
     static constexpr int MODEL_ID = 1;
     using JacobianRows = Rocket2dJacobianRows;
+    using JacobianTable = Rocket2dJacobianTable;
     template <class T>
     __host__ __device__ static void systemFlowMap(const T *x, const T *u, const double *par, T *f)
     {

@@ -35,6 +35,44 @@ template <class M> int run()
             for (int j = 0; j < NJ; j++) printf(" %.17g", jr[j]);
             printf("\n");
         }
+        // the lane-parallel table form, evaluated the way discretize_kernel does (two passes over 64 slots)
+        {
+            using T = typename M::JacobianTable;
+            double W[T::NW] = {};
+            for (int i = 0; i < NX; i++) W[T::W_X + i] = x[i];
+            for (int i = 0; i < NU; i++) W[T::W_U + i] = u[i];
+            for (int i = 0; i < NP; i++) W[T::W_PAR + i] = p[i];
+            for (int i = 0; i < M::JacobianRows::NAUX; i++) W[T::W_AUX + i] = aux[i];
+            for (int i = 0; i < M::JacobianRows::NUAUX; i++) W[T::W_UAUX + i] = uaux[i];
+            double h[T::NH];
+            T::evalHoists(x, u, p, aux, uaux, h);
+            for (int i = 0; i < T::NH; i++) W[T::W_H + i] = h[i];
+            W[T::W_ONE] = 1.;
+            for (int pass = 0; pass < 2; pass++)
+            {
+                double val[64];
+                for (int l = 0; l < 64; l++)
+                {
+                    const int slot = pass * 64 + l;
+                    double a = 0.;
+                    for (int q = 0; q < T::MAXMON; q++)
+                    {
+                        double m = T::coef(slot, q);
+                        for (int k = 0; k < T::MAXFAC; k++) m *= W[T::factor(slot, q, k)];
+                        a += m;
+                    }
+                    val[l] = a;
+                }
+                for (int l = 0; l < 64; l++)
+                    if (T::target(pass * 64 + l) >= 0) W[T::target(pass * 64 + l)] = val[l];
+            }
+            for (int r = 0; r < NX; r++)
+            {
+                printf("%.17g", W[T::W_F + r]);
+                for (int j = 0; j < NJ; j++) printf(" %.17g", W[T::W_J + r * NJ + j]);
+                printf("\n");
+            }
+        }
         // forward-mode AD of the plugin's flow map, one direction at a time
         for (int d = 0; d < NJ; d++)
         {
@@ -69,16 +107,18 @@ def test_generated_rows_match_sympy_golden_and_forward_ad(rows_bin, name, flag, 
     inp = str(n) + "\n" + "\n".join(" ".join(repr(float(v)) for v in np.concatenate([g["x"][i], g["u"][i], g["par"][i]])) for i in range(n))
     out = subprocess.run([rows_bin, flag], input=inp, capture_output=True, text=True, check=True).stdout
     vals = np.array([[float(t) for t in line.split()] for line in out.strip().split("\n")], dtype=object)
-    per = nx + (nx + nu)
+    per = nx + nx + (nx + nu)
     for i in range(n):
         blk = vals[i * per:(i + 1) * per]
         rows = np.array([r for r in blk[:nx]], dtype=float)          # [f | A row | B row]
-        ad = np.array([r for r in blk[nx:]], dtype=float).T             # [NX][NJ]
+        tab = np.array([r for r in blk[nx:2 * nx]], dtype=float)      # the same from the lane-parallel table
+        ad = np.array([r for r in blk[2 * nx:]], dtype=float).T        # [NX][NJ]
         f, A, B = rows[:, 0], rows[:, 1:1 + nx], rows[:, 1 + nx:]
         scale = max(1.0, np.abs(g["A"][i]).max(), np.abs(g["B"][i]).max())
         assert np.abs(f - g["f"][i]).max() <= 1e-13 * max(1.0, np.abs(g["f"][i]).max())
         assert np.abs(A - g["A"][i]).max() <= 1e-13 * scale and np.abs(B - g["B"][i]).max() <= 1e-13 * scale
         assert np.abs(np.hstack([A, B]) - ad).max() <= 1e-13 * scale
+        assert np.abs(tab - rows).max() <= 1e-13 * max(scale, np.abs(rows[:, 0]).max())
 
 
 def test_generated_header_is_up_to_date(tmp_path):

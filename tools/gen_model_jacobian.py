@@ -167,12 +167,160 @@ def emit(model):
     return "\n".join(lines)
 
 
+MAXMON, MAXFAC = 4, 4  # monomials per table slot, factors per monomial
+
+
+def emit_table(model):
+    """Lane-parallel form of the same Jacobian: every structural non-zero (and f) is a short polynomial in the vector
+    W = [x | u | par | aux | uaux | h | 1 | partial sums | J | f]; one table slot = one output = at most MAXMON monomials of
+    at most MAXFAC factors.  Outputs with more monomials are split into partial sums (level 1) that a level-2 slot adds."""
+    name, x, u, p, f, hoist = model
+    nx, nu, npar = len(x), len(u), len(p)
+    nj = nx + nu
+    pr = Printer()
+    psyms, usyms, xsyms = set(p), set(u), set(x)
+    hsym = [(sp.Symbol(n, real=True), e) for n, e in hoist]
+    names = {}
+    aux, uaux, hev = [], [], []
+    for (n, e), (sy, _) in zip(hoist, hsym):
+        fs = e.free_symbols - {s_ for s_, _ in hsym}
+        dep = set()
+        for s_, _ in hsym:
+            if s_ in e.free_symbols:
+                dep |= names[s_]
+        kinds = set(dep)
+        if fs & xsyms:
+            kinds.add("x")
+        if fs & usyms:
+            kinds.add("u")
+        names[sy] = kinds
+        (hev if "x" in kinds else uaux if "u" in kinds else aux).append((n, e, sy))
+    # extra per-evaluation hoists: squares of per-evaluation reciprocals keep the degree within MAXFAC
+    sq = [(n + "2", sy * sy, sp.Symbol(n + "2", real=True)) for n, e, sy in hev if e.is_Pow and e.exp == -1]
+    hev_all = hev + sq
+    W = list(x) + list(u) + list(p) + [sy for _, _, sy in aux] + [sy for _, _, sy in uaux] + [sy for _, _, sy in hev_all]
+    W_ONE = len(W)
+    base = dict(W_X=0, W_U=nx, W_PAR=nx + nu, W_AUX=nx + nu + npar, W_UAUX=nx + nu + npar + len(aux),
+                W_H=nx + nu + npar + len(aux) + len(uaux), W_ONE=W_ONE)
+    widx = {sy: i for i, sy in enumerate(W)}
+
+    def hoisted(e):
+        for sy, he in hsym:
+            if he.is_Pow and he.exp == -1:
+                b = he.base
+                e = e.replace(lambda ex: ex.is_Pow and ex.base == b and ex.exp.is_Integer and ex.exp.is_negative,
+                              lambda ex: sy ** (-ex.exp))
+            else:
+                e = e.subs(he, sy)
+        for n, e2, sy2 in sq:
+            root = sp.Symbol(n[:-1], real=True)
+            e = e.replace(lambda ex: ex.is_Pow and ex.base == root and ex.exp == 2, lambda ex: sy2)
+        return sp.expand(sp.expand_trig(e) if name == "Rocket2d" else e)
+
+    def monomials(e):
+        out = []
+        for t in sp.Add.make_args(sp.expand(e)):
+            c, rest = t.as_coeff_Mul()
+            fac = []
+            for b_, ex in rest.as_powers_dict().items():
+                if b_ == 1:
+                    continue
+                assert ex.is_Integer and ex > 0 and b_ in widx, (name, t, b_)
+                fac += [widx[b_]] * int(ex)
+            assert len(fac) <= MAXFAC, (name, t)
+            out.append((float(c), fac))
+        return out
+
+    v = list(x) + list(u)
+    outputs = []  # (target kind, index, monomials)
+    for i in range(nx):
+        outputs.append(("f", i, monomials(hoisted(f[i]))))
+        for j in range(nj):
+            d = sp.diff(f[i], v[j])
+            if d != 0:
+                outputs.append(("J", i * nj + j, monomials(hoisted(sp.simplify(d) if name != "Rocket2d" else d))))
+    parts, level1, level2 = [], [], []
+    for kind, idx, mons in outputs:
+        if len(mons) <= MAXMON:
+            level1.append((kind, idx, mons))
+            continue
+        chunks = [mons[k:k + MAXMON] for k in range(0, len(mons), MAXMON)]
+        assert len(chunks) <= MAXMON
+        ids = []
+        for ch in chunks:
+            ids.append(len(parts))
+            parts.append(ch)
+        level2.append((kind, idx, ids))
+    npart = len(parts)
+    W_PART = W_ONE + 1
+    W_J = W_PART + npart
+    W_F = W_J + nx * nj
+    NW = W_F + nx
+
+    def tgt(kind, idx):
+        return W_F + idx if kind == "f" else W_J + idx
+
+    slots = [(W_PART + k, ch) for k, ch in enumerate(parts)] + [(tgt(k_, i_), m_) for k_, i_, m_ in level1]
+    n1 = len(slots)
+    assert npart <= 64 and n1 <= 64 + 40
+    passA, rest = slots[:64], slots[64:]
+    passB = rest + [(tgt(k_, i_), [(1.0, [W_PART + q]) for q in ids]) for k_, i_, ids in level2]
+    assert len(passB) <= 64
+    allslots = passA + [(-1, [])] * (64 - len(passA)) + passB + [(-1, [])] * (64 - len(passB))
+    coef, offs, targ = [], [], []
+    for t_, mons in allslots:
+        targ.append(t_)
+        for q in range(MAXMON):
+            if q < len(mons):
+                c, fac = mons[q]
+                fac = fac + [W_ONE] * (MAXFAC - len(fac))
+            else:
+                c, fac = 0.0, [W_ONE] * MAXFAC
+            coef.append(c)
+            offs += fac
+    L = []
+    L.append("// Lane-parallel table form of the same Jacobian (see tools/gen_model_jacobian.py: emit_table)")
+    L.append("struct %sJacobianTable\n{" % name)
+    L.append("    static constexpr int NX = %d, NU = %d, NP = %d, NJ = %d, NAUX = %d, NUAUX = %d, NH = %d, NPART = %d;" %
+             (nx, nu, npar, nj, max(1, len(aux)), max(1, len(uaux)), max(1, len(hev_all)), npart))
+    L.append("    // W = [x | u | par | aux | uaux | h | 1 | partial sums | J (row-major, pitch NJ) | f]")
+    L.append("    static constexpr int %s, W_PART = %d, W_J = %d, W_F = %d, NW = %d;" %
+             (", ".join("%s = %d" % kv for kv in base.items()), W_PART, W_J, W_F, NW))
+    L.append("    static constexpr int MAXMON = %d, MAXFAC = %d, NSLOT = 128, NOUT = %d, NLEVEL1 = %d;" % (MAXMON, MAXFAC, len(outputs), n1))
+    L.append("    // slot s < 64: first pass (lane s), s >= 64: second pass (lane s - 64); the partial sums are all produced in the first")
+    L.append("    __host__ __device__ static inline double coef(int slot, int q)\n    {")
+    L.append("        static const double T[NSLOT * MAXMON] = {%s};" % ", ".join(repr(c) for c in coef))
+    L.append("        return T[slot * MAXMON + q];\n    }")
+    L.append("    __host__ __device__ static inline int factor(int slot, int q, int k) // index into W\n    {")
+    L.append("        static const unsigned short T[NSLOT * MAXMON * MAXFAC] = {%s};" % ", ".join(str(o) for o in offs))
+    L.append("        return T[(slot * MAXMON + q) * MAXFAC + k];\n    }")
+    L.append("    __host__ __device__ static inline int target(int slot) // index into W, -1: idle slot\n    {")
+    L.append("        static const short T[NSLOT] = {%s};" % ", ".join(str(t_) for t_ in targ))
+    L.append("        return T[slot];\n    }")
+    xs_ = {**{x[i]: sp.Symbol("x[%d]" % i) for i in range(nx)}, **{u[i]: sp.Symbol("u[%d]" % i) for i in range(nu)},
+           **{p[i]: sp.Symbol("par[%d]" % i) for i in range(npar)}}
+    L.append("    // per-evaluation sub-expressions h[NH] (they depend on the state)")
+    L.append("    __host__ __device__ static inline void evalHoists(const double *x, const double *u, const double *par, const double *aux, const double *uaux, double *h)\n    {")
+    for k, (n, e, sy) in enumerate(aux):
+        L.append("        const double %s = aux[%d];" % (n, k))
+    for k, (n, e, sy) in enumerate(uaux):
+        L.append("        const double %s = uaux[%d];" % (n, k))
+    for k, (n, e, sy) in enumerate(hev_all):
+        L.append("        const double %s = %s;" % (n, pr.doprint(e.subs(xs_))))
+        L.append("        h[%d] = %s;" % (k, n))
+    if not hev_all:
+        L.append("        h[0] = 0.;")
+    L.append("        (void)x; (void)u; (void)par; (void)aux; (void)uaux;\n    }")
+    L.append("};\n")
+    return "\n".join(L)
+
+
 def main():
     hdr = ["// GENERATED by tools/gen_model_jacobian.py (sympy %s) -- do not edit; regenerate after changing a flow map." % sp.__version__,
            "// Analytic rows of [df/dx | df/du] of the model plugins (the build-time analogue of the reference's CppADCodeGen step,",
            "// scpp_core/include/systemDynamics.hpp:109-168).  One `case` per state row: discretize_kernel keeps one Jacobian row per lane.",
            "#pragma once", "#include \"common.h\"", "", "namespace scpp", "{", ""]
-    body = [emit(rocketquat()), emit(rocket2d())]
+    body = [emit(rocketquat()), emit_table(rocketquat()), emit(rocket2d()), emit_table(rocket2d())]
     with open(OUT, "w") as fh:
         fh.write("\n".join(hdr) + "\n".join(body) + "} // namespace scpp\n")
     print("wrote", OUT)
