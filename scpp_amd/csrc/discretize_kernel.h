@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                 {
                     double val = 0.;
 #pragma unroll
-                    for (int q = 0; q < TB::MAXMON; q++)
+                    for (int q = 0; q < (ps == 0 ? TB::MAXMON : TB::MAXMON_B); q++)
                     {
                         const double f0 = *reinterpret_cast<const double *>(wb + (tof[ps][q][0] & 0xFFFFu));
                         const double f1 = *reinterpret_cast<const double *>(wb + (tof[ps][q][0] >> 16));

@@ -260,6 +260,9 @@ def emit_table(model):
     def tgt(kind, idx):
         return W_F + idx if kind == "f" else W_J + idx
 
+    # largest level-1 outputs first: what spills into the second pass is then the single-monomial entries, and that pass
+    # (shared with the level-2 sums) needs fewer monomials per slot
+    level1.sort(key=lambda o: -len(o[2]))
     slots = [(W_PART + k, ch) for k, ch in enumerate(parts)] + [(tgt(k_, i_), m_) for k_, i_, m_ in level1]
     n1 = len(slots)
     assert npart <= 64 and n1 <= 64 + 40
@@ -267,6 +270,7 @@ def emit_table(model):
     passB = rest + [(tgt(k_, i_), [(1.0, [W_PART + q]) for q in ids]) for k_, i_, ids in level2]
     assert len(passB) <= 64
     allslots = passA + [(-1, [])] * (64 - len(passA)) + passB + [(-1, [])] * (64 - len(passB))
+    maxmon_b = max([len(m_) for _, m_ in passB] + [1])
     coef, offs, targ = [], [], []
     for t_, mons in allslots:
         targ.append(t_)
@@ -287,6 +291,7 @@ def emit_table(model):
     L.append("    static constexpr int %s, W_PART = %d, W_J = %d, W_F = %d, NW = %d;" %
              (", ".join("%s = %d" % kv for kv in base.items()), W_PART, W_J, W_F, NW))
     L.append("    static constexpr int MAXMON = %d, MAXFAC = %d, NSLOT = 128, NOUT = %d, NLEVEL1 = %d;" % (MAXMON, MAXFAC, len(outputs), n1))
+    L.append("    static constexpr int MAXMON_B = %d; // monomials per slot actually used in the second pass" % maxmon_b)
     L.append("    // slot s < 64: first pass (lane s), s >= 64: second pass (lane s - 64); the partial sums are all produced in the first")
     L.append("    __host__ __device__ static inline double coef(int slot, int q)\n    {")
     L.append("        static const double T[NSLOT * MAXMON] = {%s};" % ", ".join(repr(c) for c in coef))
