@@ -139,3 +139,30 @@ def test_emu_config_variants(oracle, emu_lib, tmp_path):
     for b in np.nonzero(ok)[0]:
         assert np.abs(out["X"][b] - ref["X"][b]).max() <= 1e-6 * np.abs(ref["X"][b]).max()
         assert np.abs(out["U"][b] - ref["U"][b]).max() <= 1e-5 * np.abs(ref["U"][b]).max()
+
+
+def test_emu_discretize_fixed_time_and_rocket2d(oracle, emu_lib):
+    """The other two instantiations of discretize_kernel on the emulator: FOH + fixed final time (RocketQuat, SCvx variant) and
+    the Rocket2d plugin -- both go through the generated Jacobian table and the matrix-core product of their own shape."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rocketquat_dd_K15.npz"))
+    ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, 15, 1, library=emu_lib)
+    ctx.set_flow_params(g["par"][None]); ctx.upload_traj(g["X"][None], g["U"][None], [float(g["t"])])
+    ctx.discretize(scpp_amd.MODE_FOH)
+    out = ctx.download_dd()
+    ref = oracle.discretize(0, g["par"], g["X"], g["U"], float(g["t"]), foh=True, vt=False)
+    for k in (0, 1, 2, 4):
+        assert np.abs(out[k][0] - ref[k]).max() <= 1e-10 * max(1.0, np.abs(ref[k]).max())
+    ctx.close()
+    sc = oracle.SC(oracle.ROCKET2D); sc.solve()
+    X, U, t = sc.iterate(1)
+    s = sc.scales()
+    par = np.array([1.0, 5000000.0 / (s[0] * s[1] ** 2), 0.0, -9.81 / s[1], 0.0, -15.0 / s[1]])
+    ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKET2D, 30, 1, library=emu_lib)
+    ctx.set_flow_params(par[None]); ctx.upload_traj(X[None], U[None], [t]); ctx.discretize()
+    out = ctx.download_dd()
+    ref = oracle.discretize(1, par, X, U, t)
+    for a, o in zip(out, ref):
+        assert np.abs(a[0] - o).max() <= 1e-10 * max(1.0, np.abs(o).max())
+    ctx.close()
