@@ -2,7 +2,7 @@
 # SQ issue/stall breakdown of the kernels of one small bench step (own PMC pass, no tracing)
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_sq; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d $OUT -- python $ROOT/bench.py --batch ${1:-2048} --steps 1 --warmup 0 --no-cpu-baseline --scvx-batch 0 > $OUT/log.txt 2>&1
+timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d $OUT -- python $ROOT/bench.py --batch ${1:-2048} --steps 1 --warmup 0 --no-cpu-baseline --scvx-batch 0 --mpc-batch 0 > $OUT/log.txt 2>&1
 echo rc=$?
 cd $ROOT
 python - <<'PY'
