@@ -246,3 +246,21 @@ def test_gpu_mpc_large_batch_properties(rocket2d, hip_lib):
     ic = np.linalg.norm((a.input_weights * U).reshape(B, -1), axis=1)
     assert np.abs(out["cost"][:, 0] - ic).max() < 1e-6 * ic.max() and np.abs(out["cost"][:, 1] - ec).max() < 1e-6 * ec.max()
     a.ctx.close()
+
+
+def test_emu_mpc_mirror_symmetry(rocket2d, emu_lib):
+    """Size-independent property: the planar rocket, its constraints and the MPC cost are symmetric under the mirror
+    (x, vx, eta, omega, gimbal) -> -(x, vx, eta, omega, gimbal); the optimal plan of the mirrored state is the mirrored plan."""
+    a = _alg(rocket2d, emu_lib)
+    x0 = rocket2d.randomized_initial_states(6, first=300)
+    M = np.array([-1.0, 1.0, -1.0, 1.0, -1.0, -1.0])
+    a.setInitialState(np.vstack([x0, x0 * M])); a.setFinalState(rocket2d.p.x_final)
+    assert a.solve() == 12
+    out = a.getSolution()
+    U, X = out["U"], out["X"]
+    assert np.array_equal(out["iters"][:6], out["iters"][6:]) or np.abs(out["iters"][:6] - out["iters"][6:]).max() <= 1
+    assert np.abs(U[:6, :, 0] + U[6:, :, 0]).max() <= 1e-6 * rocket2d.p.gimbal_max
+    assert np.abs(U[:6, :, 1] - U[6:, :, 1]).max() <= 1e-6 * rocket2d.p.T_max
+    assert np.abs(X[:6] * M - X[6:]).max() <= 1e-6 * np.abs(X).max()
+    assert np.abs(out["cost"][:6] - out["cost"][6:]).max() <= 1e-7 * out["cost"].max()
+    a.ctx.close()
