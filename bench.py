@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X batched Successive-Convexification engine.
 
-Metric (BASELINE.json): trajectories/sec of RocketQuat SC_oneshot, K=50, on 1/2/4/8 MI355X.
-One "step" = one pass of the hot path over one batch: SCAlgorithm::solve (cold start) of `--batch`
-randomised RocketQuat instances PER GPU, i.e. up to 15 x (multipleShooting + SOCP solve + update),
-followed (N > 1) by the RCCL all-gather of the result trajectories.  Weak scaling: per-GPU batch fixed.
+Metric (BASELINE.json): CONVERGED SCvx trajectories/sec, RocketQuat, K=50, on 1/2/4/8 MI355X.
 
-`value` counts every trajectory whose SC loop TERMINATED under the reference's own rule
-(converged OR max_iterations reached, SCAlgorithm.cpp:161); `config.converged_fraction` reports how many
-met the convergence test (SCAlgorithm.cpp:131).  With the shipped weights at K=50 that fraction is 0 for
-this scenario family -- an oracle-confirmed property of the reference algorithm, see DESIGN.md §Findings.
+One "step" = one batch of `--batch` (8192, BASELINE configs[2]) randomised RocketQuat instances PER GPU pushed through
+SCvxAlgorithm::solve (cold start; shipped SCvx.info, K=50): per instance up to 30 SCvx iterations of
+multipleShooting + SOCP solve + nonlinear cost + accept/reject (SCvxAlgorithm.cpp:61-164).  The `--steps` batches of the
+timed region form ONE job of steps x batch instances per GPU for the streaming engine (continuous batching over `--batch`
+resident slots, scpp_hip_scvx_solve_stream): a slot whose instance has terminated is refilled with the next queued instance
+on the device, so the batches overlap instead of each draining through its own long tail (instances need 10..90 solves).
+Timed: upload of the initial states -> on-device solve of every instance -> (N > 1) RCCL all-gather of the result rows ->
+download of this rank's rows to the host.  `value` = instances that MET THE CONVERGENCE TEST |dL| < change_threshold
+(SCvxAlgorithm.cpp:125) summed over ranks / wall time (max over ranks).  Weak scaling: per-GPU work fixed.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
+Secondary numbers (rank 0, outside the timed region) under `config`: the SC-mode (SCAlgorithm, what SC_oneshot runs) rate in
+trajectories TERMINATED per second -- with the shipped weights none of them meets SCAlgorithm's convergence test at K=50,
+see DESIGN.md -- an isolated single-batch SCvx solve, un-overlapped (single-pool) kernel times, and the linear-MPC leg.
+
+Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run; --backend gloo + --library
+<emulation build> drives the same N>1 code path on CPU in tests/test_bench_distributed.py)
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,11 +35,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic work per unit
 FLOP_PER_IPM_ITER = 2.0e6        # one Mehrotra iteration of one instance: 1 factorisation + 2 solves + cone algebra
-# (79.04e9 B fetched + 65.37e9 B written per launch) / (2048 instances x 23.59 IPM iterations per launch)
-IPM_TRAFFIC_BYTES_PER_ITER = 2.99e6
-FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border
+FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border (cold start: once per instance)
+IPM_ALGO_BYTES_PER_SOLVE = 131712 + 7208 + 7200  # read dd + td, write X, U: what one sub-problem solve must move
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
-DISC_FLOP_PER_INSTANCE = 5.9e7    # 49 seg x 65 RHS x ~18.6 kflop (AD Jacobian + A*V + RK combination)
+DISC_FLOP_PER_INSTANCE = 5.9e7    # 49 seg x 65 RHS x ~18.6 kflop
 PEAK_FP64_TFLOPS = 78.6           # MI355X FP64 vector == FP64 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
 
@@ -43,44 +50,93 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
-def cpu_baseline(K, seed, seconds_budget=20.0):
-    """Oracle (CPU restatement, structured-IPM twin, g++ -O2) timed on the GPU box's host cores."""
+def _scvx_cpu(K, seed, solver, seconds_budget, threads):
+    """oracle.SCvx (CPU restatement) on `threads` host threads; ctypes releases the GIL inside the solve."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import oracle_lib
 
+    def one(i):
+        s = oracle_lib.SCvx(K=K)
+        s.randomize(seed, i)
+        s.set_solver(solver)
+        rc = s.solve()
+        m = s.meta()
+        return rc, m["converged"], m["iterations"], m["solves"]
+
+    t0 = time.time()
+    r0 = one(0)
+    t1 = time.time() - t0
+    n = int(max(threads, min(32 * threads, (seconds_budget / max(t1, 1e-3)) * threads * 0.7)))
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        rs = list(ex.map(one, range(n)))
+    dt = time.time() - t0
+    conv = sum(r[1] for r in rs if r[0] == 0)
+    return dict(n=n, dt=dt, converged=conv, failures=sum(r[0] != 0 for r in rs), latency=t1,
+                mean_iters=float(np.mean([r[2] for r in rs])), mean_solves=float(np.mean([r[3] for r in rs])), first=r0)
+
+
+def cpu_baseline(K, seed, seconds_budget=12.0):
+    """The oracle (CPU restatement of SCpp's algorithm, g++ -O2 -- NOT ECOS: the reference cannot be built)
+    on the GPU box's host cores, same workload as the headline: converged SCvx trajectories/s."""
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 32))
-    t0 = time.time()
-    oracle_lib.sc_batch(K, seed, 0, 1, nthreads=1, solver=1)
-    t1 = time.time() - t0  # single-thread latency of one trajectory
-    n = int(max(threads, min(64 * threads, (seconds_budget / max(t1, 1e-3)) * threads * 0.7)))
-    t0 = time.time()
-    r = oracle_lib.sc_batch(K, seed, 0, n, nthreads=threads, solver=1)
-    dt = time.time() - t0
-    return {
-        "value": n / dt,
-        "unit": "trajectories/s",
+    tw = _scvx_cpu(K, seed, 1, seconds_budget, threads)
+    out = {
+        "value": tw["converged"] / tw["dt"],
+        "unit": "converged SCvx trajectories/s",
         "cores": threads,
         "kind": "port",
-        "single_thread_latency_s": t1,
-        "sample": f"{n} RocketQuat K={K} SC_oneshot instances (seed {seed}, instances 0..{n - 1}), oracle structured-IPM twin "
-                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} threads; "
-                  f"mean SC iters {float(r['iters'].mean()):.1f}, mean IPM iters {float(r['ipm_iters'].mean()):.0f}",
+        "single_thread_latency_s": tw["latency"],
+        "sample": f"{tw['n']} RocketQuat K={K} SCvx instances (seed {seed}, instances 0..{tw['n'] - 1}), oracle structured-IPM twin "
+                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} threads; {tw['converged']} converged, "
+                  f"{tw['failures']} solver failures, mean {tw['mean_iters']:.1f} SCvx iterations / {tw['mean_solves']:.1f} solves",
     }
+    # the reference-shaped form: Epigraph-style literal problem (n=2273, p=814, m=2573) on the sparse ECOS restatement
+    try:
+        lt = _scvx_cpu(K, seed, 0, seconds_budget, threads)
+        out["literal_form"] = {
+            "value": lt["converged"] / lt["dt"], "unit": "converged SCvx trajectories/s", "cores": threads,
+            "single_thread_latency_s": lt["latency"],
+            "sample": f"{lt['n']} instances, oracle literal sparse-KKT solver (socp.hpp) on the reference-shaped problem; {lt['converged']} converged, "
+                      f"{lt['failures']} solver failures, mean {lt['mean_iters']:.1f} SCvx iterations / {lt['mean_solves']:.1f} solves",
+        }
+    except Exception as e:
+        out["literal_form"] = {"error": str(e)}
+    return out
+
+
+def measured_traffic():
+    """HBM bytes per instance-IPM-iteration of ipm_kernel from the newest committed PMC summary (tools/pmc_hbm.sh ->
+    profiles/r*_pmc_hbm_*.json); None if there is none."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_*.json"))):
+        try:
+            d = json.load(open(f))
+            if "ipm_bytes_per_instance_iteration" in d:
+                best = (f, d)
+        except Exception:
+            pass
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="instances per GPU (BASELINE config 3: 8192)")
+    ap.add_argument("--batch", type=int, default=8192, help="instances per step and per GPU = resident slots (BASELINE configs[2]: 8192)")
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--seed", type=int, default=20260927)
+    ap.add_argument("--pools", type=int, default=0, help="slot pools (HIP streams) of the streaming engine; 0 = library default")
+    ap.add_argument("--max-iterations", type=int, default=None, help="override SCvx.info max_iterations (tests)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of this script)")
+    ap.add_argument("--library", default=None, help="path of the C-ABI library (tests pass the CPU emulation build)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered result rows to this .npy (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mpc-batch", type=int, default=32768,
-                    help="size of the extra linear-MPC run (Rocket2D) reported under config.mpc_mode (0 = skip)")
-    ap.add_argument("--scvx-batch", type=int, default=8192,
-                    help="size of the extra SCvx-mode run reported under config.scvx_mode (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (SC mode, single batch, single pool, MPC)")
+    ap.add_argument("--mpc-batch", type=int, default=32768)
     args = ap.parse_args()
 
     import torch
@@ -89,180 +145,208 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = args.backend != "gloo"
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    else:
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    elif on_gpu:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev_index = (local_rank if world > 1 else 0) if on_gpu else 0
+    dev = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
 
     B, K = args.batch, args.K
     model = scpp_amd.RocketQuat().loadParameters()
-    alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, device=dev.index).initialize()
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, device=dev_index, library=args.library,
+                                 max_iterations=args.max_iterations).initialize()
     ctx = alg.ctx
-    pX, pU, pS = ctx.device_ptrs()
-    dX = torch.as_tensor(_DevArray(pX, (B, K, 14)), device=dev)
-    dU = torch.as_tensor(_DevArray(pU, (B, K, 4)), device=dev)
-    dS = torch.as_tensor(_DevArray(pS, (B,)), device=dev)
-    if world > 1:
-        gX = torch.empty((world * B, K, 14), dtype=torch.float64, device=dev)
-        gU = torch.empty((world * B, K, 4), dtype=torch.float64, device=dev)
-        gS = torch.empty((world * B,), dtype=torch.float64, device=dev)
+    rowd = K * 18 + len(ctx.STREAM_SCALARS)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    staging = {}
-
-    def gather(dst, src):
-        """all-gather straight out of the library's result buffers; if the collective refuses memory that torch's
-        allocator does not own, go through a torch-owned staging tensor (one device-to-device copy)."""
-        if staging.get("on"):
-            st = staging.setdefault(id(src), torch.empty_like(src))
-            st.copy_(src)
-            dist.all_gather_into_tensor(dst, st)
-            return
-        try:
-            dist.all_gather_into_tensor(dst, src)
-        except Exception:
-            staging["on"] = True
-            gather(dst, src)
-
-    def step(i):
+    def states(first_step, nsteps):
         # instance ids are disjoint across ranks and steps (fresh problems every step)
-        first = (i * world + rank) * B
-        x0 = model.randomized_initial_states(B, seed=args.seed, first=first)
-        return x0
+        return np.concatenate([model.randomized_initial_states(B, seed=args.seed, first=((first_step + i) * world + rank) * B)
+                               for i in range(nsteps)], axis=0)
 
-    stats = dict(conv=0, total=0, sc_iters=0, ipm_iters=0, fails=0, nu=[])
-    x0s = [step(i) for i in range(args.warmup + args.steps)]  # host-side generation outside the timed region
-    for i in range(args.warmup):
-        alg.solve(x0s[i])
+    def run_job(x0):
+        """one streaming job + the collective + the download; returns (#converged on this rank, local rows, gathered rows)"""
+        nconv = alg.solveStream(x0, slots=B, pools=args.pools)
+        n = x0.shape[0]
+        gathered = None
         if world > 1:
-            gather(gX, dX)
+            ptr, rd, nrows = ctx.stream_rows_device()
+            assert rd == rowd and nrows == n
+            if on_gpu:
+                # the library's result rows live in hipMalloc'ed memory torch's allocator does not own: stage them through a
+                # torch tensor (one device-to-device copy of 7.3 KB per instance, noise next to the solve)
+                src = torch.as_tensor(_DevArray(ptr, (n, rowd)), device=dev)
+                mine = torch.empty((n, rowd), dtype=torch.float64, device=dev)
+                mine.copy_(src)
+            else:
+                mine = torch.from_numpy(ctx.stream_download_rows())
+            gathered = torch.empty((world * n, rowd), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(gathered, mine)
+        out = ctx.stream_download()  # D2H of this rank's rows: getSolution is part of the path's contract
+        return nconv, out, gathered
+
+    x_warm = states(0, args.warmup) if args.warmup > 0 else None
+    x_timed = states(args.warmup, args.steps)  # host-side generation outside the timed region
+    if x_warm is not None:
+        run_job(x_warm)
     ctx.timing(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        nconv = alg.solve(x0s[i])  # sc_setup (0.9 MB H2D of initial states) + on-device SC loop
-        if world > 1:
-            gather(gX, dX)
-            gather(gU, dU)
-            gather(gS, dS)
-        out = ctx.download()  # D2H of the result trajectories (part of the hot path's contract: getSolution)
-        stats["conv"] += int(nconv)
-        stats["total"] += B
-        stats["sc_iters"] += int(out["sc_iters"].sum())
-        stats["ipm_iters"] += int(out["ipm_iters"].sum())
-        stats["fails"] += int((out["status"] != 0).sum())
-        stats["nu"].append(float(np.median(out["nu_norm"])))
+    nconv, out, gathered = run_job(x_timed)
     barrier()
     dt = time.perf_counter() - t0
-    tm = ctx.timing(reset=False)
+    tm = ctx.timing(reset=True)
+    rounds = ctx.stream_rounds() if hasattr(ctx, "stream_rounds") else None
 
-    # ---- the same engine in SCvx mode (SCvxAlgorithm: fixed final time, hard trust region) on rank 0: the metric's name
-    # says "SCvx"; with the shipped weights this is the variant whose convergence test is actually met ----
-    scvx_report = None
-    if rank == 0 and args.scvx_batch > 0:
-        try:
-            Bv = min(args.scvx_batch, B)
-            xv = model.randomized_initial_states(Bv, seed=args.seed, first=10_000_000)
-            valg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=Bv, device=dev.index).initialize()
-            valg.solve(xv[: min(Bv, 256)])  # warm-up
-            torch.cuda.synchronize()
-            tv0 = time.perf_counter()
-            nconv_v = valg.solve(xv)
-            vout = valg.getSolution()
-            tv = time.perf_counter() - tv0
-            scvx_report = {
-                "algorithm": "SCvxAlgorithm (scpp_core/src/SCvxAlgorithm.cpp), shipped SCvx.info weights, K=%d" % K,
-                "batch": int(Bv),
-                "trajectories_per_s": Bv / tv,
-                "converged_trajectories_per_s": nconv_v / tv,
-                "converged_fraction": nconv_v / Bv,
-                "solver_failures": int((vout["status"] != 0).sum()),
-                "mean_scvx_iterations": float(vout["sc_iters"].mean()),
-                "mean_subproblem_solves": float(vout["solves"].mean()),
-                "median_final_nonlinear_defect": float(np.median(vout["nonlinear_cost"])),
-            }
-            valg.ctx.close()
-        except Exception as e:  # the headline number must not depend on the extra run
-            scvx_report = {"error": str(e)}
-
-    # ---- linear MPC path (Rocket2D, MPCAlgorithm / MPC_sim; SURVEY 8(f) row 4) on rank 0: one wavefront per controller ----
-    mpc_report = None
-    if rank == 0 and args.mpc_batch > 0:
-        try:
-            m2 = scpp_amd.Rocket2D().loadParameters()
-            m2.p.constrain_initial_final = False  # model.info: "enable for SC and disable for MPC/LQR"
-            Bm = args.mpc_batch
-            malg = scpp_amd.MPCAlgorithm(m2, batch_max=Bm, device=dev.index).initialize()
-            xm = m2.randomized_initial_states(Bm, seed=args.seed)
-            malg.setInitialState(xm); malg.setFinalState(m2.p.x_final)
-            malg.solve()  # warm-up
-            malg.ctx.timing(reset=True)
-            torch.cuda.synchronize()
-            tm0 = time.perf_counter()
-            reps = 10
-            for _ in range(reps):
-                nok = malg.solve()
-            tmw = (time.perf_counter() - tm0) / reps
-            mt = malg.ctx.timing(reset=True)
-            mout = malg.getSolution()
-            Bl, steps_l = min(4096, Bm), 300
-            tl0 = time.perf_counter()
-            lr = scpp_amd.MPCSim(malg, max_steps=steps_l).run(xm[:Bl])
-            tl = time.perf_counter() - tl0
-            mpc_report = {
-                "algorithm": "MPCAlgorithm (scpp_core/src/MPCAlgorithm.cpp) on the shipped Rocket2D MPC.info, K=%d, "
-                             "constant dynamics, cold start per solve" % malg.K,
-                "batch": int(Bm),
-                "solves_per_s": Bm / tmw,
-                "solves_per_s_kernel_only": Bm / (mt["ms_socp"] / mt["n_socp"]) * 1e3,
-                "avg_launch_ms": mt["ms_socp"] / mt["n_socp"],
-                "solved_fraction": nok / Bm,
-                "mean_ipm_iterations": float(mout["iters"].mean()),
-                "closed_loop": {"loops": int(Bl), "steps": steps_l, "controller_steps_per_s": float(lr["steps"].sum()) / tl,
-                                "failed_solves": int(lr["failed_solves"].sum())},
-                "note": "host buffers in, host buffers out (x_init upload and status download inside the wall-clock rate)",
-            }
-            malg.ctx.close()
-        except Exception as e:
-            mpc_report = {"error": str(e)}
-
+    total = x_timed.shape[0]
+    local = np.array([nconv, total, int(out["sc_iters"].sum()), int(out["solves"].sum()), int(out["ipm_iters"].sum()),
+                      int((out["status"] != 0).sum())], dtype=np.float64)
+    assert (out["instance"] == np.arange(total)).all(), "result rows out of order"
+    assert int(out["converged"].sum()) == nconv
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([stats["conv"], stats["total"], stats["sc_iters"], stats["ipm_iters"], stats["fails"]], dtype=torch.float64, device=dev)
+        agg = torch.tensor(local, dtype=torch.float64, device=dev)
         dist.all_reduce(agg)
-        conv, total, sc_it, ipm_it, fails = [float(v) for v in agg.tolist()]
+        g_conv, g_total, g_iters, g_solves, g_ipm, g_fail = [float(v) for v in agg.tolist()]
+        # the gathered rows carry the same story as the reduced counters (every rank holds every trajectory)
+        conv_col = K * 18 + ctx.STREAM_SCALARS.index("converged")
+        assert int(round(float(gathered[:, conv_col].sum().item()))) == int(g_conv), "all-gather payload disagrees with the counters"
+        if rank == 0 and args.dump:
+            np.save(args.dump, gathered.cpu().numpy())
     else:
-        conv, total, sc_it, ipm_it, fails = stats["conv"], stats["total"], stats["sc_iters"], stats["ipm_iters"], stats["fails"]
+        g_conv, g_total, g_iters, g_solves, g_ipm, g_fail = [float(v) for v in local]
+        if args.dump:
+            np.save(args.dump, ctx.stream_download_rows())
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # ---- un-overlapped kernel times: the same engine with ONE slot pool (one stream), a 2-batch job ----
+        try:
+            ctx.timing(reset=True)
+            xs = model.randomized_initial_states(2 * B, seed=args.seed, first=20_000_000)
+            ts0 = time.perf_counter()
+            nc1 = alg.solveStream(xs, slots=B, pools=1)
+            o1 = ctx.stream_download()
+            ts = time.perf_counter() - ts0
+            t1 = ctx.timing(reset=True)
+            ipm_s = t1["ms_socp"] * 1e-3
+            fl = float(o1["ipm_iters"].sum()) * FLOP_PER_IPM_ITER + 2 * B * FLOP_PER_SOCP_INIT
+            extras["single_pool"] = {
+                "note": "one stream: hipEvent spans of consecutive kernels do not overlap",
+                "converged_trajectories_per_s": nc1 / ts,
+                "ipm_kernel_avg_launch_ms": t1["ms_socp"] / max(t1["n_socp"], 1),
+                "ipm_kernel_launches": t1["n_socp"],
+                "ipm_kernel_fp64_TFLOPs": fl / ipm_s / 1e12 if ipm_s > 0 else None,
+                "ipm_kernel_fp64_frac": fl / ipm_s / 1e12 / PEAK_FP64_TFLOPS if ipm_s > 0 else None,
+                "ipm_share_of_wall": ipm_s / ts,
+                "discretize_kernel_avg_launch_ms": t1["ms_discretize"] / max(t1["n_discretize"], 1),
+                "discretize_share_of_wall": t1["ms_discretize"] * 1e-3 / ts,
+            }
+        except Exception as e:
+            extras["single_pool"] = {"error": str(e)}
+        # ---- one isolated batch through the plain batch entry point (latency view: includes its own tail) ----
+        try:
+            xv = model.randomized_initial_states(B, seed=args.seed, first=10_000_000)
+            tv0 = time.perf_counter()
+            nconv_v = alg.solve(xv)
+            vout = alg.getSolution()
+            tv = time.perf_counter() - tv0
+            extras["single_batch"] = {
+                "entry": "scpp_hip_scvx_solve: one batch, no refill", "batch": int(B),
+                "converged_trajectories_per_s": nconv_v / tv, "converged_fraction": nconv_v / B,
+                "max_subproblem_solves": int(vout["solves"].max()), "mean_subproblem_solves": float(vout["solves"].mean()),
+            }
+        except Exception as e:
+            extras["single_batch"] = {"error": str(e)}
+        ctx.close()
+        # ---- SC mode (SCAlgorithm: what SC_oneshot runs): terminated trajectories/s ----
+        try:
+            salg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, device=dev_index, library=args.library).initialize()
+            xs = model.randomized_initial_states(2 * B, seed=args.seed, first=30_000_000)
+            salg.solve(xs[:B])
+            salg.ctx.synchronize()
+            salg.ctx.timing(reset=True)
+            ts0 = time.perf_counter()
+            nconv_s = salg.solve(xs[B:])
+            sout = salg.getSolution()
+            ts = time.perf_counter() - ts0
+            st = salg.ctx.timing(reset=True)
+            extras["sc_mode"] = {
+                "algorithm": "SCAlgorithm (SCAlgorithm.cpp:66-189), shipped SC.info weights, K=%d, cold start" % K,
+                "batch": int(B), "terminated_trajectories_per_s": B / ts, "converged_trajectories_per_s": nconv_s / ts,
+                "converged_fraction": nconv_s / B, "mean_sc_iterations": float(sout["sc_iters"].mean()),
+                "mean_ipm_iterations_per_trajectory": float(sout["ipm_iters"].mean()),
+                "solver_failures": int((sout["status"] != 0).sum()),
+                "median_final_virtual_control_norm1": float(np.median(sout["nu_norm"])),
+                "ipm_kernel_avg_launch_ms_two_stream_overlapped": st["ms_socp"] / max(st["n_socp"], 1),
+            }
+            salg.ctx.close()
+        except Exception as e:
+            extras["sc_mode"] = {"error": str(e)}
+        # ---- linear MPC path (Rocket2D, MPCAlgorithm / MPC_sim) ----
+        if args.mpc_batch > 0:
+            try:
+                m2 = scpp_amd.Rocket2D().loadParameters()
+                m2.p.constrain_initial_final = False  # model.info: "enable for SC and disable for MPC/LQR"
+                Bm = args.mpc_batch
+                malg = scpp_amd.MPCAlgorithm(m2, batch_max=Bm, device=dev_index, library=args.library).initialize()
+                xm = m2.randomized_initial_states(Bm, seed=args.seed)
+                malg.setInitialState(xm); malg.setFinalState(m2.p.x_final)
+                malg.solve()  # warm-up
+                malg.ctx.timing(reset=True)
+                tm0 = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    nok = malg.solve()
+                tmw = (time.perf_counter() - tm0) / reps
+                mt = malg.ctx.timing(reset=True)
+                mout = malg.getSolution()
+                extras["mpc_mode"] = {
+                    "algorithm": "MPCAlgorithm on the shipped Rocket2D MPC.info, K=%d, constant dynamics, cold start per solve" % malg.K,
+                    "batch": int(Bm), "solves_per_s": Bm / tmw, "avg_launch_ms": mt["ms_socp"] / max(mt["n_socp"], 1),
+                    "solved_fraction": nok / Bm, "mean_ipm_iterations": float(mout["iters"].mean()),
+                }
+                malg.ctx.close()
+            except Exception as e:
+                extras["mpc_mode"] = {"error": str(e)}
 
     if rank == 0:
-        value = total / dt
-        # roofline of the dominant kernel (ipm_kernel), rank 0's launches, hipEvent-timed on the kernel's stream
-        # the ECOS-style initialisation (one factorisation + two solves) runs once per trajectory: later SC iterations
-        # warm-start the interior-point iteration from the previous sub-problem's point
-        socp_flops = stats["ipm_iters"] * FLOP_PER_IPM_ITER + stats["total"] * FLOP_PER_SOCP_INIT
+        value = g_conv / dt
+        # roofline of the dominant kernel (ipm_kernel), rank 0's launches of the timed region, hipEvent spans on the launching
+        # streams.  With more than one slot pool the spans of different streams overlap in time (the kernels share the CUs), so
+        # the per-launch duration is an upper bound of the kernel's own time; `single_pool` has the un-overlapped figure.
+        ipm_iters0 = float(out["ipm_iters"].sum())
+        socp_flops = ipm_iters0 * FLOP_PER_IPM_ITER + total * FLOP_PER_SOCP_INIT
         socp_s = tm["ms_socp"] * 1e-3
         achieved_tf = socp_flops / socp_s / 1e12 if socp_s > 0 else 0.0
+        launches = max(tm["n_socp"], 1)
+        pmc = measured_traffic()
+        traffic = None
+        traffic_note = "no profiles/r*_pmc_hbm_*.json summary found: traffic unmeasured"
+        if pmc is not None:
+            f, d = pmc
+            traffic = d["ipm_bytes_per_instance_iteration"] * ipm_iters0 / launches
+            traffic_note = (f"{os.path.relpath(f, ROOT)}: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes) of ipm_kernel = "
+                            f"{d['ipm_bytes_per_instance_iteration']:.3e} B per instance-IPM-iteration (commit {d.get('commit', '?')}, "
+                            f"{d.get('calibration', 'uncalibrated')}), scaled by this run's iterations per launch; algorithmic minimum "
+                            f"(read dd + td, write X, U) = {IPM_ALGO_BYTES_PER_SOLVE} B per instance-solve")
         disc_s = tm["ms_discretize"] * 1e-3
-        disc = {
-            "kernel": "discretize_kernel<RocketQuat,FOH,VT>",
-            "avg_launch_ms": tm["ms_discretize"] / max(tm["n_discretize"], 1),
-            "hbm_GBs": tm["inst_discretize"] * DISC_BYTES_PER_INSTANCE / disc_s / 1e9 if disc_s > 0 else 0.0,
-            "hbm_frac": (tm["inst_discretize"] * DISC_BYTES_PER_INSTANCE / disc_s / 1e9) / PEAK_HBM_GBS if disc_s > 0 else 0.0,
-            "fp64_TFLOPs": tm["inst_discretize"] * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 if disc_s > 0 else 0.0,
-            "fp64_frac": (tm["inst_discretize"] * DISC_FLOP_PER_INSTANCE / disc_s / 1e12) / PEAK_FP64_TFLOPS if disc_s > 0 else 0.0,
-            "bound": "fp64-alu (450 flop/B: HBM is not the binding roof, SURVEY §8(d))",
-        }
+        # discretize launches are masked (needs_disc): instances that re-solve after a rejection skip it, so count solves
         line = {
             "metric": "converged SCvx trajectories/sec (RocketQuat, K=50) at 1/2/4/8 MI355X",
             "value": value,
@@ -277,38 +361,57 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"RocketQuat SC_oneshot (SCAlgorithm mode, free final time, FOH), K={K}, batch={B} randomised initial "
-                            f"states per GPU (BASELINE configs[2]/[4]: 8192 per GPU, 65536 on 8), shipped Falcon-9 model.info + SC.info weights",
-                "algorithm": "SCAlgorithm (what SC_oneshot runs, SURVEY F3); termination = reference rule (converged or max_iterations=15)",
+                "workload": f"RocketQuat SCvx (SCvxAlgorithm: fixed final time, hard input trust region, FOH), K={K}, {args.steps} steps x "
+                            f"batch={B} randomised initial states per GPU (BASELINE configs[2]/[4]: 8192 per GPU, 65536 on 8), shipped "
+                            f"Falcon-9 model.info + SCvx.info",
+                "algorithm": "SCvxAlgorithm::solve, cold start per instance; converged = |dL| < change_threshold (SCvxAlgorithm.cpp:125)",
+                "engine": f"scpp_hip_scvx_solve_stream: continuous batching over {B} resident slots per GPU, steps x batch instances queued",
                 "global_batch": int(B * world),
-                "parallelism": f"batch-sharded x{world}, RCCL all-gather of result trajectories" if world > 1 else "single GPU",
-                "converged_fraction": conv / total if total else 0.0,
-                "mean_sc_iterations": sc_it / total if total else 0.0,
-                "mean_ipm_iterations_per_trajectory": ipm_it / total if total else 0.0,
-                "solver_failures": fails,
-                "median_final_virtual_control_norm1": float(np.median(stats["nu"])) if stats["nu"] else None,
-                "mfma": True,
-                "scvx_mode": scvx_report,
-                "mpc_mode": mpc_report,
+                "instances_timed": int(g_total),
+                "parallelism": (f"instance-sharded x{world}, no collective in the loop, one {args.backend} all-gather of the result rows "
+                                f"({rowd * 8} B per instance)") if world > 1 else "single GPU",
+                "converged_fraction": g_conv / g_total if g_total else 0.0,
+                "terminated_trajectories_per_s": g_total / dt,
+                "mean_scvx_iterations": g_iters / g_total if g_total else 0.0,
+                "mean_subproblem_solves": g_solves / g_total if g_total else 0.0,
+                "mean_ipm_iterations_per_trajectory": g_ipm / g_total if g_total else 0.0,
+                "solver_failures": g_fail,
+                "median_final_virtual_control_norm1": float(np.median(out["nu_norm"])),
+                "median_final_nonlinear_defect": float(np.median(out["nonlinear_cost"])),
+                "rounds": rounds,
+                **extras,
             },
             "roofline": {
-                "kernel": "ipm_kernel (batched structured IPM, one wavefront per instance)",
+                "kernel": "ipm_kernel (batched structured IPM, one wavefront per instance, block factorisations on v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_TFLOPS,
-                # HBM bytes per launch: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes,
-                # profiles/r01_pmc_hbm_v4_batch2048.txt) per instance-IPM-iteration x this run's iterations per launch
-                "traffic": IPM_TRAFFIC_BYTES_PER_ITER * stats["ipm_iters"] / max(tm["n_socp"], 1),
-                "traffic_GBs": IPM_TRAFFIC_BYTES_PER_ITER * stats["ipm_iters"] / socp_s / 1e9 if socp_s > 0 else 0.0,
-                "traffic_note": "PMC-measured 2.99 MB per instance-IPM-iteration (r01 v4 profile, batch 2048), scaled by the "
-                                "iterations of this run; algorithmic minimum (read dd + write X,U) is 0.15 MB per launch-instance",
-                "avg_launch_ms": tm["ms_socp"] / max(tm["n_socp"], 1),
+                "traffic": traffic,
+                "traffic_note": traffic_note,
+                "avg_launch_ms": tm["ms_socp"] / launches,
                 "launches": tm["n_socp"],
-                "flop_model": f"{FLOP_PER_IPM_ITER:.2e} flop per IPM iteration x measured IPM iterations + {FLOP_PER_SOCP_INIT:.2e} per cold start (1 per trajectory)",
+                "flop_model": f"{FLOP_PER_IPM_ITER:.2e} flop per IPM iteration x {ipm_iters0:.0f} measured IPM iterations + "
+                              f"{FLOP_PER_SOCP_INIT:.2e} per cold start x {total} instances (rank 0)",
+                "hbm_view": {
+                    "algorithmic_bytes_per_launch": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / launches,
+                    "algorithmic_GBs": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / socp_s / 1e9 if socp_s > 0 else None,
+                    "measured_GBs": (traffic * launches / socp_s / 1e9) if (traffic is not None and socp_s > 0) else None,
+                    "peak_GBs": PEAK_HBM_GBS,
+                },
             },
-            "kernels": {"discretize": disc},
+            "kernels": {
+                "discretize": {
+                    "kernel": "discretize_kernel<RocketQuat,FOH,fixed time>",
+                    "avg_launch_ms": tm["ms_discretize"] / max(tm["n_discretize"], 1),
+                    "launches": tm["n_discretize"],
+                    "instance_calls": g_iters / world,
+                    "fp64_TFLOPs_of_span_time": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 if disc_s > 0 else None,
+                    "hbm_GBs_of_span_time": (g_iters / world) * DISC_BYTES_PER_INSTANCE / disc_s / 1e9 if disc_s > 0 else None,
+                    "bound": "fp64-alu (450 flop/B: HBM is not the binding roof, SURVEY §8(d))",
+                },
+            },
         }
         if not args.no_cpu_baseline:
             try:

@@ -157,6 +157,22 @@ extern "C"
     int scpp_hip_scvx_solve(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_scvx_download_state(scpp_hip_ctx *ctx, double *trust_region, double *nonlinear_cost, int32_t *solves,
                                      double *last_decision /* [B][4] */);
+    /* ---- SCvx streaming engine (continuous batching): SCvxAlgorithm::solve (cold start, SCvxAlgorithm.cpp:166-227) of N
+       independent instances pushed through `slots` (<= batch_max; 0: batch_max) resident problem slots.  Instances need very
+       different numbers of sub-problem solves (accepted + rejected candidates, SCvxAlgorithm.cpp:132-138); a slot whose
+       loop has terminated is refilled from the queue at the next round, so the device stays full until the queue is empty.
+       `pools` (0: default 2) slot ranges run on their own HIP streams.  Every instance computes exactly what
+       scpp_hip_scvx_setup + scpp_hip_scvx_solve compute for it (bitwise), whatever slot it lands in.
+       Results: one row of K*18 + 10 float64 per instance, in instance order: X [K][14], U [K][4] (dimensional), then
+       sigma, ||nu||_1, last nonlinear cost, trust radius, SCvx iterations, sub-problem solves, converged, status,
+       interior-point iterations, instance id.  scpp_hip_stream_rows exposes the DEVICE buffer (for the RCCL all-gather of
+       the converged trajectories), scpp_hip_stream_download copies rows [first, first+count) to the host. ---- */
+    int scpp_hip_scvx_solve_stream(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_scvx_opts *opts,
+                                   const double *x_init /* [N][14] dimensional */, int N, int slots, int pools,
+                                   int *n_converged);
+    int scpp_hip_stream_rows(scpp_hip_ctx *ctx, void **rows, int *row_doubles, int *n);
+    int scpp_hip_stream_download(scpp_hip_ctx *ctx, double *rows /* [count][K*18+10] */, int first, int count);
+    int scpp_hip_stream_info(scpp_hip_ctx *ctx, long long *rounds_enqueued, int *pools_used); /* diagnostics of the last job */
     /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                           int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);

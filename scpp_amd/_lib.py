@@ -108,6 +108,7 @@ SYMBOLS = [
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
     "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
     "scpp_hip_mpc_sim_download",
+    "scpp_hip_scvx_solve_stream", "scpp_hip_stream_rows", "scpp_hip_stream_download", "scpp_hip_stream_info",
 ]
 
 
@@ -237,6 +238,51 @@ class Context:
         tr, cost, solves, dec = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
         _chk(self.lib.scpp_hip_scvx_download_state(self.h, _p(tr), _p(cost), _p(solves), _p(dec)), "scvx_download_state")
         return dict(trust_region=tr, nonlinear_cost=cost, solves=solves, last_decision=dec)
+
+    # ---- SCvx streaming engine (continuous batching) ----
+    STREAM_SCALARS = ("sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",
+                      "ipm_iters", "instance")
+
+    def scvx_solve_stream(self, model_params, scvx_opts, x_init, slots=0, pools=0):
+        """SCvxAlgorithm::solve of every row of x_init [N][14] through `slots` resident slots. Returns #converged."""
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        n = C.c_int(0)
+        self._stream_N = x_init.shape[0]
+        _chk(self.lib.scpp_hip_scvx_solve_stream(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(x_init.shape[0]),
+                                                 int(slots), int(pools), C.byref(n)), "scvx_solve_stream")
+        return n.value
+
+    def stream_rows_device(self):
+        """(device pointer, doubles per row, rows) of the result rows of the last streaming job."""
+        ptr, rd, n = C.c_void_p(), C.c_int(0), C.c_int(0)
+        _chk(self.lib.scpp_hip_stream_rows(self.h, C.byref(ptr), C.byref(rd), C.byref(n)), "stream_rows")
+        return ptr.value, rd.value, n.value
+
+    def stream_download_rows(self, first=0, count=None):
+        """raw result rows [count][K*18 + 10] of the last streaming job (the all-gather payload)"""
+        count = self._stream_N - first if count is None else count
+        rowd = self.K * 18 + len(self.STREAM_SCALARS)
+        rows = np.zeros((count, rowd))
+        _chk(self.lib.scpp_hip_stream_download(self.h, _p(rows), int(first), int(count)), "stream_download")
+        return rows
+
+    def stream_download(self, first=0, count=None):
+        return self.unpack_stream_rows(self.stream_download_rows(first, count), self.K)
+
+    def stream_rounds(self):
+        """rounds the host enqueued for the last streaming job and the number of slot pools it used"""
+        r, p = C.c_longlong(0), C.c_int(0)
+        _chk(self.lib.scpp_hip_stream_info(self.h, C.byref(r), C.byref(p)), "stream_info")
+        return {"rounds": r.value, "pools": p.value}
+
+    @classmethod
+    def unpack_stream_rows(cls, rows, K):
+        n = rows.shape[0]
+        out = dict(X=rows[:, :K * 14].reshape(n, K, 14), U=rows[:, K * 14:K * 18].reshape(n, K, 4))
+        for j, name in enumerate(cls.STREAM_SCALARS):
+            col = rows[:, K * 18 + j]
+            out[name] = col if name in ("sigma", "nu_norm", "nonlinear_cost", "trust_region") else col.astype(np.int32)
+        return out
 
     # ---- MPC boundary (Rocket2D) ----
     def mpc_setup(self, opts, flow_par):

@@ -38,6 +38,8 @@ struct KernelArgs
     int max_sc_iterations;
     int *warm;                   // [B] (may be null) 1: the workspace holds the primal-dual point of a successful previous solve
     int do_sc_update;            // 1: apply readSolution + convergence logic ; 0: plain sub-problem solve
+    double *Xold, *Uold;         // (may be null) SCvx: snapshot of the linearisation point taken before the solution
+                                 // overwrites X / U (old_td = td, SCvxAlgorithm.cpp:77), [B][K][14] / [B][K][4]
     Settings opt;
     double *dbg;                 // optional [B][8]: pcost, gap, pres, dres, iters, status
 };
@@ -1674,6 +1676,14 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     it.bk_valid = 0;
     it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
 
+    if (a.Xold && k < K)
+    {
+        const size_t o = size_t(inst) * K + k;
+        for (int j = 0; j < NX; j++)
+            a.Xold[o * NX + j] = a.X[o * NX + j];
+        for (int j = 0; j < NU; j++)
+            a.Uold[o * NU + j] = a.U[o * NU + j];
+    }
     PROF_T(tp0);
     int warm = (a.warm && a.warm[inst] != 0) ? 1 : 0;
     int status = -1, iter = 0, iter_total = 0;

@@ -25,15 +25,14 @@ struct SCBuffers
     double *norm1_nu, *sum_delta, *delta_sigma;
 };
 
-// cold (warm=0) or warm (warm=1) start of SCAlgorithm::solve for every instance
-__global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_opts so, int warm)
+// cold (warm=0) or warm (warm=1) start of SCAlgorithm::solve of ONE instance (slot i), written so that it can run on one
+// thread (k0 = 0, kstep = 1: sc_setup_kernel) or spread over the lanes of a wavefront (k0 = lane, kstep = 64: the
+// streaming engine refills a finished slot with the next queued instance).  xi: the instance's dimensional initial state.
+__device__ inline void scSetupOne(const SCBuffers &b, const scpp_rocketquat_params &mp, const scpp_sc_opts &so, int warm,
+                                  long i, const double *xi, int k0, int kstep)
 {
     using namespace ipm;
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= b.B)
-        return;
     const int K = b.K;
-    const double *xi = b.x_init_dim + i * 14;
     double *ip = b.ip + i * IP_N;
     double m_scale = 1., r_scale = 1.;
     if (so.nondimensionalize)
@@ -54,44 +53,47 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
         x0[j] /= r_scale;
         xf[j] /= r_scale;
     }
-    for (int j = 0; j < 14; j++)
-    {
-        ip[IP_XINIT + j] = x0[j];
-        ip[IP_XFINAL + j] = xf[j];
-    }
     const double T_min = mp.T_min / (m_scale * r_scale), T_max = mp.T_max / (m_scale * r_scale);
-    ip[IP_GS] = tan(mp.gamma_gs);
-    ip[IP_TILT] = sqrt((1. - cos(mp.theta_max)) / 2.);
-    ip[IP_WMAX] = mp.w_B_max;
-    ip[IP_TMIN] = T_min;
-    ip[IP_TMAX] = T_max;
-    ip[IP_GIM] = tan(mp.gimbal_max);
-    ip[IP_MDRY] = xf[0];
-    ip[IP_WT] = so.weight_time;
-    ip[IP_WTRT] = so.weight_trust_region_time;
-    ip[IP_WTRX] = so.weight_trust_region_trajectory;
-    ip[IP_WVC] = so.weight_virtual_control;
-    ip[IP_PAR + 0] = mp.alpha_m * r_scale;
-    for (int j = 0; j < 3; j++)
+    if (k0 == 0)
     {
-        ip[IP_PAR + 1 + j] = mp.g_I[j] / r_scale;
-        ip[IP_PAR + 4 + j] = mp.J_B[j] / (m_scale * r_scale * r_scale);
-        ip[IP_PAR + 7 + j] = mp.r_T_B[j] / r_scale;
+        for (int j = 0; j < 14; j++)
+        {
+            ip[IP_XINIT + j] = x0[j];
+            ip[IP_XFINAL + j] = xf[j];
+        }
+        ip[IP_GS] = tan(mp.gamma_gs);
+        ip[IP_TILT] = sqrt((1. - cos(mp.theta_max)) / 2.);
+        ip[IP_WMAX] = mp.w_B_max;
+        ip[IP_TMIN] = T_min;
+        ip[IP_TMAX] = T_max;
+        ip[IP_GIM] = tan(mp.gimbal_max);
+        ip[IP_MDRY] = xf[0];
+        ip[IP_WT] = so.weight_time;
+        ip[IP_WTRT] = so.weight_trust_region_time;
+        ip[IP_WTRX] = so.weight_trust_region_trajectory;
+        ip[IP_WVC] = so.weight_virtual_control;
+        ip[IP_PAR + 0] = mp.alpha_m * r_scale;
+        for (int j = 0; j < 3; j++)
+        {
+            ip[IP_PAR + 1 + j] = mp.g_I[j] / r_scale;
+            ip[IP_PAR + 4 + j] = mp.J_B[j] / (m_scale * r_scale * r_scale);
+            ip[IP_PAR + 7 + j] = mp.r_T_B[j] / r_scale;
+        }
+        ip[IP_MSCALE] = m_scale;
+        ip[IP_RSCALE] = r_scale;
+        ip[IP_FINALTIME] = mp.final_time;
+        ip[IP_SCVX] = 0.;
+        ip[IP_TR] = 0.;
     }
-    ip[IP_MSCALE] = m_scale;
-    ip[IP_RSCALE] = r_scale;
-    ip[IP_FINALTIME] = mp.final_time;
-    ip[IP_SCVX] = 0.;
-    ip[IP_TR] = 0.;
 
     double *X = b.X + i * K * 14, *U = b.U + i * K * 4;
-    if (!warm)
+    for (int k = k0; k < K; k += kstep)
     {
-        // getInitializedTrajectory (k/K interpolation quirk kept)
-        for (int k = 0; k < K; k++)
+        double *x = X + k * 14, *u = U + k * 4;
+        if (!warm)
         {
+            // getInitializedTrajectory (k/K interpolation quirk kept)
             const double a1 = double(K - k) / K, a2 = double(k) / K;
-            double *x = X + k * 14;
             for (int j = 0; j < 7; j++)
                 x[j] = a1 * x0[j] + a2 * xf[j];
             const double *q0 = x0 + 7, *q1 = xf + 7;
@@ -116,21 +118,15 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
                 x[7 + j] = s0 * q0[j] + s1 * q1[j];
             for (int j = 11; j < 14; j++)
                 x[j] = a1 * x0[j] + a2 * xf[j];
-            double *u = U + k * 4;
             u[0] = 0.;
             u[1] = 0.;
             u[2] = (T_max - T_min) / 2.;
             u[3] = 0.;
         }
-        b.sigma[i] = mp.final_time;
-        b.wtrx[i] = so.weight_trust_region_trajectory; // loadParameters() on cold start
-    }
-    else
-    {
-        // warm start: stored trajectory is dimensional -> nondimensionalizeTrajectory
-        for (int k = 0; k < K; k++)
+        else
         {
-            double *x = X + k * 14, *u = U + k * 4;
+            // warm start: stored trajectory is dimensional -> nondimensionalizeTrajectory
+            // (weight_trust_region_trajectory keeps its doubled value: loadParameters() is skipped)
             x[0] /= m_scale;
             for (int j = 1; j < 7; j++)
                 x[j] /= r_scale;
@@ -138,15 +134,10 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
                 u[j] /= m_scale * r_scale;
             u[3] /= m_scale * r_scale * r_scale;
         }
-        // weight_trust_region_trajectory keeps its (doubled) value: loadParameters() is skipped
-    }
-    // updateProblemParameters: thrust_const from the trajectory bound at solve() start
-    for (int k = 0; k < K; k++)
-    {
+        // updateProblemParameters: thrust_const from the trajectory bound at solve() start
         double *uh = b.uhat + (i * K + k) * 3;
         if (mp.exact_minimum_thrust)
         {
-            const double *u = U + k * 4;
             const double z = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
             const double s = z > 0. ? 1. / sqrt(z) : 1.;
             for (int j = 0; j < 3; j++)
@@ -159,14 +150,37 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
             uh[2] = 1.;
         }
     }
-    b.active[i] = 1;
-    b.converged[i] = 0;
-    b.sc_iters[i] = 0;
-    b.ipm_iters[i] = 0;
-    b.status[i] = 0;
-    b.norm1_nu[i] = 0.;
-    b.sum_delta[i] = 0.;
-    b.delta_sigma[i] = 0.;
+    if (k0 == 0)
+    {
+        if (!warm)
+        {
+            b.sigma[i] = mp.final_time;
+            b.wtrx[i] = so.weight_trust_region_trajectory; // loadParameters() on cold start
+        }
+        b.active[i] = 1;
+        b.converged[i] = 0;
+        b.sc_iters[i] = 0;
+        b.ipm_iters[i] = 0;
+        b.status[i] = 0;
+        b.norm1_nu[i] = 0.;
+        b.sum_delta[i] = 0.;
+        b.delta_sigma[i] = 0.;
+    }
+}
+
+__global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_opts so, int warm)
+{
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    scSetupOne(b, mp, so, warm, i, b.x_init_dim + i * 14, 0, 1);
+}
+
+// factor that redimensionalises entry j of a state (input) vector
+__device__ inline double redimX(int j, double m_scale, double r_scale) { return j == 0 ? m_scale : (j < 7 ? r_scale : 1.); }
+__device__ inline double redimU(int j, double m_scale, double r_scale)
+{
+    return j < 3 ? m_scale * r_scale : m_scale * r_scale * r_scale;
 }
 
 // redimensionalizeTrajectory, in place

@@ -48,6 +48,15 @@ struct scpp_hip_ctx
     int *vx_has_last = nullptr, *vx_needs_disc = nullptr, *vx_solves = nullptr;
     scpp_scvx_opts scvx{};
     bool scvx_ready = false;
+    // streaming engine (allocated on first scvx_solve_stream): instance queue, result rows, slot -> instance map
+    double *q_xinit = nullptr, *q_rows = nullptr;
+    int *q_counters = nullptr; // [4] head, done, nconv
+    int *q_slot_inst = nullptr;
+    size_t q_cap = 0;          // capacity (instances) of q_xinit / q_rows
+    int q_N = 0;               // instances of the last job
+    std::vector<hipStream_t> pool_streams; // streams of the slot pools beyond the first (which runs on `stream`)
+    std::vector<hipEvent_t> pool_events;
+    int *h_poll = nullptr;     // pinned host words the lagged termination polls land in
     // linear MPC state (allocated on first mpc_setup)
     mpc::MpcConst *mpc_const = nullptr;
     mpc::MpcConst *mpc_host = nullptr;
@@ -73,10 +82,32 @@ struct scpp_hip_ctx
     std::vector<hipEvent_t> pool;
     scpp_timing timing{};
     int last_active = 0;
+    long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
+    int stream_pools = 0;
 };
 
 namespace
 {
+
+// Every entry point runs on the context's device whatever the calling thread's current device is (a host that drives
+// several GPUs from one thread, or a framework that switches devices between calls), and restores the caller's device.
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const scpp_hip_ctx *c)
+    {
+        if (!c)
+            return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->device)
+            switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+};
 
 template <class T>
 int devAlloc(T **p, size_t n)
@@ -97,17 +128,35 @@ hipEvent_t getEvent(scpp_hip_ctx *c)
         return nullptr;
     return e;
 }
-void spanBegin(scpp_hip_ctx *c, int kind, long long inst, hipStream_t st)
+void collectTiming(scpp_hip_ctx *c);
+constexpr size_t MAX_OPEN_SPANS = 1 << 15; // callers that never poll the timing must not grow the event pool without bound
+bool spanBegin(scpp_hip_ctx *c, int kind, long long inst, hipStream_t st)
 {
+    if (c->spans.size() >= MAX_OPEN_SPANS)
+        collectTiming(c); // folds the finished spans into the running totals and recycles their events
     scpp_hip_ctx::Span s;
     s.a = getEvent(c);
     s.b = getEvent(c);
+    if (!s.a || !s.b)
+    {
+        // no event to be had: this launch goes untimed
+        if (s.a)
+            c->pool.push_back(s.a);
+        if (s.b)
+            c->pool.push_back(s.b);
+        return false;
+    }
     s.kind = kind;
     s.inst = inst;
     (void)hipEventRecord(s.a, st);
     c->spans.push_back(s);
+    return true;
 }
-void spanEnd(scpp_hip_ctx *c, hipStream_t st) { (void)hipEventRecord(c->spans.back().b, st); }
+void spanEnd(scpp_hip_ctx *c, bool open, hipStream_t st)
+{
+    if (open)
+        (void)hipEventRecord(c->spans.back().b, st);
+}
 
 // contiguous instance range processed by one launch, and the stream it is issued on
 struct Range
@@ -161,7 +210,7 @@ int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par0, int stride, 
         hipStream_t stream;
     } v{c->X + f * K * nx, c->U + f * K * nu, c->sigma + f, c->A + f * seg * nx * nx, c->Bm + f * seg * nx * nu,
         c->C + f * seg * nx * nu, c->S + f * seg * nx, c->Z + f * seg * nx, r.stream};
-    spanBegin(c, 0, ninst, r.stream);
+    const bool timed = spanBegin(c, 0, ninst, r.stream);
     if (mode == (SCPP_MODE_FOH | SCPP_MODE_VT))
         hipLaunchKernelGGL((discretize_kernel<Model, true, true>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
                            v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
@@ -174,7 +223,7 @@ int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par0, int stride, 
     else
         hipLaunchKernelGGL((discretize_kernel<Model, false, false>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
                            v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
-    spanEnd(c, r.stream);
+    spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 
@@ -236,7 +285,7 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
     return b;
 }
 
-int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0)
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0, bool snapshot = false)
 {
     ipm::KernelArgs a;
     const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1;
@@ -267,6 +316,8 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     a.max_sc_iterations = c->sc.max_iterations;
     a.warm = c->ipm_warm + f;
     a.do_sc_update = do_sc_update;
+    a.Xold = snapshot ? c->vx_Xold + f * K * 14 : nullptr;
+    a.Uold = snapshot ? c->vx_Uold + f * K * 4 : nullptr;
     a.opt.feastol = c->socp.feastol;
     a.opt.abstol = c->socp.abstol;
     a.opt.reltol = c->socp.reltol;
@@ -274,10 +325,10 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     a.opt.maxit = c->socp.maxit;
     a.opt.use_mfma = c->socp.use_mfma;
     a.dbg = c->dbg + f * 32;
-    spanBegin(c, 1, ninst, r.stream);
+    const bool timed = spanBegin(c, 1, ninst, r.stream);
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
     hipLaunchKernelGGL(ipm::ipm_kernel, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
-    spanEnd(c, r.stream);
+    spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = false)
@@ -313,7 +364,18 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
         return SCPP_E_ARG;
     if (model_id != SCPP_MODEL_ROCKETQUAT && model_id != SCPP_MODEL_ROCKET2D)
         return SCPP_E_ARG;
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
     CHECK_HIP(hipSetDevice(device_id));
+    struct Restore
+    {
+        int d;
+        ~Restore()
+        {
+            if (d >= 0)
+                (void)hipSetDevice(d);
+        }
+    } restore{prev_device == device_id ? -1 : prev_device};
     scpp_hip_ctx *c = new (std::nothrow) scpp_hip_ctx;
     if (!c)
         return SCPP_E_HIP;
@@ -386,6 +448,7 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
 
 int scpp_hip_destroy(scpp_hip_ctx *c)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_OK;
     (void)hipStreamSynchronize(c->stream);
@@ -397,6 +460,15 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
                     c->mpc_iters, c->mpc_steps, c->mpc_failed, c->mpc_ipm, c->mpc_reached};
     delete c->mpc_host;
     c->mpc_host = nullptr;
+    for (void *p : {(void *)c->q_xinit, (void *)c->q_rows, (void *)c->q_counters, (void *)c->q_slot_inst})
+        if (p)
+            (void)hipFree(p);
+    if (c->h_poll)
+        (void)hipHostFree(c->h_poll);
+    for (auto st : c->pool_streams)
+        (void)hipStreamDestroy(st);
+    for (auto e : c->pool_events)
+        (void)hipEventDestroy(e);
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -421,6 +493,7 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
 
 int scpp_hip_set_flow_params(scpp_hip_ctx *c, const double *par, int B)
 {
+    DeviceGuard guard(c);
     if (!c || !par || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     CHECK_HIP(hipMemcpyAsync(c->par, par, size_t(B) * c->np * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -430,6 +503,7 @@ int scpp_hip_set_flow_params(scpp_hip_ctx *c, const double *par, int B)
 
 int scpp_hip_upload_traj(scpp_hip_ctx *c, const double *X, const double *U, const double *sigma, int B)
 {
+    DeviceGuard guard(c);
     if (!c || !X || !U || !sigma || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     c->B = B;
@@ -441,6 +515,7 @@ int scpp_hip_upload_traj(scpp_hip_ctx *c, const double *X, const double *U, cons
 
 int scpp_hip_discretize(scpp_hip_ctx *c, int mode)
 {
+    DeviceGuard guard(c);
     if (!c || c->B < 1 || mode < 0 || mode > 3)
         return SCPP_E_ARG;
     if (!(mode & SCPP_MODE_FOH))
@@ -456,6 +531,7 @@ int scpp_hip_discretize(scpp_hip_ctx *c, int mode)
 
 int scpp_hip_download_dd(scpp_hip_ctx *c, double *A, double *B, double *C, double *S, double *Z)
 {
+    DeviceGuard guard(c);
     if (!c || c->B < 1)
         return SCPP_E_ARG;
     const size_t n = size_t(c->B) * (c->K - 1), nx = c->nx, nu = c->nu;
@@ -475,6 +551,7 @@ int scpp_hip_download_dd(scpp_hip_ctx *c, double *A, double *B, double *C, doubl
 
 int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const double *u1, double *x, int B)
 {
+    DeviceGuard guard(c);
     if (!c || !dt || !u0 || !u1 || !x || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     CHECK_HIP(hipMemcpyAsync(c->sim_dt, dt, size_t(B) * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -499,6 +576,7 @@ int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const
 
 int scpp_hip_set_socp_opts(scpp_hip_ctx *c, const scpp_socp_opts *o)
 {
+    DeviceGuard guard(c);
     if (!c || !o)
         return SCPP_E_ARG;
     c->socp = *o;
@@ -508,6 +586,7 @@ int scpp_hip_set_socp_opts(scpp_hip_ctx *c, const scpp_socp_opts *o)
 int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_sc_opts *so, const double *x_init,
                       int B, int warm_start)
 {
+    DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKETQUAT)
@@ -535,6 +614,7 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
 
 int scpp_hip_sc_set_active(scpp_hip_ctx *c, const int32_t *mask, int B)
 {
+    DeviceGuard guard(c);
     if (!c || !mask || B != c->B)
         return SCPP_E_ARG;
     if (!c->sc_ready)
@@ -554,6 +634,7 @@ int scpp_hip_sc_set_active(scpp_hip_ctx *c, const int32_t *mask, int B)
 
 int scpp_hip_sc_iterate(scpp_hip_ctx *c, int *n_active)
 {
+    DeviceGuard guard(c);
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
     int rc = discretizeDispatch(c, c->mode, c->ip + ipm::IP_PAR, ipm::IP_N, c->active, c->last_active);
@@ -574,6 +655,7 @@ int scpp_hip_sc_iterate(scpp_hip_ctx *c, int *n_active)
 
 int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
 {
+    DeviceGuard guard(c);
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
     if (c->sc.nondimensionalize)
@@ -596,6 +678,7 @@ int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
 
 int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
 {
+    DeviceGuard guard(c);
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
     const int B = c->B;
@@ -683,6 +766,7 @@ SCvxBuffers scvxBuffers(scpp_hip_ctx *c)
 int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
                         int B, int warm_start)
 {
+    DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKETQUAT)
@@ -759,48 +843,94 @@ SCvxBuffers scvxBuffersRange(scpp_hip_ctx *c, Range r)
 }
 
 // one SCvx round (one sub-problem solve of every active instance) of an instance range on its stream: instances whose
-// previous candidate was rejected re-solve on their old discretisation (needs_disc = 0), the others start a new iteration
+// previous candidate was rejected re-solve on their old discretisation (needs_disc = 0), the others start a new iteration.
+// Three launches: discretisation, interior-point solve (which first snapshots td -> old_td), and the fused nonlinear-cost /
+// accept-reject kernel (which rolls a rejected candidate back).
 int scvxRound(scpp_hip_ctx *c, Range r)
 {
-    const size_t K = size_t(c->K), f = size_t(r.first), n = size_t(r.count);
     int rc = discretizeDispatch(c, SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, r.count, r);
     if (rc)
         return rc;
-    CHECK_HIP(hipMemcpyAsync(c->vx_Xold + f * K * 14, c->X + f * K * 14, n * K * 14 * sizeof(double), hipMemcpyDeviceToDevice, r.stream));
-    CHECK_HIP(hipMemcpyAsync(c->vx_Uold + f * K * 4, c->U + f * K * 4, n * K * 4 * sizeof(double), hipMemcpyDeviceToDevice, r.stream));
-    rc = launchIpm(c, 0, r.count, true, r);
+    rc = launchIpm(c, 0, r.count, true, r, 0, true);
     if (rc)
         return rc;
     const SCBuffers b = scBuffersRange(c, r);
     const SCvxBuffers v = scvxBuffersRange(c, r);
-    hipLaunchKernelGGL((scvx_cost_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v,
-                       c->scvx.interpolate_input);
-    hipLaunchKernelGGL(scvx_update_kernel, dim3(unsigned((r.count + 63) / 64)), dim3(64), 0, r.stream, b, v, c->scvx);
+    hipLaunchKernelGGL((scvx_cost_update_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+
+int ensurePoll(scpp_hip_ctx *c)
+{
+    if (!c->h_poll)
+        CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_poll), 64 * sizeof(int), 0));
+    return 0;
+}
+// slot pools beyond the first run on their own streams
+int ensurePools(scpp_hip_ctx *c, int pools)
+{
+    while (int(c->pool_streams.size()) < pools - 1)
+    {
+        hipStream_t st;
+        CHECK_HIP(hipStreamCreate(&st));
+        c->pool_streams.push_back(st);
+    }
+    while (int(c->pool_events.size()) < pools)
+    {
+        hipEvent_t e;
+        CHECK_HIP(hipEventCreate(&e));
+        c->pool_events.push_back(e);
+    }
+    return 0;
 }
 } // namespace
 
 int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
 {
+    DeviceGuard guard(c);
     if (!c || !c->scvx_ready)
         return SCPP_E_STATE;
-    int n_active = c->last_active;
+    if (int rc = ensurePoll(c))
+        return rc;
+    if (int rc = ensurePools(c, 1))
+        return rc;
     const long max_rounds = long(c->scvx.max_iterations) * 64;
-    // one stream: measured, the two-stream skewed pipeline of scpp_hip_sc_solve loses here (1914 vs 2174 converged
-    // trajectories/s at 8192): rounds late in the run have few active instances and are latency-bound either way
-    for (long round = 0; round < max_rounds && n_active > 0; round++)
+    // One stream (measured: the two-stream skewed pipeline of scpp_hip_sc_solve loses here, rounds late in the run have few
+    // active instances and are latency-bound either way).  The host does not wait for a round before enqueueing the next:
+    // the active count is read back asynchronously every POLL rounds and looked at one poll later, so the device never
+    // idles on the host; rounds enqueued after the last instance terminated return at the top of every kernel.
+    constexpr int POLL = 4;
+    bool pending = false;
+    volatile int *h_active = c->h_poll;
+    for (long round = 0; round < max_rounds; round++)
     {
         int rc = scvxRound(c, fullRange(c));
         if (rc)
             return rc;
-        rc = countActive(c, &n_active);
-        if (rc)
-            return rc;
-        c->last_active = n_active;
+        if (round % POLL == POLL - 1 || c->B < 64)
+        {
+            if (pending)
+            {
+                CHECK_HIP(hipEventSynchronize(c->pool_events[0]));
+                if (*h_active == 0)
+                    break;
+            }
+            hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, c->stream, c->B, (const int *)c->active, c->counter);
+            CHECK_HIP(hipMemcpyAsync(c->h_poll, c->counter, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            CHECK_HIP(hipEventRecord(c->pool_events[0], c->stream));
+            pending = true;
+        }
     }
     if (c->scvx.nondimensionalize)
         hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
     CHECK_HIP(hipStreamSynchronize(c->stream));
+    {
+        int n = 0;
+        int rc = countActive(c, &n);
+        if (rc)
+            return rc;
+        c->last_active = n;
+    }
     if (n_converged)
     {
         std::vector<int> conv(c->B);
@@ -813,8 +943,193 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
     return SCPP_OK;
 }
 
+// ---------------------------------------------------------------- SCvx streaming engine (continuous batching)
+int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                               int N, int slots, int pools, int *n_converged)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKETQUAT)
+        return SCPP_E_UNSUPPORTED;
+    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
+        return SCPP_E_UNSUPPORTED;
+    const int S = slots > 0 ? (slots < N ? slots : N) : (c->Bmax < N ? c->Bmax : N);
+    // the engine's per-slot state is the batch state of scvx_setup: set it up on the first S instances' worth of slots
+    // WITHOUT starting them (every slot starts empty and is filled by the first refill)
+    if (int rc = scpp_hip_scvx_setup(c, mp, so, x_init, S, 0))
+        return rc;
+    const size_t K = size_t(c->K), rowd = size_t(streamRowDoubles(c->K, 14, 4));
+    if (c->q_cap < size_t(N))
+    {
+        if (c->q_xinit)
+            (void)hipFree(c->q_xinit);
+        if (c->q_rows)
+            (void)hipFree(c->q_rows);
+        c->q_xinit = c->q_rows = nullptr;
+        c->q_cap = 0;
+        int a = 0;
+        a |= devAlloc(&c->q_xinit, size_t(N) * 14);
+        a |= devAlloc(&c->q_rows, size_t(N) * rowd);
+        if (a)
+            return SCPP_E_HIP;
+        c->q_cap = size_t(N);
+    }
+    if (!c->q_counters)
+    {
+        int a = 0;
+        a |= devAlloc(&c->q_counters, 4);
+        a |= devAlloc(&c->q_slot_inst, size_t(c->Bmax));
+        if (a)
+            return SCPP_E_HIP;
+    }
+    (void)K;
+    c->q_N = N;
+    CHECK_HIP(hipMemcpyAsync(c->q_xinit, x_init, size_t(N) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemsetAsync(c->q_counters, 0, 4 * sizeof(int), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->q_slot_inst, 0xFF, size_t(c->Bmax) * sizeof(int), c->stream)); // -1: empty
+    CHECK_HIP(hipMemsetAsync(c->active, 0, size_t(c->Bmax) * sizeof(int), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->vx_needs_disc, 0, size_t(c->Bmax) * sizeof(int), c->stream));
+    // pools: disjoint slot ranges, each on its own stream, all pulling from the one queue.  Their rounds drift apart, so the
+    // memory-bound interior-point kernel of one pool overlaps the ALU/LDS-bound discretisation of another without any of
+    // the explicit skewing scpp_hip_sc_solve needs.
+    int P = pools > 0 ? pools : 2;
+    if (const char *e = std::getenv("SCPP_STREAM_POOLS"))
+        P = std::atoi(e) > 0 ? std::atoi(e) : P;
+    if (S < 2048 * P)
+        P = S >= 4096 ? 2 : 1;
+    if (P > 8)
+        P = 8;
+    if (int rc = ensurePoll(c))
+        return rc;
+    if (int rc = ensurePools(c, P))
+        return rc;
+    std::vector<Range> pool;
+    {
+        const int per = ((S + P - 1) / P + 7) & ~7; // keep the XCD groups of 8 instances intact
+        int first = 0;
+        for (int p = 0; p < P && first < S; p++)
+        {
+            const int cnt = first + per <= S ? per : S - first;
+            pool.push_back(Range{first, cnt, p == 0 ? c->stream : c->pool_streams[size_t(p - 1)]});
+            first += cnt;
+        }
+        P = int(pool.size());
+    }
+    // everything enqueued so far is on the main stream
+    CHECK_HIP(hipEventRecord(c->pool_events[0], c->stream));
+    for (int p = 1; p < P; p++)
+        CHECK_HIP(hipStreamWaitEvent(pool[size_t(p)].stream, c->pool_events[0], 0));
+    StreamQueue q;
+    q.N = N;
+    q.x_init = c->q_xinit;
+    q.rows = c->q_rows;
+    q.head = c->q_counters;
+    q.done = c->q_counters + 1;
+    q.nconv = c->q_counters + 2;
+    scpp_sc_opts sc = c->sc; // as built by scvx_setup
+    // an instance needs at most max_iterations accepted + ~log2 rejected solves each; the queue drains in ceil(N/S) waves
+    const long per_instance = long(so->max_iterations) * 64;
+    const long max_rounds = per_instance * ((N + S - 1) / S + 1);
+    constexpr int POLL = 4;
+    bool pending = false;
+    volatile int *h_done = c->h_poll;
+    long round = 0;
+    for (; round < max_rounds; round++)
+    {
+        for (int p = 0; p < P; p++)
+        {
+            const Range r = pool[size_t(p)];
+            const SCBuffers b = scBuffersRange(c, r);
+            const SCvxBuffers v = scvxBuffersRange(c, r);
+            StreamQueue qp = q;
+            qp.slot_inst = c->q_slot_inst + r.first;
+            qp.warm = c->ipm_warm + r.first;
+            hipLaunchKernelGGL(scvx_stream_refill_kernel, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, qp, *mp, sc, *so);
+            int rc = scvxRound(c, r);
+            if (rc)
+                return rc;
+        }
+        if (round % POLL == POLL - 1)
+        {
+            if (pending)
+            {
+                int done = 0;
+                for (int p = 0; p < P; p++)
+                {
+                    CHECK_HIP(hipEventSynchronize(c->pool_events[size_t(p)]));
+                    done = h_done[p] > done ? h_done[p] : done;
+                }
+                if (done >= N)
+                    break;
+            }
+            for (int p = 0; p < P; p++)
+            {
+                CHECK_HIP(hipMemcpyAsync(c->h_poll + p, c->q_counters + 1, sizeof(int), hipMemcpyDeviceToHost, pool[size_t(p)].stream));
+                CHECK_HIP(hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream));
+            }
+            pending = true;
+        }
+    }
+    c->stream_rounds = round;
+    c->stream_pools = P;
+    for (int p = 1; p < P; p++)
+    {
+        CHECK_HIP(hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream));
+        CHECK_HIP(hipStreamWaitEvent(c->stream, c->pool_events[size_t(p)], 0));
+    }
+    int counters[4] = {0, 0, 0, 0};
+    CHECK_HIP(hipMemcpyAsync(counters, c->q_counters, sizeof counters, hipMemcpyDeviceToHost, c->stream));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->last_active = 0;
+    if (n_converged)
+        *n_converged = counters[2];
+    return counters[1] == N ? SCPP_OK : SCPP_E_STATE; // round cap hit with instances still running: cannot happen with finite max_iterations
+}
+
+int scpp_hip_stream_rows(scpp_hip_ctx *c, void **rows, int *row_doubles, int *n)
+{
+    DeviceGuard guard(c);
+    if (!c)
+        return SCPP_E_ARG;
+    if (!c->q_rows || c->q_N < 1)
+        return SCPP_E_STATE;
+    if (rows)
+        *rows = c->q_rows;
+    if (row_doubles)
+        *row_doubles = streamRowDoubles(c->K, 14, 4);
+    if (n)
+        *n = c->q_N;
+    return SCPP_OK;
+}
+
+int scpp_hip_stream_info(scpp_hip_ctx *c, long long *rounds, int *pools)
+{
+    if (!c)
+        return SCPP_E_ARG;
+    if (rounds)
+        *rounds = c->stream_rounds;
+    if (pools)
+        *pools = c->stream_pools;
+    return SCPP_OK;
+}
+
+int scpp_hip_stream_download(scpp_hip_ctx *c, double *rows, int first, int count)
+{
+    DeviceGuard guard(c);
+    if (!c || !rows || first < 0 || count < 1)
+        return SCPP_E_ARG;
+    if (!c->q_rows || first + count > c->q_N)
+        return SCPP_E_STATE;
+    const size_t rowd = size_t(streamRowDoubles(c->K, 14, 4));
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    CHECK_HIP(hipMemcpy(rows, c->q_rows + size_t(first) * rowd, size_t(count) * rowd * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
 int scpp_hip_scvx_download_state(scpp_hip_ctx *c, double *trust_region, double *nonlinear_cost, int32_t *solves, double *last_decision)
 {
+    DeviceGuard guard(c);
     if (!c || !c->scvx_ready)
         return SCPP_E_STATE;
     CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -832,6 +1147,7 @@ int scpp_hip_scvx_download_state(scpp_hip_ctx *c, double *trust_region, double *
 
 int scpp_hip_socp_solve(scpp_hip_ctx *c)
 {
+    DeviceGuard guard(c);
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
     int rc = launchIpm(c, 0, c->B);
@@ -844,6 +1160,7 @@ int scpp_hip_socp_solve(scpp_hip_ctx *c)
 int scpp_hip_download(scpp_hip_ctx *c, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                       int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta)
 {
+    DeviceGuard guard(c);
     if (!c || c->B < 1)
         return SCPP_E_ARG;
     const size_t B = size_t(c->B);
@@ -871,6 +1188,7 @@ int scpp_hip_download(scpp_hip_ctx *c, double *X, double *U, double *sigma, int3
 
 int scpp_hip_download_socp_info(scpp_hip_ctx *c, double *info)
 {
+    DeviceGuard guard(c);
     if (!c || !info || !c->dbg || c->B < 1)
         return SCPP_E_ARG;
     CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -881,6 +1199,7 @@ int scpp_hip_download_socp_info(scpp_hip_ctx *c, double *info)
 // ---- linear MPC (Rocket2D): MPCAlgorithm.cpp:34-139, MPC_sim.cpp:49-86 ----
 int scpp_hip_mpc_setup(scpp_hip_ctx *c, const scpp_mpc_opts *o, const double *flow_par)
 {
+    DeviceGuard guard(c);
     if (!c || !o || !flow_par)
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKET2D)
@@ -925,6 +1244,7 @@ int scpp_hip_mpc_setup(scpp_hip_ctx *c, const scpp_mpc_opts *o, const double *fl
 
 int scpp_hip_mpc_get_model(scpp_hip_ctx *c, double *A, double *B, double *z)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     if (!c->mpc_ready)
@@ -954,6 +1274,7 @@ void launchMpcSolve(scpp_hip_ctx *c, const double *x0, const int *active, int B)
 
 int scpp_hip_mpc_solve(scpp_hip_ctx *c, const double *x_init, const double *x_final, int B, int *n_solved)
 {
+    DeviceGuard guard(c);
     if (!c || !x_init || !x_final || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
     if (!c->mpc_ready)
@@ -968,9 +1289,9 @@ int scpp_hip_mpc_solve(scpp_hip_ctx *c, const double *x_init, const double *x_fi
         CHECK_HIP(hipMemsetAsync(c->mpc_cost, 0, size_t(B) * 2 * sizeof(double), c->stream));
         c->mpc_B = B;
     }
-    spanBegin(c, 1, B, c->stream);
+    const bool timed = spanBegin(c, 1, B, c->stream);
     launchMpcSolve(c, c->mpc_x0, nullptr, B);
-    spanEnd(c, c->stream);
+    spanEnd(c, timed, c->stream);
     CHECK_HIP(hipGetLastError());
     if (n_solved)
     {
@@ -988,6 +1309,7 @@ int scpp_hip_mpc_solve(scpp_hip_ctx *c, const double *x_init, const double *x_fi
 
 int scpp_hip_mpc_download(scpp_hip_ctx *c, double *X, double *U, double *cost, int32_t *status, int32_t *iters)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     if (!c->mpc_ready || c->mpc_B < 1)
@@ -1012,6 +1334,7 @@ int scpp_hip_mpc_download(scpp_hip_ctx *c, double *X, double *U, double *cost, i
 int scpp_hip_mpc_sim(scpp_hip_ctx *c, const double *x_start, const double *x_final, int B, double time_step, double sim_time,
                      double stop_tol, int max_steps, int *n_reached)
 {
+    DeviceGuard guard(c);
     if (!c || !x_start || !x_final || B < 1 || B > c->Bmax || !(time_step > 0.) || !(sim_time > 0.))
         return SCPP_E_ARG;
     if (!c->mpc_ready)
@@ -1073,6 +1396,7 @@ int scpp_hip_mpc_sim(scpp_hip_ctx *c, const double *x_start, const double *x_fin
 int scpp_hip_mpc_sim_download(scpp_hip_ctx *c, double *x, double *u, double *t, int32_t *steps, int32_t *failed_solves,
                               int32_t *ipm_iters, int32_t *reached)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     if (!c->mpc_ready || c->mpc_B < 1)
@@ -1099,6 +1423,7 @@ int scpp_hip_mpc_sim_download(scpp_hip_ctx *c, double *x, double *u, double *t, 
 
 int scpp_hip_get_timing(scpp_hip_ctx *c, scpp_timing *out, int reset)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     collectTiming(c);
@@ -1111,6 +1436,7 @@ int scpp_hip_get_timing(scpp_hip_ctx *c, scpp_timing *out, int reset)
 
 int scpp_hip_device_ptrs(scpp_hip_ctx *c, void **X, void **U, void **sigma)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     if (X)
@@ -1124,6 +1450,7 @@ int scpp_hip_device_ptrs(scpp_hip_ctx *c, void **X, void **U, void **sigma)
 
 int scpp_hip_synchronize(scpp_hip_ctx *c)
 {
+    DeviceGuard guard(c);
     if (!c)
         return SCPP_E_ARG;
     CHECK_HIP(hipStreamSynchronize(c->stream));

@@ -3,6 +3,11 @@
 //   SCvxAlgorithm::getNonlinearCost                 scpp_core/src/SCvxAlgorithm.cpp:262-278  (K-1 nonlinear propagations)
 //   accept / reject / radius update of iterate()    scpp_core/src/SCvxAlgorithm.cpp:95-152
 // The sub-problem itself (SCvxProblem.cpp:6-71) is solved by ipm_kernel in its SCvx mode (ipm_kernel.h: IP_SCVX).
+//
+// Streaming engine (continuous batching): the context's B instance SLOTS pull problem instances from a device-side queue.
+// A slot whose SCvx loop has terminated hands its result row to the output buffer and is refilled with the next queued
+// instance by scvx_stream_refill_kernel at the top of the next round, so every round runs with (nearly) all slots busy
+// although the instances need very different numbers of sub-problem solves (mean 26, up to > 60 for the shipped scenario).
 #pragma once
 #include "discretize_kernel.h"
 #include "sc_kernels.h"
@@ -12,7 +17,7 @@ namespace scpp
 
 struct SCvxBuffers
 {
-    double *Xold, *Uold;       // candidate backup (td = old_td on rejection)
+    double *Xold, *Uold;       // candidate backup (td = old_td on rejection); filled by ipm_kernel before it overwrites X / U
     double *tr;                // [B] trust-region radius
     double *last_cost;         // [B] last_nonlinear_cost
     double *cost;              // [B] J of the current candidate
@@ -20,14 +25,12 @@ struct SCvxBuffers
     int *has_last, *needs_disc, *solves;
 };
 
-// per-instance SCvx start-up AFTER sc_setup_kernel (which nondimensionalises, builds the initial or warm trajectory
+// per-instance SCvx start-up AFTER scSetupOne (which nondimensionalises, builds the initial or warm trajectory
 // and thrust_const): fixed final time, SCvx flags of the sub-problem, radius.
-__global__ void scvx_setup_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so, double final_time, int warm)
+__device__ inline void scvxSetupOne(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, double final_time, int warm,
+                                    long i)
 {
     using namespace ipm;
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= b.B)
-        return;
     double *ip = b.ip + i * IP_N;
     ip[IP_SCVX] = 1.;
     ip[IP_WT] = 1.;   // dummy decoupled sigma block (S = 0)
@@ -50,12 +53,101 @@ __global__ void scvx_setup_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so,
         v.info[i * 4 + j] = 0.;
     b.sc_iters[i] = 1; // iteration++ at the top of the first iterate()
 }
+__global__ void scvx_setup_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so, double final_time, int warm)
+{
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    scvxSetupOne(b, v, so, final_time, warm, i);
+}
 
-// getNonlinearCost: one wavefront per instance, lane k propagates segment k with the nonlinear dynamics (RKF78 x 20
-// like scpp::simulate) and contributes ||x_prop - x_{k+1}||_1; fixed summation order (wave_sum) keeps the
-// accept/reject decisions reproducible.
+// SCvxAlgorithm.cpp:95-152 for one active instance, after the sub-problem solve and the cost evaluation (one lane).
+// Returns 1 if the candidate was rejected (td = old_td: the caller restores X / U from the backup).
+__device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, long i, double nonlinear_cost)
+{
+    using namespace ipm;
+    v.solves[i] += 1;
+    if (b.status[i] != 0)
+    {
+        b.active[i] = 0; // solver failure: the reference terminates (SCvxAlgorithm.cpp:87-91)
+        v.needs_disc[i] = 0;
+        return 0;
+    }
+    const double linear_cost = b.norm1_nu[i];
+    bool done_iteration = false, converged = false;
+    int restore = 0;
+    double code = 1.;
+    if (!v.has_last[i])
+    {
+        v.has_last[i] = 1;
+        v.last_cost[i] = nonlinear_cost;
+        done_iteration = true;
+        code = 2.;
+    }
+    else
+    {
+        const double actual_change = v.last_cost[i] - nonlinear_cost;
+        const double predicted_change = v.last_cost[i] - linear_cost;
+        v.last_cost[i] = nonlinear_cost; // (overwritten even when the candidate is rejected, :118)
+        v.info[i * 4 + 1] = actual_change;
+        v.info[i * 4 + 2] = predicted_change;
+        if (fabs(predicted_change) < so.change_threshold)
+        {
+            converged = true;
+            done_iteration = true;
+            code = 3.;
+        }
+        else
+        {
+            const double rho = actual_change / predicted_change;
+            v.info[i * 4 + 0] = rho;
+            if (rho < so.rho_0)
+            {
+                v.tr[i] /= so.alpha;
+                restore = 1; // td = old_td ; re-solve without re-discretising
+                v.needs_disc[i] = 0;
+                code = 0.;
+            }
+            else
+            {
+                if (rho < so.rho_1)
+                    v.tr[i] /= so.alpha;
+                else if (rho >= so.rho_2)
+                    v.tr[i] *= so.beta;
+                done_iteration = true;
+            }
+        }
+    }
+    v.info[i * 4 + 3] = code;
+    b.ip[i * IP_N + IP_TR] = v.tr[i];
+    if (done_iteration)
+    {
+        if (converged)
+        {
+            b.converged[i] = 1;
+            b.active[i] = 0;
+            v.needs_disc[i] = 0;
+        }
+        else if (b.sc_iters[i] >= so.max_iterations)
+        {
+            b.active[i] = 0;
+            v.needs_disc[i] = 0;
+        }
+        else
+        {
+            b.sc_iters[i] += 1;
+            v.needs_disc[i] = 1;
+        }
+    }
+    return restore;
+}
+
+// getNonlinearCost + the accept / reject / radius logic: one wavefront per instance.  Lane k propagates segment k with the
+// nonlinear dynamics (RKF78 x 20 like scpp::simulate) and contributes ||x_prop - x_{k+1}||_1; fixed summation order
+// (wave_sum) keeps the accept/reject decisions reproducible.  Lane 0 then takes the decision of iterate(); a rejected
+// candidate is rolled back by the whole wavefront (td = old_td).
 template <class Model>
-__global__ void __launch_bounds__(WAVE) scvx_cost_kernel(SCBuffers b, SCvxBuffers v, int foh)
+__global__ void __launch_bounds__(WAVE) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
 {
     using namespace ipm;
     constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP;
@@ -63,6 +155,7 @@ __global__ void __launch_bounds__(WAVE) scvx_cost_kernel(SCBuffers b, SCvxBuffer
     if (i >= b.B || b.active[i] == 0)
         return;
     const int K = b.K, k = threadIdx.x;
+    const int foh = so.interpolate_input;
     double acc = 0.;
     if (k < K - 1 && b.status[i] == 0)
     {
@@ -115,93 +208,116 @@ __global__ void __launch_bounds__(WAVE) scvx_cost_kernel(SCBuffers b, SCvxBuffer
             acc += fabs(y[j] - X[NX + j]);
     }
     acc = wave_sum(acc);
+    int restore = 0;
     if (k == 0)
+    {
         v.cost[i] = acc;
+        restore = scvxDecide(b, v, so, i, acc);
+    }
+    restore = __shfl(restore, 0);
+    if (restore)
+    {
+        for (int e = k; e < K * NX; e += WAVE)
+            b.X[i * K * NX + e] = v.Xold[i * K * NX + e];
+        for (int e = k; e < K * NU; e += WAVE)
+            b.U[i * K * NU + e] = v.Uold[i * K * NU + e];
+    }
 }
 
-// SCvxAlgorithm.cpp:95-152 for every active instance, after the sub-problem solve and the cost evaluation
-__global__ void scvx_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
+// ---------------------------------------------------------------- streaming engine
+// result row of one instance (doubles): X [K][14], U [K][4] (dimensional), then the scalars below
+enum StreamRow
+{
+    SR_SIGMA = 0,
+    SR_NU,     // final ||nu||_1 (linear cost of the last sub-problem)
+    SR_COST,   // last nonlinear cost J
+    SR_TR,     // final trust-region radius
+    SR_ITERS,  // SCvx iterations
+    SR_SOLVES, // sub-problem solves
+    SR_CONV,   // 1: |dL| < change_threshold (SCvxAlgorithm.cpp:125)
+    SR_STATUS, // 0 ok, < 0 interior-point failure
+    SR_IPM,    // interior-point iterations over all solves
+    SR_INST,   // instance id (row index): self-check of the hand-over
+    SR_NSCALARS
+};
+__host__ __device__ inline int streamRowDoubles(int K, int nx, int nu) { return K * (nx + nu) + SR_NSCALARS; }
+
+struct StreamQueue
+{
+    int N;                 // instances in the job
+    const double *x_init;  // [N][14] dimensional initial states
+    double *rows;          // [N][streamRowDoubles]
+    int *head;             // next instance id to hand out
+    int *done;             // instances whose row has been written
+    int *nconv;            // converged instances
+    int *slot_inst;        // [B] instance id held by the slot, -1: empty
+    int *warm;             // [B] interior-point warm-start flag of the slot
+};
+
+// One wavefront per slot, at the top of every round: harvest a terminated instance (redimensionalised row -> rows[inst]),
+// then pull the next instance id off the queue and run its cold start (scSetupOne + scvxSetupOne spread over the lanes).
+__global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, SCvxBuffers v, StreamQueue q, scpp_rocketquat_params mp,
+                                                                   scpp_sc_opts sc, scpp_scvx_opts so)
 {
     using namespace ipm;
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= b.B || b.active[i] == 0)
+    const long slot = blockIdx.x;
+    if (slot >= b.B || b.active[slot] != 0)
         return;
-    v.solves[i] += 1;
-    if (b.status[i] != 0)
+    const int K = b.K, lane = threadIdx.x;
+    const int inst = q.slot_inst[slot];
+    if (inst >= 0)
     {
-        b.active[i] = 0; // solver failure: the reference terminates (SCvxAlgorithm.cpp:87-91)
-        v.needs_disc[i] = 0;
-        return;
-    }
-    const int K = b.K;
-    const double nonlinear_cost = v.cost[i], linear_cost = b.norm1_nu[i];
-    bool done_iteration = false, converged = false;
-    double code = 1.;
-    if (!v.has_last[i])
-    {
-        v.has_last[i] = 1;
-        v.last_cost[i] = nonlinear_cost;
-        done_iteration = true;
-        code = 2.;
-    }
-    else
-    {
-        const double actual_change = v.last_cost[i] - nonlinear_cost;
-        const double predicted_change = v.last_cost[i] - linear_cost;
-        v.last_cost[i] = nonlinear_cost; // (overwritten even when the candidate is rejected, :118)
-        v.info[i * 4 + 1] = actual_change;
-        v.info[i * 4 + 2] = predicted_change;
-        if (fabs(predicted_change) < so.change_threshold)
+        const double *ip = b.ip + slot * IP_N;
+        const double ms = so.nondimensionalize ? ip[IP_MSCALE] : 1., rs = so.nondimensionalize ? ip[IP_RSCALE] : 1.;
+        double *row = q.rows + size_t(inst) * streamRowDoubles(K, 14, 4);
+        for (int e = lane; e < K * 14; e += WAVE)
+            row[e] = b.X[slot * K * 14 + e] * redimX(e % 14, ms, rs);
+        for (int e = lane; e < K * 4; e += WAVE)
+            row[K * 14 + e] = b.U[slot * K * 4 + e] * redimU(e % 4, ms, rs);
+        if (lane == 0)
         {
-            converged = true;
-            done_iteration = true;
-            code = 3.;
-        }
-        else
-        {
-            const double rho = actual_change / predicted_change;
-            v.info[i * 4 + 0] = rho;
-            if (rho < so.rho_0)
-            {
-                v.tr[i] /= so.alpha;
-                // td = old_td ; re-solve without re-discretising
-                for (int e = 0; e < K * 14; e++)
-                    b.X[i * K * 14 + e] = v.Xold[i * K * 14 + e];
-                for (int e = 0; e < K * 4; e++)
-                    b.U[i * K * 4 + e] = v.Uold[i * K * 4 + e];
-                v.needs_disc[i] = 0;
-                code = 0.;
-            }
-            else
-            {
-                if (rho < so.rho_1)
-                    v.tr[i] /= so.alpha;
-                else if (rho >= so.rho_2)
-                    v.tr[i] *= so.beta;
-                done_iteration = true;
-            }
+            double *s = row + K * 18;
+            s[SR_SIGMA] = b.sigma[slot];
+            s[SR_NU] = b.norm1_nu[slot];
+            s[SR_COST] = v.last_cost[slot];
+            s[SR_TR] = v.tr[slot];
+            s[SR_ITERS] = double(b.sc_iters[slot]);
+            s[SR_SOLVES] = double(v.solves[slot]);
+            s[SR_CONV] = double(b.converged[slot]);
+            s[SR_STATUS] = double(b.status[slot]);
+            s[SR_IPM] = double(b.ipm_iters[slot]);
+            s[SR_INST] = double(inst);
+            if (b.converged[slot])
+                atomicAdd(q.nconv, 1);
         }
     }
-    v.info[i * 4 + 3] = code;
-    b.ip[i * IP_N + IP_TR] = v.tr[i];
-    if (done_iteration)
+    WAVE_SYNC(); // every lane has read the slot's old instance id and state before lane 0 replaces them
+    int next = -1;
+    if (lane == 0)
     {
-        if (converged)
+        if (*(volatile int *)q.head < q.N)
         {
-            b.converged[i] = 1;
-            b.active[i] = 0;
-            v.needs_disc[i] = 0;
+            next = atomicAdd(q.head, 1);
+            if (next >= q.N)
+                next = -1;
         }
-        else if (b.sc_iters[i] >= so.max_iterations)
+        q.slot_inst[slot] = next;
+    }
+    next = __shfl(next, 0);
+    if (next >= 0)
+    {
+        const double *xi = q.x_init + size_t(next) * 14;
+        scSetupOne(b, mp, sc, 0, slot, xi, lane, WAVE);
+        if (lane == 0)
         {
-            b.active[i] = 0;
-            v.needs_disc[i] = 0;
+            scvxSetupOne(b, v, so, mp.final_time, 0, slot);
+            q.warm[slot] = 0; // a new instance starts from ECOS's cold initialisation
         }
-        else
-        {
-            b.sc_iters[i] += 1;
-            v.needs_disc[i] = 1;
-        }
+    }
+    if (lane == 0 && inst >= 0)
+    {
+        __threadfence();
+        atomicAdd(q.done, 1); // after the row is complete
     }
 }
 

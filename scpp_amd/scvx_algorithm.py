@@ -51,6 +51,16 @@ class SCvxAlgorithm:
         self.ctx.scvx_setup(self.model.p, self.opts, x_init, warm_start=warm_start)
         return self.ctx.scvx_solve()
 
+    def solveStream(self, x_init, slots=0, pools=0):
+        """Cold-start SCvxAlgorithm::solve of every row of x_init [N][14] with continuous batching: N may exceed batch_max,
+        finished slots are refilled from the queue on the device.  Returns #converged; results via getStreamSolution()."""
+        x_init = np.atleast_2d(np.asarray(x_init, dtype=np.float64))
+        self.opts = load_scvx_opts(self.model.getParameterFolder(), self.opts.K, self._max_iterations)
+        return self.ctx.scvx_solve_stream(self.model.p, self.opts, x_init, slots=slots, pools=pools)
+
+    def getStreamSolution(self, first=0, count=None):
+        return self.ctx.stream_download(first, count)
+
     def getSolution(self):
         out = self.ctx.download()
         out.update(self.ctx.scvx_state())

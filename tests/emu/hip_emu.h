@@ -340,6 +340,14 @@ inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int *d)
+{
+    *d = 0;
+    return 0;
+}
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+inline void __threadfence() {}
 inline hipError_t hipGetDeviceCount(int *n)
 {
     *n = 1;

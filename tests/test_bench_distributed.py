@@ -1,0 +1,49 @@
+"""bench.py's OWN N > 1 path (one process per rank, instance sharding, the single all-gather of the result rows) executed end
+to end on CPU: world size 2 over gloo with the CPU emulation build of the kernels standing in for the GPU library.  The
+gathered payload must equal what a single process computes for the same instance ids (bitwise: instances are independent
+and the engine is deterministic)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import scpp_amd
+from conftest import ROOT
+
+
+def test_bench_world2_gloo_matches_single_process(model, emu_lib, tmp_path):
+    K, B, steps, warm, maxit, seed = 8, 3, 2, 1, 4, 20260927
+    dump = str(tmp_path / "rows.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+           "--backend", "gloo", "--library", emu_lib, "--K", str(K), "--batch", str(B), "--max-iterations", str(maxit),
+           "--no-cpu-baseline", "--no-extras", "--dump", dump]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warm
+    assert line["config"]["instances_timed"] == 2 * steps * B
+    rows = np.load(dump)
+    assert rows.shape == (2 * steps * B, K * 18 + 10)
+    got = scpp_amd.Context.unpack_stream_rows(rows, K)
+    # the same instance ids through the plain batch entry point of one process
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    world = 2
+    at = 0
+    for rank in range(world):
+        for i in range(steps):
+            first = ((warm + i) * world + rank) * B
+            x0 = model.randomized_initial_states(B, seed=seed, first=first)
+            alg.solve(x0)
+            ref = alg.getSolution()
+            sl = slice(at, at + B)
+            for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+                assert np.array_equal(got[key][sl], ref[key]), (rank, i, key)
+            at += B
+    conv = int(got["converged"].sum())
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * steps - conv) < 1e-6 * max(conv, 1) + 1e-9
+    # full payload of SURVEY 8(e): X, U, sigma, ||nu||_1, iterations, status all travel in the row
+    assert (got["instance"].reshape(world, steps * B) == np.arange(steps * B)[None, :]).all()

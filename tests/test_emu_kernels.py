@@ -112,6 +112,29 @@ def test_emu_scvx_matches_oracle(oracle, model, emu_lib):
     assert compared >= 2
 
 
+def test_emu_scvx_stream_equals_batch(model, emu_lib):
+    """Continuous batching: 7 instances through 3 resident slots (two pools) give bitwise the results of the batch path,
+    whatever slot and round an instance lands in."""
+    K, maxit, N = 8, 6, 7
+    x0 = model.randomized_initial_states(N)
+    ref = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=emu_lib, max_iterations=maxit).initialize()
+    nref = ref.solve(x0)
+    r = ref.getSolution()
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=4, library=emu_lib, max_iterations=maxit).initialize()
+    for slots, pools in ((3, 1), (4, 2)):
+        n = alg.solveStream(x0, slots=slots, pools=pools)
+        o = alg.getStreamSolution()
+        assert n == nref
+        assert (o["instance"] == np.arange(N)).all()
+        for key in ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",
+                    "ipm_iters"):
+            assert np.array_equal(o[key], r[key]), (slots, pools, key)
+    # a second job on the same context, fewer instances than slots
+    n = alg.solveStream(x0[:2])
+    o = alg.getStreamSolution()
+    assert np.array_equal(o["X"], r["X"][:2]) and np.array_equal(o["solves"], r["solves"][:2])
+
+
 def test_emu_config_variants(oracle, emu_lib, tmp_path):
     """Configuration switches of the model file that change the sub-problem: `exact_minimum_thrust false` (the minimum
     thrust becomes U_z >= T_min instead of the linearised direction, rocketQuat.cpp:117-133) and a smaller trust-region

@@ -298,3 +298,25 @@ def test_pipelined_loop_equals_single_stream_loop(model, hip_lib):
             assert np.array_equal(a[key][lo:lo + 512], b[key]), (lo, key)
     small.ctx.close()
 
+
+
+def test_scvx_stream_equals_batch_on_gpu(model, hip_lib):
+    """Continuous batching (scpp_hip_scvx_solve_stream): 1500 instances through 512 resident slots in two pools give, bitwise,
+    what the plain batch entry point computes for them -- whatever slot, pool and round an instance lands in -- and the
+    device-side queue hands out every instance exactly once."""
+    K, N = 50, 1500
+    x0 = model.randomized_initial_states(N, first=5000)
+    ref = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=hip_lib).initialize()
+    nref = ref.solve(x0)
+    r = ref.getSolution()
+    ref.ctx.close()
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=512, library=hip_lib).initialize()
+    for slots, pools in ((512, 2), (300, 1)):
+        n = alg.solveStream(x0, slots=slots, pools=pools)
+        o = alg.getStreamSolution()
+        assert n == nref and n >= 0.95 * N  # the shipped scenario converges in SCvx mode
+        assert (o["instance"] == np.arange(N)).all()
+        for key in ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",
+                    "ipm_iters"):
+            assert np.array_equal(o[key], r[key]), (slots, pools, key)
+    alg.ctx.close()
