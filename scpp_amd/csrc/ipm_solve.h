@@ -526,13 +526,14 @@ __device__ inline void zeroT(const SV &st)
 // The solver is split into OUT-OF-LINE phases.  Each phase gets its own register allocation (the monolithic
 // kernel kept >1000 values alive and spilled inside every hot loop); what survives a phase boundary lives in
 // the field-major records (global memory) or in the two small wave-uniform structs Glob / Iter, which the
-// kernel keeps in private memory and every phase copies in and out.
+// kernel keeps in LDS (one copy per wavefront, 1.4 KB) and every phase copies in and out.  (They lived in private memory
+// first: 64 per-lane copies of ~100 wave-uniform doubles, stored and re-loaded by every phase, were ~0.9 MB of scratch
+// traffic per interior-point iteration on a kernel that is HBM-bandwidth bound.)
 // =====================================================================================================
+#define PRIV LDSP
 #ifdef SCPP_HIP_EMU
-#define PRIV
 #define PHASE_FN inline
 #else
-#define PRIV __attribute__((address_space(5)))
 #define PHASE_FN __device__ __attribute__((noinline))
 #endif
 
@@ -561,7 +562,9 @@ __device__ inline T loadPriv(const PRIV T *p)
 template <class T>
 __device__ inline void storePriv(PRIV T *p, const T &t)
 {
-    __builtin_memcpy(p, &t, sizeof(T));
+    WAVE_SYNC(); // every lane has taken its copy before the (wave-uniform) new value goes in
+    if (threadIdx.x == 0)
+        __builtin_memcpy(p, &t, sizeof(T));
 }
 
 // lane-local views used by every phase
@@ -591,7 +594,7 @@ __device__ inline Views makeViews(const Ctx &c)
 }
 
 // ---- setup: clear records, field-major copy of the dynamics, trust-region centre, fixed values ----
-PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
+PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
 {
     const bool warm = uniformInt(warmIn) != 0;
     const Ctx c = uniformCtx(cin);
@@ -697,7 +700,7 @@ PHASE_FN void phSetup(const Ctx &cin, const double *Xin, const double *Uin, cons
 }
 
 // ---- ECOS init, primal part: rhs of  min ||x||^2 + ||s||^2  s.t. equalities (W = I) ----
-PHASE_FN void phInitPrimalRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phInitPrimalRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -737,7 +740,7 @@ PHASE_FN void phInitPrimalRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     storePriv(ip_, it);
     WAVE_SYNC();
 }
-PHASE_FN void phInitPrimalFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phInitPrimalFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
@@ -752,7 +755,7 @@ PHASE_FN void phInitPrimalFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     WAVE_SYNC();
 }
 // ---- ECOS init, dual part: H x' + A'y = -c ; z = -L x' ----
-PHASE_FN void phInitDualRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -783,7 +786,7 @@ PHASE_FN void phInitDualRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     storePriv(ip_, it);
     WAVE_SYNC();
 }
-PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phInitDualFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -819,7 +822,7 @@ PHASE_FN void phInitDualFinish(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     WAVE_SYNC();
 }
 // ---- warm start: slacks re-evaluated on the new data and pushed theta into the interior, duals likewise ----
-PHASE_FN void phWarmInit(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phWarmInit(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
@@ -832,7 +835,7 @@ PHASE_FN void phWarmInit(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
     WAVE_SYNC();
 }
 // ---- data norms for the termination test (ECOS-style scaling) ----
-PHASE_FN void phDataNorms(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -937,7 +940,7 @@ __device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc
     stf<N>(sg, G_RXNU * NL + I0, rnu);
     stf<N>(sg, G_RXNUB * NL + I0, rnub);
 }
-PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -1108,7 +1111,7 @@ PHASE_FN void phResiduals(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
 }
 
 // ---- Nesterov-Todd scalings and the per-stage factorisation inputs ----
-PHASE_FN void phScalings(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -1212,7 +1215,7 @@ __device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sig
     stf<N>(sg, G_BTN * NL + I0, btn);
     stf<N>(sg, G_RHO * NL + I0, rho);
 }
-PHASE_FN void phRhs(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
     const Ctx c = uniformCtx(cin);
     const int pass = uniformInt(passIn);
@@ -1374,7 +1377,7 @@ __device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double 
     stf<N>(sg, G_DZ2 * NL + I0, dz2);
     stf<N>(sg, G_DS2 * NL + I0, ds2);
 }
-PHASE_FN void phDirection(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
     const Ctx c = uniformCtx(cin);
     const int pass = uniformInt(passIn);
@@ -1567,7 +1570,7 @@ __device__ inline void axpyFields(const SV &rec, int fDst, int fSrc, double alph
     for (int i = 0; i < N; i++)
         rec[fDst + i] = d[i] + alpha * x[i];
 }
-PHASE_FN void phUpdate(const Ctx &cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews(c);
@@ -1660,10 +1663,16 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.ip = a.ip + size_t(inst) * IP_N;
     const Settings opt = a.opt;
 
-    Glob g;
-    Iter it;
+    // wave-uniform state in LDS: one copy per wavefront, handed to the out-of-line phases by LDS address
+    __shared__ Glob g;
+    __shared__ Iter it;
+    __shared__ Ctx cshared;
     PRIV Glob *gp = (PRIV Glob *)&g;
     PRIV Iter *itp = (PRIV Iter *)&it;
+    const PRIV Ctx *cs = (const PRIV Ctx *)&cshared;
+    if (lane == 0)
+        cshared = c;
+    WAVE_SYNC();
     const double wtrx = a.wtrx[inst];
     it.wtrx = wtrx;
     it.w_t = c.ip[IP_WT];
@@ -1691,31 +1700,31 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     // a warm start that breaks down is repeated from ECOS's cold initialisation (attempt 1)
     for (int attempt = 0; attempt < 2; attempt++)
     {
-    phSetup(c, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
+    phSetup(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
     if (warm)
     {
         // sub-problems of consecutive SC iterations are close: restart from the previous primal-dual point
-        phWarmInit(c, gp, itp);
+        phWarmInit(cs, gp, itp);
     }
     else
     {
         // =============== initialisation (ECOS init, W = I) ===============
-        phInitPrimalRhs(c, gp, itp);
+        phInitPrimalRhs(cs, gp, itp);
         {
             const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-            factorSweepFused(c, sh, sp);
-            bwdSweep(c, sp);
+            factorSweepFused(cs, sh, sp);
+            bwdSweep(cs, sp);
         }
-        phInitPrimalFinish(c, gp, itp);
-        phInitDualRhs(c, gp, itp);
+        phInitPrimalFinish(cs, gp, itp);
+        phInitDualRhs(cs, gp, itp);
         {
             const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-            fwdSweep(c, sp);
-            bwdSweep(c, sp);
+            fwdSweep(cs, sp);
+            bwdSweep(cs, sp);
         }
-        phInitDualFinish(c, gp, itp);
+        phInitDualFinish(cs, gp, itp);
     }
-    phDataNorms(c, gp, itp);
+    phDataNorms(cs, gp, itp);
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
 
@@ -1729,7 +1738,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     for (iter = 0;; iter++)
     {
         PROF_T(tr0);
-        phResiduals(c, gp, itp);
+        phResiduals(cs, gp, itp);
         PROF_T(tr1);
         PROF_ADD(1, tr0, tr1);
         {
@@ -1760,7 +1769,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 break;
             }
         }
-        phScalings(c, gp, itp);
+        phScalings(cs, gp, itp);
         PROF_T(tr2);
         PROF_ADD(2, tr1, tr2);
         if (it.bad)
@@ -1771,7 +1780,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         for (int pass = 0; pass < 2; pass++)
         {
             PROF_T(tq0);
-            phRhs(c, gp, itp, pass);
+            phRhs(cs, gp, itp, pass);
             PROF_T(tq1);
             PROF_ADD(4, tq0, tq1);
             if (pass == 0)
@@ -1779,26 +1788,26 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
                 // column and of the affine right-hand side
                 const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-                factorSweepFused(c, sh, sp);
+                factorSweepFused(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
-                bwdSweep(c, sp);
+                bwdSweep(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             else
             {
                 const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-                fwdSweep(c, sp);
+                fwdSweep(cs, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
-                bwdSweep(c, sp);
+                bwdSweep(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             PROF_T(tq2);
             PROF_ADD(5, tq1, tq2);
-            phDirection(c, gp, itp, pass);
+            phDirection(cs, gp, itp, pass);
             PROF_T(tq3);
             PROF_ADD(6, tq2, tq3);
             if (it.bad)
@@ -1810,7 +1819,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             break;
         }
         PROF_T(tu0);
-        phUpdate(c, gp, itp);
+        phUpdate(cs, gp, itp);
         PROF_T(tu1);
         PROF_ADD(7, tu0, tu1);
     }

@@ -21,25 +21,30 @@ namespace ipm
 #define SWEEP_FN __device__ inline __attribute__((always_inline))
 #endif
 
-// re-establish wave-uniformity of the context inside an out-of-line sweep
-__device__ inline Ctx uniformCtx(const Ctx &cin)
+// the instance context lives in LDS (one copy per wavefront); out-of-line phases / sweeps re-materialise it in SGPRs
+#ifdef SCPP_HIP_EMU
+#define LDSP
+#else
+#define LDSP __attribute__((address_space(3)))
+#endif
+__device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
 {
     Ctx c;
-    c.K = uniformInt(cin.K);
+    c.K = uniformInt(cin->K);
     c.lane = threadIdx.x;
-    c.pitch = uniformInt(cin.pitch);
-    c.st = uniformPtr(cin.st);
-    c.sg = uniformPtr(cin.sg);
-    c.dy = uniformPtr(cin.dy);
-    c.fac = uniformPtr(cin.fac);
-    c.sv = uniformPtr(cin.sv);
-    c.gsave = uniformPtr(cin.gsave);
-    c.A = uniformPtr(cin.A);
-    c.B = uniformPtr(cin.B);
-    c.C = uniformPtr(cin.C);
-    c.S = uniformPtr(cin.S);
-    c.Z = uniformPtr(cin.Z);
-    c.ip = uniformPtr(cin.ip);
+    c.pitch = uniformInt(cin->pitch);
+    c.st = uniformPtr(cin->st);
+    c.sg = uniformPtr(cin->sg);
+    c.dy = uniformPtr(cin->dy);
+    c.fac = uniformPtr(cin->fac);
+    c.sv = uniformPtr(cin->sv);
+    c.gsave = uniformPtr(cin->gsave);
+    c.A = uniformPtr(cin->A);
+    c.B = uniformPtr(cin->B);
+    c.C = uniformPtr(cin->C);
+    c.S = uniformPtr(cin->S);
+    c.Z = uniformPtr(cin->Z);
+    c.ip = uniformPtr(cin->ip);
     return c;
 }
 struct RhsSpec
@@ -313,7 +318,7 @@ __device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int
     return f;
 }
 
-SWEEP_FN void factorSweepFused(const Ctx &cin, TileShared &sh, const RhsSpec &spin)
+SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
@@ -389,7 +394,7 @@ __device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
         f.yt = f.tit = f.ti = f.n = f.rl = f.rwn = tileZero();
     return f;
 }
-SWEEP_FN void fwdSweep(const Ctx &cin, const RhsSpec &spin)
+SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
@@ -471,7 +476,7 @@ __device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
         b.nt = b.tit = b.ti = b.y = b.cs = tileZero();
     return b;
 }
-SWEEP_FN void bwdSweep(const Ctx &cin, const RhsSpec &spin)
+SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
