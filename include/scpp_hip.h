@@ -88,6 +88,18 @@ extern "C"
         int enable_roll_control;
     } scpp_rocketquat_params;
 
+    /* Rocket2d::Parameters after loadFromFile (rocket2d.cpp:150-198): SI units, angles in radians; constrain_initial_final
+       must be on (the SC configuration, model.info:55-56) */
+    typedef struct
+    {
+        double g_I[2], r_T_B[2];
+        double m, J_B;
+        double T_min, T_max;
+        double gimbal_max, theta_max, gamma_gs, w_B_max;
+        double x_final[6];
+        double final_time;
+    } scpp_rocket2d_params;
+
     /* SC.info (SCAlgorithm.cpp:22-46) */
     typedef struct
     {
@@ -138,6 +150,10 @@ extern "C"
     int scpp_hip_set_socp_opts(scpp_hip_ctx *ctx, const scpp_socp_opts *opts);
     int scpp_hip_sc_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_sc_opts *opts,
                           const double *x_init /* [B][14] dimensional */, int B, int warm_start);
+    /* the same for a Rocket2d context (the reference's default active model, scpp_core/include/activeModel.hpp:10): the
+       sub-problem is the same structured solver instantiated for Rocket2d's constraint table (csrc/constraint_table.h) */
+    int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_sc_opts *opts,
+                                   const double *x_init /* [B][6] dimensional */, int B, int warm_start);
     /* restrict the next sc_iterate / sc_solve to a subset (mask[i] != 0); call after sc_setup.  This is the batched
        form of SC_sim's per-closed-loop stop rule (scpp/src/SC_sim.cpp:57-62): finished loops are not solved again */
     int scpp_hip_sc_set_active(scpp_hip_ctx *ctx, const int32_t *mask /* [B] */, int B);

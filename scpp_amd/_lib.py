@@ -36,6 +36,17 @@ class RocketQuatParams(C.Structure):
     ]
 
 
+class Rocket2dParams(C.Structure):
+    """scpp_rocket2d_params (Rocket2d::Parameters after loadFromFile, rocket2d.cpp:150-198)."""
+
+    _fields_ = [
+        ("g_I", C.c_double * 2), ("r_T_B", C.c_double * 2), ("m", C.c_double), ("J_B", C.c_double),
+        ("T_min", C.c_double), ("T_max", C.c_double),
+        ("gimbal_max", C.c_double), ("theta_max", C.c_double), ("gamma_gs", C.c_double), ("w_B_max", C.c_double),
+        ("x_final", C.c_double * 6), ("final_time", C.c_double),
+    ]
+
+
 class SCOpts(C.Structure):
     """scpp_sc_opts (SC.info, SCAlgorithm.cpp:22-46)."""
 
@@ -103,7 +114,7 @@ _lib_path = None
 
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
-    "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup",
+    "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
     "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
@@ -209,9 +220,10 @@ class Context:
         _chk(self.lib.scpp_hip_set_socp_opts(self.h, C.byref(o)), "set_socp_opts")
 
     def sc_setup(self, model_params, sc_opts, x_init, warm_start=False):
-        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         self.B = x_init.shape[0]
-        _chk(self.lib.scpp_hip_sc_setup(self.h, C.byref(model_params), C.byref(sc_opts), _p(x_init), int(self.B), int(warm_start)), "sc_setup")
+        fn = self.lib.scpp_hip_sc_setup if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_sc_setup_rocket2d
+        _chk(fn(self.h, C.byref(model_params), C.byref(sc_opts), _p(x_init), int(self.B), int(warm_start)), "sc_setup")
 
     def sc_set_active(self, mask):
         mask = np.ascontiguousarray(mask, dtype=np.int32).reshape(-1)

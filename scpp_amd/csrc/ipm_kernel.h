@@ -1,103 +1,86 @@
-// Batched structure-exploiting interior-point solver for the RocketQuat SC sub-problem.
-// Replaces, for B problem instances at once, the reference's per-iteration
+// Batched structure-exploiting interior-point solver for the SC / SCvx sub-problem of any model described by a
+// constraint table (constraint_table.h).  Replaces, for B problem instances at once, the reference's per-iteration
 //   solver->solve(false)      scpp_core/src/SCAlgorithm.cpp:78   (Epigraph -> ECOS)
-// on the problem of buildSCProblem (scpp_core/src/SCProblem.cpp:6-138) +
-// RocketQuat::addApplicationConstraints (scpp_models/src/rocketQuat.cpp:70-144), followed by
-// readSolution + the convergence/weight logic of SCAlgorithm::iterate (SCAlgorithm.cpp:100-131).
+// on the problem of buildSCProblem (scpp_core/src/SCProblem.cpp:6-138) + Model::addApplicationConstraints
+// (scpp_models/src/rocketQuat.cpp:70-144, rocket2d.cpp:46-84), followed by readSolution + the convergence/weight logic of
+// SCAlgorithm::iterate (SCAlgorithm.cpp:100-131).
 //
 // Formulation (scalar twin with the derivation: oracle/structured_ipm.hpp):
-//   * presolve: x_0, the fixed final-state components, U[{0,1},K-1], X[13,:] and U[3,:] are constants;
-//     16 stage variables w_k = (x_k[0..12], u_k[0..2]) remain, plus delta_k, nu_k, nu_bound_k, sigma,
-//     delta_sigma, norm1_nu;
+//   * presolve: the variables the table pins (x_0, fixed final-state components, fixed final inputs, states / inputs pinned
+//     for the whole horizon) are constants; <= 16 stage variables w_k = (x_k[XMAP], u_k[UMAP]) remain, plus delta_k, nu_k,
+//     nu_bound_k, sigma, delta_sigma, norm1_nu;
 //   * primal-dual Mehrotra predictor-corrector with Nesterov-Todd scaling (the ECOS scheme), no
 //     self-dual embedding (virtual control makes every sub-problem feasible);
 //   * per IPM iteration ONE factorisation of the reduced KKT system: nu, nu_bound, norm1_nu, delta_k,
 //     delta_sigma eliminated in closed form, then a block-tridiagonal quasi-definite system
 //       [H_k M_k'; M_k -E_k^-1] ... coupled by N_k, with sigma as a one-column border,
-//     factorised stage by stage with dense 16x16 Cholesky tiles held in LDS (FP64 MFMA
-//     v_mfma_f64_16x16x4_f64 for the Z'Z / YY' tile products).
+//     factorised stage by stage with dense 16x16 Cholesky tiles (FP64 MFMA v_mfma_f64_16x16x4_f64 for the tile products).
 //
 // Mapping: ONE 64-lane wavefront (one workgroup) per problem instance. Element-wise phases run with
 // lane == stage/segment index (K <= 64); the factorisation / substitution sweeps are sequential over
 // stages with the 64 lanes cooperating on the 16x16 tiles.  All per-instance state lives in an HBM
-// workspace (layout below, ~0.66 MB per instance for K = 50).
+// workspace (layout below).
 #pragma once
 #include "common.h"
 #include "cone_math.h"
+#include "constraint_table.h"
+#include <type_traits>
+#include <utility>
 
 namespace scpp
 {
 namespace ipm
 {
 
-constexpr int NX = 14, NU = 4, NV = 16, NS = 35, NL = 14, NCONE = 6;
-constexpr int C1 = 0, C2 = 17, C3 = 20, C4 = 23, C5 = 26, C6 = 30, L1 = 33, L2 = 34;
-__device__ inline int coneOff(int c) { return c == 0 ? 0 : c == 1 ? 17 : c == 2 ? 20 : c == 3 ? 23 : c == 4 ? 26 : 30; }
-__device__ inline int coneDim(int c) { return c == 0 ? 17 : c == 4 ? 4 : 3; }
-
-// ---- per-instance parameter block (doubles) ----
-enum InstPar
+// ---- record layout of a model's problem (doubles per stage / segment) ----
+template <class P>
+struct Lay : Derived<P>
 {
-    IP_XINIT = 0,   // [14] nondimensional
-    IP_XFINAL = 14, // [14]
-    IP_GS = 28,
-    IP_TILT,
-    IP_WMAX,
-    IP_TMIN,
-    IP_TMAX,
-    IP_GIM,
-    IP_MDRY,
-    IP_WT = 35,
-    IP_WTRT,
-    IP_WTRX,
-    IP_WVC,
-    IP_PAR = 39, // [10] flow-map parameters
-    IP_MSCALE = 49,
-    IP_RSCALE,
-    IP_FINALTIME,
-    // SCvx mode (SCvxProblem.cpp:6-71) inside the same structure -- see oracle/structured_ipm.hpp (RQSocpInput::scvx):
-    // delta_k is the constant trust_region, the state rows of the trust cone are zero padding, S = 0 decouples sigma
-    IP_SCVX = 52,
-    IP_TR = 53,
-    IP_N = 56
+    using D = Derived<P>;
+    static constexpr int NX = P::NX, NU = P::NU, NXV = P::NXV, NUV = P::NUV, NS = D::NS, NL = D::NL, HS_N = D::HS_N;
+    // ---- stage record ----
+    static constexpr int F_W = 0;                 // [16] stage variables
+    static constexpr int F_DL = F_W + NV;         // delta_k
+    static constexpr int F_DW = F_DL + 1;         // [16]
+    static constexpr int F_DDL = F_DW + NV;
+    static constexpr int F_WBAR = F_DDL + 1;      // [16] trust-region centre
+    static constexpr int F_UHAT = F_WBAR + NV;    // [3]
+    static constexpr int F_HDD = F_UHAT + 3;
+    static constexpr int F_HDW = F_HDD + 1;       // [16]
+    static constexpr int F_RXW = F_HDW + NV;      // [16]
+    static constexpr int F_RXD = F_RXW + NV;
+    static constexpr int F_BETA = F_RXD + 1;      // [16]
+    static constexpr int F_BCW = F_BETA + NV;     // [16] border column (w part)
+    static constexpr int F_VW = F_BCW + NV;       // [16] block-solve output
+    static constexpr int F_S = F_VW + NV;         // [NS]
+    static constexpr int F_Z = F_S + NS;
+    static constexpr int F_DS = F_Z + NS;
+    static constexpr int F_DZ = F_DS + NS;
+    static constexpr int F_RZ = F_DZ + NS;
+    static constexpr int F_TZ = F_RZ + NS;
+    static constexpr int F_LS = F_TZ + NS;        // lambda (scaled)
+    static constexpr int F_DSS = F_LS + NS;       // W^-1 ds
+    static constexpr int F_DZS = F_DSS + NS;      // W dz
+    static constexpr int F_ETA = F_DZS + NS;      // [NCONES]
+    static constexpr int F_WB = F_ETA + D::NCONES; // [LP0] wbar of the cones, same offsets as the slack layout
+    static constexpr int F_BXW = F_WB + D::LP0;   // [16] right-hand side (w part)
+    static constexpr int F_BXD = F_BXW + NV;
+    static constexpr int F_HS = F_BXD + 1;        // [HS_N] small Hessian blocks of the application cones / LP rows
+    static constexpr int F_HC = F_HS + HS_N;      // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
+    static constexpr int F_WBK = F_HC + 2;        // [17] W and delta of the last iterate that met the reduced tolerances
+    static constexpr int STREC = F_WBK + NV + 1;
+    // ---- segment record: G_NFIELDS fields of NL doubles (enum SegField) ----
+    // ---- per-stage factor record, PACKED (the kernel is HBM-throughput bound): Li lower triangle (136), Yt 16 x NL,
+    //      Ti lower triangle of the NL x NL block.  Z = Ti N is not stored: N = [I | -C] makes it 4 extra matrix-core
+    //      instructions from Ti and the entries of C.
+    static constexpr int FAC_LI = 0, FAC_YT = NV * (NV + 1) / 2, FAC_TI = FAC_YT + NV * NL;
+    static constexpr int FACREC = (FAC_TI + NL * (NL + 1) / 2 + 7) & ~7;
+    // field-major copy of the segment dynamics (A, B, C, s, z) for the lane = segment phases
+    // the lane = segment phases walk the NL rows of a segment in three register-sized chunks
+    static constexpr int SC1 = (NL + 2) / 3, SC2 = (NL - SC1 + 1) / 2, SC3 = NL - SC1 - SC2;
+    static constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX;
 };
-
-// ---- stage record (doubles) ----
-enum StageField
-{
-    F_W = 0,      // [16] stage variables
-    F_DL = 16,    // delta_k
-    F_DW = 17,    // [16]
-    F_DDL = 33,
-    F_WBAR = 34,  // [16] trust-region centre
-    F_UHAT = 50,  // [3]
-    F_HDD = 53,
-    F_HDW = 54,   // [16]
-    F_RXW = 70,   // [16]
-    F_RXD = 86,
-    F_BETA = 87,  // [16]
-    F_BCW = 103,  // [16] border column (w part)
-    F_VW = 119,   // [16] block-solve output
-    F_AV = 135,   // [16] forward-sweep intermediate
-    F_S = 151,    // [35]
-    F_Z = 186,
-    F_DS = 221,
-    F_DZ = 256,
-    F_RZ = 291,
-    F_TZ = 326,
-    F_LS = 361,   // lambda (scaled)
-    F_DSS = 396,  // W^-1 ds
-    F_DZS = 431,  // W dz
-    F_ETA = 466,  // [6]
-    F_WB = 472,   // [33] wbar of the 6 cones, same offsets as the slack layout
-    F_BXW = 505,  // [16] right-hand side (w part)
-    F_BXD = 521,
-    F_HS = 522,   // [27] small Hessian blocks of the non-trust-region cones
-    F_HC = 549,   // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
-    F_WBK = 552,  // [17] W and delta of the last iterate that met the reduced tolerances (ECOS-style best iterate)
-    STREC = 569
-};
-// ---- segment record: 33 fields of 14 doubles ----
+// ---- segment record fields (each NL doubles) ----
 enum SegField
 {
     G_NU = 0,
@@ -135,26 +118,21 @@ enum SegField
     G_BY,
     G_NFIELDS
 };
-constexpr int SEGREC = G_NFIELDS * NL; // 462
-// per-stage factor record, PACKED (the kernel is HBM-throughput bound): Li lower triangle (136), Yt 16x14 (224),
-// Ti lower triangle of the 14x14 block (105).  Z = Ti N is not stored: N = [I | -C] makes it 4 extra matrix-core
-// instructions from Ti and the 42 entries of C.
-constexpr int FAC_LI = 0, FAC_YT = 136, FAC_TI = 360, FACREC = 472;
 constexpr int NRHS_MAX = 3;            // right-hand-side columns carried by one sweep
 constexpr int SVREC = 2 * NRHS_MAX * 16; // saved forward intermediates (a, c) per stage
 
-// Stage / segment records are stored FIELD-major: element f of stage k lives at st[f*64 + k], so that the
-// lane == stage phases read and write fully coalesced 512-byte rows (one lane per stage).
+// Stage / segment records are stored FIELD-major: element f of stage k lives at st[f*pitch + k], so that the
+// lane == stage phases read and write fully coalesced rows (one lane per stage).
 constexpr int LANES = 64;
 // row pitch (doubles) of the field-major records: one row = one field of all K stages.  K rounded up to even
 // instead of 64 keeps rows 16-byte aligned and cuts the record traffic by 1 - K/64 (22 % at K = 50).
 __host__ __device__ inline int recPitch(int K) { return (K + 1) & ~1; }
-// field-major copy of the segment dynamics (A 14x14, B 14x4, C 14x4, s, z) for the lane = segment phases
-constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX; // 336
 constexpr int GSAVE = 16; // wave-uniform scalars of the last solve (sigma, delta_sigma, n1 and their slacks / duals): warm start
+template <class P>
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
-    return size_t(recPitch(K)) * (STREC + SEGREC + DYNREC) + size_t(K) * (FACREC + SVREC) + GSAVE;
+    using L = Lay<P>;
+    return size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE;
 }
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is
@@ -210,9 +188,9 @@ struct Ctx
 {
     int K, lane;
     int pitch;   // row pitch of the field-major records (doubles)
-    double *st;  // [STREC][64]   field-major
-    double *sg;  // [SEGREC][64]  field-major
-    double *dy;  // [DYNREC][64]  field-major copy of A,B,C,s,z
+    double *st;  // [STREC][pitch]   field-major
+    double *sg;  // [SEGREC][pitch]  field-major
+    double *dy;  // [DYNREC][pitch]  field-major copy of A,B,C,s,z
     double *fac; // [K][FACREC]
     double *sv;  // [K][SVREC]
     double *gsave; // [GSAVE]
@@ -220,241 +198,279 @@ struct Ctx
     const double *ip;                // instance parameters
 };
 
-__device__ inline unsigned fixedMask(int k, int K)
+// ---------------- the table, evaluated ----------------
+// Every index into the table is a template constant (sfor hands the loop counter over as an integral_constant), so that the
+// front end folds the table away completely: what reaches the optimiser is the same straight-line code a hand-written
+// saff / Lmul / LTmul for the model would be.  (Plain unrolled loops over the constexpr arrays left the folding to late
+// optimisation passes, after the per-lane slack arrays had already been demoted to scratch memory.)
+template <class F, int... Is>
+__device__ inline void sforImpl(F &&f, std::integer_sequence<int, Is...>)
 {
-    if (k == 0)
-        return 0x1FFFu;
-    if (k == K - 1)
-        return (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 11) |
-               (1u << 12) | (1u << 13) | (1u << 14);
-    return 0u;
+    (f(std::integral_constant<int, Is>{}), ...);
 }
-// bits 0..5 cones C1..C6, bit 6 mass LP, bit 7 min-thrust LP
-__device__ inline unsigned activeMask(int k, int K)
+template <int N, class F>
+__device__ inline void sfor(F &&f)
 {
-    if (k == 0)
-        return 0xFFu & ~((1u << 1) | (1u << 2) | (1u << 3) | (1u << 6));
-    if (k == K - 1)
-        return 0xFFu & ~((1u << 1) | (1u << 2) | (1u << 3));
-    return 0xFFu;
+    sforImpl(f, std::make_integer_sequence<int, N>{});
+}
+#define SFOR_IDX(name, tag) constexpr int name = decltype(tag)::value
+
+// coefficient of a term at this node
+template <int COEF, class AU>
+__device__ inline double termCoefC(const double *ip, AU uh)
+{
+    if constexpr (COEF == CF_ONE)
+        return 1.;
+    else if constexpr (COEF == CF_UHAT0)
+        return uh[0];
+    else if constexpr (COEF == CF_UHAT1)
+        return uh[1];
+    else if constexpr (COEF == CF_UHAT2)
+        return uh[2];
+    else
+        return ip[COEF];
+}
+// row(w) = sum_t mul_t coef_t w[var_t]   (+ hmul * ip[hpar] if WITH_CONST), summed in table order, constant last
+template <class P, int C, int I, bool WITH_CONST, class AW, class AU>
+__device__ inline double rowValue(const double *ip, AW w, AU uh)
+{
+    // C >= 0: row I of application cone C ; C == -1: LP row I
+    constexpr Row r = C >= 0 ? P::CONES[C >= 0 ? C : 0].r[I < MAXDIM ? I : 0] : P::LPS[I < P::NLP ? I : 0];
+    double s = 0.;
+    if constexpr (r.t[0].var >= 0)
+    {
+        constexpr Term t0 = r.t[0];
+        s = (t0.coef == CF_ONE && t0.mul == 1.) ? double(w[t0.var]) : (t0.mul == 1. ? termCoefC<t0.coef>(ip, uh) * w[t0.var] : t0.mul * termCoefC<t0.coef>(ip, uh) * w[t0.var]);
+        if constexpr (r.t[1].var >= 0)
+        {
+            constexpr Term t1 = r.t[1];
+            s += (t1.coef == CF_ONE && t1.mul == 1.) ? double(w[t1.var]) : (t1.mul == 1. ? termCoefC<t1.coef>(ip, uh) * w[t1.var] : t1.mul * termCoefC<t1.coef>(ip, uh) * w[t1.var]);
+        }
+        if constexpr (r.t[2].var >= 0)
+        {
+            constexpr Term t2 = r.t[2];
+            s += (t2.coef == CF_ONE && t2.mul == 1.) ? double(w[t2.var]) : (t2.mul == 1. ? termCoefC<t2.coef>(ip, uh) * w[t2.var] : t2.mul * termCoefC<t2.coef>(ip, uh) * w[t2.var]);
+        }
+    }
+    if constexpr (WITH_CONST && r.hpar >= 0)
+    {
+        const double h = r.hmul == 1. ? ip[r.hpar] : (r.hmul == -1. ? -ip[r.hpar] : r.hmul * ip[r.hpar]);
+        if constexpr (r.t[0].var >= 0)
+            s += h;
+        else
+            s = h;
+    }
+    return s;
 }
 
-template <class AV>
+template <class P, class AV>
 __device__ inline void maskInactive(unsigned act, AV v)
 {
-    for (int c = 0; c < NCONE; c++)
-        if (!(act & (1u << c)))
-            for (int i = 0; i < coneDim(c); i++)
-                v[coneOff(c) + i] = 0.;
-    if (!(act & 64u))
-        v[L1] = 0.;
-    if (!(act & 128u))
-        v[L2] = 0.;
+    using D = Derived<P>;
+    sfor<P::NCONE>([&](auto ct) {
+        SFOR_IDX(C, ct);
+        constexpr int OFF = D::coneOff(C + 1), DIM = P::CONES[C].dim;
+        if (!(act & (1u << (C + 1)))) // (the trust-region cone, bit 0, is active at every node)
+            sfor<DIM>([&](auto it) { v[OFF + decltype(it)::value] = 0.; });
+    });
+    sfor<P::NLP>([&](auto lt) {
+        SFOR_IDX(Lr, lt);
+        if (!(act & (1u << (D::NCONES + Lr))))
+            v[D::LP0 + Lr] = 0.;
+    });
 }
 // affine slack h - Gx of one stage
-template <class AW, class AB, class AU, class AO>
+template <class P, class AW, class AB, class AU, class AO>
 __device__ inline void saff(const double *ip, unsigned act, AW wk, double dlk, AB wb, AU uh, AO out)
 {
+    using D = Derived<P>;
     const bool scvx = ip[IP_SCVX] != 0.;
     out[0] = scvx ? ip[IP_TR] : dlk;
-    for (int j = 0; j < NV; j++)
-        out[1 + j] = (scvx && j < 13) ? 0. : wb[j] - wk[j];
-    out[17] = ip[IP_GS] * wk[3];
-    out[18] = wk[1];
-    out[19] = wk[2];
-    out[20] = ip[IP_TILT];
-    out[21] = wk[8];
-    out[22] = wk[9];
-    out[23] = ip[IP_WMAX];
-    out[24] = wk[11];
-    out[25] = wk[12];
-    out[26] = ip[IP_TMAX];
-    out[27] = wk[13];
-    out[28] = wk[14];
-    out[29] = wk[15];
-    out[30] = ip[IP_GIM] * wk[15];
-    out[31] = wk[13];
-    out[32] = wk[14];
-    out[33] = wk[0] - ip[IP_MDRY];
-    out[34] = uh[0] * wk[13] + uh[1] * wk[14] + uh[2] * wk[15] - ip[IP_TMIN];
-    maskInactive(act, out);
+    sfor<NV>([&](auto jt) {
+        SFOR_IDX(j, jt);
+        if constexpr (j >= D::NVU)
+            out[1 + j] = 0.;
+        else if constexpr (j < P::NXV)
+            out[1 + j] = scvx ? 0. : wb[j] - wk[j];
+        else
+            out[1 + j] = wb[j] - wk[j];
+    });
+    sfor<P::NCONE>([&](auto ct) {
+        SFOR_IDX(C, ct);
+        constexpr int OFF = D::coneOff(C + 1);
+        sfor<P::CONES[C].dim>([&](auto it) {
+            SFOR_IDX(I, it);
+            out[OFF + I] = rowValue<P, C, I, true>(ip, wk, uh);
+        });
+    });
+    sfor<P::NLP>([&](auto lt) {
+        SFOR_IDX(Lr, lt);
+        out[D::LP0 + Lr] = rowValue<P, -1, Lr, true>(ip, wk, uh);
+    });
+    maskInactive<P>(act, out);
 }
 // linear part of saff
-template <class AW, class AU, class AO>
+template <class P, class AW, class AU, class AO>
 __device__ inline void Lmul(const double *ip, unsigned act, AW dwk, double ddlk, AU uh, AO out)
 {
+    using D = Derived<P>;
     const bool scvx = ip[IP_SCVX] != 0.;
     out[0] = scvx ? 0. : ddlk;
-    for (int j = 0; j < NV; j++)
-        out[1 + j] = (scvx && j < 13) ? 0. : -dwk[j];
-    out[17] = ip[IP_GS] * dwk[3];
-    out[18] = dwk[1];
-    out[19] = dwk[2];
-    out[20] = 0.;
-    out[21] = dwk[8];
-    out[22] = dwk[9];
-    out[23] = 0.;
-    out[24] = dwk[11];
-    out[25] = dwk[12];
-    out[26] = 0.;
-    out[27] = dwk[13];
-    out[28] = dwk[14];
-    out[29] = dwk[15];
-    out[30] = ip[IP_GIM] * dwk[15];
-    out[31] = dwk[13];
-    out[32] = dwk[14];
-    out[33] = dwk[0];
-    out[34] = uh[0] * dwk[13] + uh[1] * dwk[14] + uh[2] * dwk[15];
-    maskInactive(act, out);
+    sfor<NV>([&](auto jt) {
+        SFOR_IDX(j, jt);
+        if constexpr (j >= D::NVU)
+            out[1 + j] = 0.;
+        else if constexpr (j < P::NXV)
+            out[1 + j] = scvx ? 0. : -dwk[j];
+        else
+            out[1 + j] = -dwk[j];
+    });
+    sfor<P::NCONE>([&](auto ct) {
+        SFOR_IDX(C, ct);
+        constexpr int OFF = D::coneOff(C + 1);
+        sfor<P::CONES[C].dim>([&](auto it) {
+            SFOR_IDX(I, it);
+            out[OFF + I] = rowValue<P, C, I, false>(ip, dwk, uh);
+        });
+    });
+    sfor<P::NLP>([&](auto lt) {
+        SFOR_IDX(Lr, lt);
+        out[D::LP0 + Lr] = rowValue<P, -1, Lr, false>(ip, dwk, uh);
+    });
+    maskInactive<P>(act, out);
 }
-// L' v (entries of inactive cones must be zero)
-template <class AV, class AU>
-__device__ inline void LTmul(const double *ip, unsigned fm, AV v, AU uh, double *gw, double *gdl)
+// contribution of term T of row (C, I) to (L'v)[J]: accumulates into add in table order
+template <class P, int J, int C, int I, int T, class AV, class AU>
+__device__ inline void ltTerm(const double *ip, AV v, AU uh, double &add, bool &any)
 {
-    const bool scvx = ip[IP_SCVX] != 0.;
-    *gdl = v[0];
-    for (int j = 0; j < NV; j++)
-        gw[j] = (scvx && j < 13) ? 0. : -v[1 + j];
-    gw[3] += ip[IP_GS] * v[17];
-    gw[1] += v[18];
-    gw[2] += v[19];
-    gw[8] += v[21];
-    gw[9] += v[22];
-    gw[11] += v[24];
-    gw[12] += v[25];
-    gw[13] += v[27] + v[31] + uh[0] * v[34];
-    gw[14] += v[28] + v[32] + uh[1] * v[34];
-    gw[15] += v[29] + ip[IP_GIM] * v[30] + uh[2] * v[34];
-    gw[0] += v[33];
-    for (int j = 0; j < NV; j++)
-        if (fm & (1u << j))
-            gw[j] = 0.;
-}
-
-template <class AW>
-__device__ inline double stageX(AW wk, int j) { return j < 13 ? wk[j] : 0.; }
-
-// dynamics residual of segment k: x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu_k - Z_k
-template <class A0, class A1, class AN>
-__device__ inline void dynRes(const Ctx &c, int k, A0 w0, A1 w1, AN nuv, double sig, double *out)
-{
-    const double *A = c.A + size_t(k) * NX * NX, *B = c.B + size_t(k) * NX * NU, *C = c.C + size_t(k) * NX * NU;
-    for (int i = 0; i < NX; i++)
+    using D = Derived<P>;
+    constexpr Row r = C >= 0 ? P::CONES[C >= 0 ? C : 0].r[I < MAXDIM ? I : 0] : P::LPS[I < P::NLP ? I : 0];
+    constexpr Term tm = r.t[T];
+    if constexpr (tm.var == J)
     {
-        double acc = stageX(w1, i) - c.S[k * NX + i] * sig - nuv[i] - c.Z[k * NX + i];
-        for (int j = 0; j < 13; j++)
-            acc -= A[i * NX + j] * w0[j];
-        for (int j = 0; j < 3; j++)
-            acc -= B[i * NU + j] * w0[13 + j] + C[i * NU + j] * w1[13 + j];
-        out[i] = acc;
+        constexpr int SL = C >= 0 ? D::coneOff((C >= 0 ? C : 0) + 1) + I : D::LP0 + I;
+        const double vi = v[SL];
+        const double x = (tm.coef == CF_ONE && tm.mul == 1.) ? vi : (tm.mul == 1. ? termCoefC<tm.coef>(ip, uh) * vi : tm.mul * termCoefC<tm.coef>(ip, uh) * vi);
+        add = any ? add + x : x;
+        any = true;
     }
 }
-// same on the field-major copy (coalesced, fully unrolled: all loads of a row are in flight together)
-template <class A0, class A1, class AN>
+// L' v (entries of inactive cones must be zero)
+template <class P, class AV, class AU>
+__device__ inline void LTmul(const double *ip, unsigned fm, AV v, AU uh, double *gw, double *gdl)
+{
+    using D = Derived<P>;
+    const bool scvx = ip[IP_SCVX] != 0.;
+    *gdl = v[0];
+    sfor<NV>([&](auto jt) {
+        SFOR_IDX(J, jt);
+        double add = 0.;
+        bool any = false;
+        sfor<P::NCONE>([&](auto ct) {
+            SFOR_IDX(C, ct);
+            sfor<P::CONES[C].dim>([&](auto it) {
+                SFOR_IDX(I, it);
+                ltTerm<P, J, C, I, 0>(ip, v, uh, add, any);
+                ltTerm<P, J, C, I, 1>(ip, v, uh, add, any);
+                ltTerm<P, J, C, I, 2>(ip, v, uh, add, any);
+            });
+        });
+        sfor<P::NLP>([&](auto lt) {
+            SFOR_IDX(Lr, lt);
+            ltTerm<P, J, -1, Lr, 0>(ip, v, uh, add, any);
+            ltTerm<P, J, -1, Lr, 1>(ip, v, uh, add, any);
+            ltTerm<P, J, -1, Lr, 2>(ip, v, uh, add, any);
+        });
+        double g;
+        if constexpr (J >= D::NVU)
+            g = 0.;
+        else if constexpr (J < P::NXV)
+            g = scvx ? 0. : -v[1 + J];
+        else
+            g = -v[1 + J];
+        if (any)
+            g += add;
+        gw[J] = (fm & (1u << J)) ? 0. : g;
+    });
+}
+
+// dynamics residual of segment k on the field-major copy (coalesced, fully unrolled: all loads of a row are in flight
+// together):  x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu_k - Z_k     (pinned states / inputs are 0)
+template <class P, class A0, class A1, class AN>
 __device__ inline void dynResF(const SV &dy, A0 w0, A1 w1, AN nuv, double sig, double *out)
 {
-    double x0[NV], u1[3];
+    using L = Lay<P>;
+    double x0[NV], u1[P::NUV];
 #pragma unroll
     for (int j = 0; j < NV; j++)
         x0[j] = w0[j];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
-        u1[j] = w1[13 + j];
-#pragma unroll
-    for (int i = 0; i < NX; i++)
-    {
-        double acc = stageX(w1, i) - dy[DY_S + i] * sig - nuv[i] - dy[DY_Z + i];
-#pragma unroll
-        for (int j = 0; j < 13; j++)
-            acc -= dy[DY_A + i * NX + j] * x0[j];
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            acc -= dy[DY_B + i * NU + j] * x0[13 + j] + dy[DY_C + i * NU + j] * u1[j];
+    for (int j = 0; j < P::NUV; j++)
+        u1[j] = w1[P::NXV + j];
+    sfor<P::NX>([&](auto rowt) {
+        SFOR_IDX(i, rowt);
+        constexpr int xi = L::XINV.v[i];
+        double acc = (xi >= 0 ? double(w1[xi >= 0 ? xi : 0]) : 0.) - dy[L::DY_S + i] * sig - nuv[i] - dy[L::DY_Z + i];
+        sfor<P::NXV>([&](auto jt) {
+            SFOR_IDX(j, jt);
+            acc -= dy[L::DY_A + i * P::NX + P::XMAP[j]] * x0[j];
+        });
+        sfor<P::NUV>([&](auto jt) {
+            SFOR_IDX(j, jt);
+            acc -= dy[L::DY_B + i * P::NU + P::UMAP[j]] * x0[P::NXV + j] + dy[L::DY_C + i * P::NU + P::UMAP[j]] * u1[j];
+        });
         out[i] = acc;
-    }
-}
-// entries of M_k = -[A|B] and N_k = [I|-C] in stage coordinates (fixed columns zeroed)
-__device__ inline double Ment(const Ctx &c, int k, unsigned fm, int i, int j)
-{
-    if (fm & (1u << j))
-        return 0.;
-    return j < 13 ? -c.A[size_t(k) * NX * NX + i * NX + j] : -c.B[size_t(k) * NX * NU + i * NU + (j - 13)];
-}
-__device__ inline double Nent(const Ctx &c, int k, unsigned fmNext, int i, int j)
-{
-    if (fmNext & (1u << j))
-        return 0.;
-    return j < 13 ? (i == j ? 1. : 0.) : -c.C[size_t(k) * NX * NU + i * NU + (j - 13)];
-}
-
-// H += sum_ab c_a c_b W^-2_ab e_va e_vb'
-template <class AW>
-__device__ inline void addConeH(double *H, double eta, AW w, int d, const int *vars, const double *coef)
-{
-    const double e2 = 1. / (eta * eta);
-    for (int a = 0; a < d; a++)
-    {
-        if (vars[a] < 0)
-            continue;
-        const double va = (a == 0) ? w[0] : -w[a];
-        for (int b = 0; b < d; b++)
-        {
-            if (vars[b] < 0)
-                continue;
-            const double vb = (b == 0) ? w[0] : -w[b];
-            double Wab = 2. * va * vb;
-            if (a == b)
-                Wab += (a == 0) ? -1. : 1.;
-            H[vars[a] * NV + vars[b]] += coef[a] * coef[b] * Wab * e2;
-        }
-    }
+    });
 }
 
 // Per-stage Hessian data (delta_k eliminated) for the in-sweep tile build: F_HDD, F_HDW (delta elimination),
-// F_HC = {1/eta1^2, 2/den} of the trust-region cone and F_HS = the small dense blocks contributed by the other
-// cones / LP rows (layout: hsIndex in tile_engine.h).
-__device__ inline int hsIndexK(int a, int b)
+// F_HC = {1/eta1^2, 2/den} of the trust-region cone and F_HS = the small dense blocks contributed by the application
+// cones / LP rows (layout: Derived<P>::PAT).
+template <class P>
+__device__ inline int hsIndex(int a, int b)
 {
-    if (a >= 1 && a <= 3 && b >= 1 && b <= 3)
-        return (a - 1) * 3 + (b - 1);
-    if (a >= 8 && a <= 9 && b >= 8 && b <= 9)
-        return 9 + (a - 8) * 2 + (b - 8);
-    if (a >= 11 && a <= 12 && b >= 11 && b <= 12)
-        return 13 + (a - 11) * 2 + (b - 11);
-    if (a >= 13 && b >= 13)
-        return 17 + (a - 13) * 3 + (b - 13);
-    if (a == 0 && b == 0)
-        return 26;
-    return -1;
+    return Derived<P>::PAT.idx[a][b];
 }
-template <class AW>
-__device__ inline void addConeHs(double *Hs, double eta, AW w, int d, const int *vars, const double *coef)
+// Hs += sum_ab c_a c_b W^-2_ab e_va e_vb'   (rows of a cone are single terms or constants)
+template <class P, int C, class AW>
+__device__ inline void addConeHs(const double *ip, double *Hs, double eta, AW w)
 {
+    using D = Derived<P>;
+    constexpr int d = P::CONES[C].dim;
     const double e2 = 1. / (eta * eta);
-    for (int a = 0; a < d; a++)
-    {
-        if (vars[a] < 0)
-            continue;
-        const double va = (a == 0) ? w[0] : -w[a];
-        for (int b = 0; b < d; b++)
+    sfor<d>([&](auto at) {
+        SFOR_IDX(a, at);
+        constexpr Term ta = P::CONES[C].r[a].t[0];
+        if constexpr (ta.var >= 0)
         {
-            if (vars[b] < 0)
-                continue;
-            const double vb = (b == 0) ? w[0] : -w[b];
-            double Wab = 2. * va * vb;
-            if (a == b)
-                Wab += (a == 0) ? -1. : 1.;
-            Hs[hsIndexK(vars[a], vars[b])] += coef[a] * coef[b] * Wab * e2;
+            const double va = (a == 0) ? double(w[0]) : -double(w[a]);
+            const double ca = ta.coef == CF_ONE ? ta.mul : ta.mul * ip[ta.coef >= 0 ? ta.coef : 0];
+            sfor<d>([&](auto bt) {
+                SFOR_IDX(b, bt);
+                constexpr Term tb = P::CONES[C].r[b].t[0];
+                if constexpr (tb.var >= 0)
+                {
+                    const double vb = (b == 0) ? double(w[0]) : -double(w[b]);
+                    const double cb = tb.coef == CF_ONE ? tb.mul : tb.mul * ip[tb.coef >= 0 ? tb.coef : 0];
+                    double Wab = 2. * va * vb;
+                    if constexpr (a == b)
+                        Wab += (a == 0) ? -1. : 1.;
+                    constexpr int idx = D::PAT.idx[ta.var][tb.var];
+                    Hs[idx] += ca * cb * Wab * e2;
+                }
+            });
         }
-    }
+    });
 }
+template <class P>
 __device__ inline void buildHs(const Ctx &c, int k, bool identity)
 {
-    const unsigned fm = fixedMask(k, c.K), act = activeMask(k, c.K);
-    const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
-    const SV eta = st + F_ETA, wb = st + F_WB, uh = st + F_UHAT;
-    double Hs[27];
-    for (int i = 0; i < 27; i++)
+    using L = Lay<P>;
+    const unsigned fm = L::fixedMask(k, c.K), act = L::activeMask(k, c.K);
+    const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+    const SV eta = st + L::F_ETA, wb = st + L::F_WB, uh = st + L::F_UHAT;
+    double Hs[L::HS_N > 0 ? L::HS_N : 1];
+    for (int i = 0; i < L::HS_N; i++)
         Hs[i] = 0.;
     {
         const bool scvx = c.ip[IP_SCVX] != 0.;
@@ -462,53 +478,46 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         const double den = 2. * wb[0] * wb[0] - 1.;
         // SC: delta_k eliminated -> H = e2 (I - (2/den) w w').  SCvx: delta_k constant -> plain L'W^-2 L = e2 (I + 2 w w')
         // on the rows that exist (the mask is applied where the tile is built, sweeps.h buildHTile)
-        st[F_HDD] = scvx ? 1. : den * e2;
+        st[L::F_HDD] = scvx ? 1. : den * e2;
         for (int j = 0; j < NV; j++)
-            st[F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
-        st[F_HC] = e2;
-        st[F_HC + 1] = scvx ? -2. : 2. / den;
+            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
+        st[L::F_HC] = e2;
+        st[L::F_HC + 1] = scvx ? -2. : 2. / den;
     }
-    if (act & 2u)
-    {
-        const int v[3] = {3, 1, 2};
-        const double cf[3] = {c.ip[IP_GS], 1., 1.};
-        addConeHs(Hs, eta[1], wb + C2, 3, v, cf);
-    }
-    if (act & 4u)
-    {
-        const int v[3] = {-1, 8, 9};
-        const double cf[3] = {0., 1., 1.};
-        addConeHs(Hs, eta[2], wb + C3, 3, v, cf);
-    }
-    if (act & 8u)
-    {
-        const int v[3] = {-1, 11, 12};
-        const double cf[3] = {0., 1., 1.};
-        addConeHs(Hs, eta[3], wb + C4, 3, v, cf);
-    }
-    if (act & 16u)
-    {
-        const int v[4] = {-1, 13, 14, 15};
-        const double cf[4] = {0., 1., 1., 1.};
-        addConeHs(Hs, eta[4], wb + C5, 4, v, cf);
-    }
-    if (act & 32u)
-    {
-        const int v[3] = {15, 13, 14};
-        const double cf[3] = {c.ip[IP_GIM], 1., 1.};
-        addConeHs(Hs, eta[5], wb + C6, 3, v, cf);
-    }
-    if (act & 64u)
-        Hs[26] += identity ? 1. : st[F_Z + L1] / st[F_S + L1];
-    if (act & 128u)
-    {
-        const double d = identity ? 1. : st[F_Z + L2] / st[F_S + L2];
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++)
-                Hs[17 + a * 3 + b] += d * uh[a] * uh[b];
-    }
-    for (int i = 0; i < 27; i++)
-        st[F_HS + i] = Hs[i];
+    sfor<P::NCONE>([&](auto ct) {
+        SFOR_IDX(C, ct);
+        constexpr int OFF = L::coneOff(C + 1);
+        if (act & (1u << (C + 1)))
+            addConeHs<P, C>(c.ip, Hs, eta[C + 1], wb + OFF);
+    });
+    sfor<P::NLP>([&](auto lt) {
+        SFOR_IDX(Lr, lt);
+        if (act & (1u << (L::NCONES + Lr)))
+        {
+            const double d = identity ? 1. : st[L::F_Z + L::LP0 + Lr] / st[L::F_S + L::LP0 + Lr];
+            sfor<3>([&](auto at) {
+                SFOR_IDX(ta, at);
+                constexpr Term a = P::LPS[Lr].t[ta];
+                if constexpr (a.var >= 0)
+                    sfor<3>([&](auto bt) {
+                        SFOR_IDX(tb, bt);
+                        constexpr Term b = P::LPS[Lr].t[tb];
+                        if constexpr (b.var >= 0)
+                        {
+                            constexpr int idx = L::PAT.idx[a.var][b.var];
+                            constexpr bool unit = a.coef == CF_ONE && b.coef == CF_ONE && a.mul * b.mul == 1.;
+                            if constexpr (unit)
+                                Hs[idx] += d;
+                            else
+                                Hs[idx] += d * (a.mul == 1. ? termCoefC<a.coef>(c.ip, uh) : a.mul * termCoefC<a.coef>(c.ip, uh)) *
+                                           (b.mul == 1. ? termCoefC<b.coef>(c.ip, uh) : b.mul * termCoefC<b.coef>(c.ip, uh));
+                        }
+                    });
+            });
+        }
+    });
+    for (int i = 0; i < L::HS_N; i++)
+        st[L::F_HS + i] = Hs[i];
 }
 
 } // namespace ipm

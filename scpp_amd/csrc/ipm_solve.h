@@ -4,6 +4,7 @@
 #pragma once
 #include "ipm_kernel.h"
 #include "sweeps.h"
+#include <type_traits>
 
 namespace scpp
 {
@@ -52,29 +53,31 @@ struct Rhs
 __device__ inline double dLP(bool identity, double sv, double zv) { return identity ? 1. : zv / sv; }
 
 // per-lane preparation of the factorisation: segment scalars, stage Hessian, sigma block
+template <class P>
 __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
             if (identity)
             {
-                sg[G_EINV * NL + i] = 0.5;
-                sg[G_QV * NL + i] = 0.;
+                sg[G_EINV * L::NL + i] = 0.5;
+                sg[G_QV * L::NL + i] = 0.;
             }
             else
             {
-                const double r1 = sg[G_S1 * NL + i] / sg[G_Z1 * NL + i], r2 = sg[G_S2 * NL + i] / sg[G_Z2 * NL + i];
-                sg[G_EINV * NL + i] = 0.25 * (r1 + r2);
-                sg[G_QV * NL + i] = (r1 - r2) / (r1 + r2);
+                const double r1 = sg[G_S1 * L::NL + i] / sg[G_Z1 * L::NL + i], r2 = sg[G_S2 * L::NL + i] / sg[G_Z2 * L::NL + i];
+                sg[G_EINV * L::NL + i] = 0.25 * (r1 + r2);
+                sg[G_QV * L::NL + i] = (r1 - r2) / (r1 + r2);
             }
         }
     }
     if (k < K)
-        buildHs(c, k, identity);
+        buildHs<P>(c, k, identity);
     {
         const double e2 = 1. / (g.seta * g.seta);
         const double vt[3] = {g.sw[0], -g.sw[1], -g.sw[2]};
@@ -95,85 +98,91 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     }
 }
 
-// Reduced KKT solve, part 1: condensed right-hand side.  Input: F_BXW/F_BXD, G_BXNU/G_BXNUB/G_BY and b.
+// Reduced KKT solve, part 1: condensed right-hand side.  Input: L::F_BXW/L::F_BXD, G_BXNU/G_BXNUB/G_BY and b.
 // Output: stage field fBeta (16) and segment field gRho (14) for the sweeps; returns the sigma-row rhs.
+template <class P>
 __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs &b, int fBeta, int gRho)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     g.dz3 = -b.n1;
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            const double d1 = dLP(identity, sg[G_S1 * NL + i], sg[G_Z1 * NL + i]);
-            const double d2 = dLP(identity, sg[G_S2 * NL + i], sg[G_Z2 * NL + i]);
-            sg[G_DINV * NL + i] = 1. / (d1 + d2);
-            const double bnb = sg[G_BXNUB * NL + i] - g.dz3;
-            const double btn = sg[G_BXNU * NL + i] - sg[G_QV * NL + i] * bnb;
-            sg[G_BNB * NL + i] = bnb;
-            sg[G_BTN * NL + i] = btn;
-            sg[gRho * NL + i] = sg[G_BY * NL + i] + sg[G_EINV * NL + i] * btn;
+            const double d1 = dLP(identity, sg[G_S1 * L::NL + i], sg[G_Z1 * L::NL + i]);
+            const double d2 = dLP(identity, sg[G_S2 * L::NL + i], sg[G_Z2 * L::NL + i]);
+            sg[G_DINV * L::NL + i] = 1. / (d1 + d2);
+            const double bnb = sg[G_BXNUB * L::NL + i] - g.dz3;
+            const double btn = sg[G_BXNU * L::NL + i] - sg[G_QV * L::NL + i] * bnb;
+            sg[G_BNB * L::NL + i] = bnb;
+            sg[G_BTN * L::NL + i] = btn;
+            sg[gRho * L::NL + i] = sg[G_BY * L::NL + i] + sg[G_EINV * L::NL + i] * btn;
         }
     }
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
-        const unsigned fm = fixedMask(k, K);
+        const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+        const unsigned fm = L::fixedMask(k, K);
         for (int j = 0; j < NV; j++)
-            st[fBeta + j] = (fm & (1u << j)) ? 0. : st[F_BXW + j] - st[F_HDW + j] * st[F_BXD] / st[F_HDD];
+            st[fBeta + j] = (fm & (1u << j)) ? 0. : st[L::F_BXW + j] - st[L::F_HDW + j] * st[L::F_BXD] / st[L::F_HDD];
     }
     return b.s - g.Hsd * b.ds / g.Hdd;
 }
 
 // border column products: schur complement of sigma (after the border column has been solved)
+template <class P>
 __device__ inline void borderSchur(const Ctx &c, Glob &g)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double acc = 0.;
     if (k < K - 1)
-        for (int i = 0; i < NL; i++)
-            acc += -c.S[k * NX + i] * c.sg[size_t(G_BCL * NL + i) * c.pitch + k];
+        for (int i = 0; i < L::NL; i++)
+            acc += -c.S[k * P::NX + i] * c.sg[size_t(G_BCL * L::NL + i) * c.pitch + k];
     acc = wave_sum(acc);
     g.schur = g.hsig - acc;
 }
 
 // part 2: after the sweeps left T_mat^-1 [beta;rho] in fVW / gVL: border correction and recovery of the
 // eliminated variables.
+template <class P>
 __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs &b, double bts, int fVW, int gVL)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double cv = 0.;
     if (k < K - 1)
-        for (int i = 0; i < NL; i++)
-            cv += -c.S[k * NX + i] * c.sg[size_t(gVL * NL + i) * c.pitch + k];
+        for (int i = 0; i < L::NL; i++)
+            cv += -c.S[k * P::NX + i] * c.sg[size_t(gVL * L::NL + i) * c.pitch + k];
     cv = wave_sum(cv);
     g.dsig = (bts - cv) / g.schur;
     g.ddsg = (b.ds - g.Hsd * g.dsig) / g.Hdd;
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
+        const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
         double acc = 0.;
         for (int j = 0; j < NV; j++)
         {
-            const double d = st[fVW + j] - st[F_BCW + j] * g.dsig;
-            st[F_DW + j] = d;
-            acc += st[F_HDW + j] * d;
+            const double d = st[fVW + j] - st[L::F_BCW + j] * g.dsig;
+            st[L::F_DW + j] = d;
+            acc += st[L::F_HDW + j] * d;
         }
-        st[F_DDL] = (c.ip[IP_SCVX] != 0.) ? 0. : (st[F_BXD] - acc) / st[F_HDD];
+        st[L::F_DDL] = (c.ip[IP_SCVX] != 0.) ? 0. : (st[L::F_BXD] - acc) / st[L::F_HDD];
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            const double dl = sg[gVL * NL + i] - sg[G_BCL * NL + i] * g.dsig;
-            sg[G_DLAM * NL + i] = dl;
-            const double dnu = sg[G_EINV * NL + i] * (dl + sg[G_BTN * NL + i]);
-            const double dnub = sg[G_BNB * NL + i] * sg[G_DINV * NL + i] - sg[G_QV * NL + i] * dnu;
-            sg[G_DNU * NL + i] = dnu;
-            sg[G_DNUB * NL + i] = dnub;
+            const double dl = sg[gVL * L::NL + i] - sg[G_BCL * L::NL + i] * g.dsig;
+            sg[G_DLAM * L::NL + i] = dl;
+            const double dnu = sg[G_EINV * L::NL + i] * (dl + sg[G_BTN * L::NL + i]);
+            const double dnub = sg[G_BNB * L::NL + i] * sg[G_DINV * L::NL + i] - sg[G_QV * L::NL + i] * dnu;
+            sg[G_DNU * L::NL + i] = dnu;
+            sg[G_DNUB * L::NL + i] = dnub;
             sumnb += dnub;
         }
     }
@@ -203,28 +212,30 @@ __device__ inline RhsSpec specSingle(int fBeta, int gRho, int fOut, int gOut)
     return sp;
 }
 
+template <class P>
 __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
-        const unsigned fm = fixedMask(k, K);
+        const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+        const unsigned fm = L::fixedMask(k, K);
 #pragma unroll
         for (int j = 0; j < NV; j++)
         {
-            const double d = st[F_DW + j];
-            st[F_W + j] += (fm & (1u << j)) ? 0. : alpha * d;
+            const double d = st[L::F_DW + j];
+            st[L::F_W + j] += (fm & (1u << j)) ? 0. : alpha * d;
         }
-        st[F_DL] += alpha * st[F_DDL];
+        st[L::F_DL] += alpha * st[L::F_DDL];
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[G_NU * NL + i] += alpha * sg[G_DNU * NL + i];
-            sg[G_NUB * NL + i] += alpha * sg[G_DNUB * NL + i];
+            sg[G_NU * L::NL + i] += alpha * sg[G_DNU * L::NL + i];
+            sg[G_NUB * L::NL + i] += alpha * sg[G_DNUB * L::NL + i];
         }
     }
     g.sig += alpha * g.dsig;
@@ -233,23 +244,25 @@ __device__ inline void applyPrimalStep(const Ctx &c, Glob &g, double alpha)
 }
 
 // affine slacks of everything at the current primal point -> stage field fOut, segment fields g1,g2; scalars
+template <class P>
 __device__ inline void evalAllSaff(const Ctx &c, const Glob &g, int fOut, int g1, int g2, double &os, double &o3, double *oc)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double sumnb = 0.;
     if (k < K)
     {
-        const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
-        saff(c.ip, activeMask(k, K), st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, st + fOut);
+        const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+        saff<P>(c.ip, L::activeMask(k, K), st + L::F_W, st[L::F_DL], st + L::F_WBAR, st + L::F_UHAT, st + fOut);
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            const double nu = sg[G_NU * NL + i], nub = sg[G_NUB * NL + i];
-            sg[g1 * NL + i] = nub - nu;
-            sg[g2 * NL + i] = nub + nu;
+            const double nu = sg[G_NU * L::NL + i], nub = sg[G_NUB * L::NL + i];
+            sg[g1 * L::NL + i] = nub - nu;
+            sg[g2 * L::NL + i] = nub + nu;
             sumnb += nub;
         }
     }
@@ -262,36 +275,39 @@ __device__ inline void evalAllSaff(const Ctx &c, const Glob &g, int fOut, int g1
 }
 
 // ECOS bring2cone over the whole product cone: stage field f, segment fields g1,g2, scalars
+template <class P>
 __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int g2, double &vs, double &v3, double *vc)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double alpha = -gamma;
     if (k < K)
     {
-        const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
-        for (int cix = 0; cix < NCONE; cix++)
+        const unsigned act = L::activeMask(k, K);
+        const SV v = makeSV(c.st, L::STREC, unsigned(k), c.pitch) + f;
+#pragma unroll
+        for (int cix = 0; cix < L::NCONES; cix++)
             if (act & (1u << cix))
             {
-                const SV r = v + coneOff(cix);
+                const SV r = v + L::CONE_OFF.v[cix];
                 double nrm = 0.;
-                for (int i = 1; i < coneDim(cix); i++)
+                for (int i = 1; i < L::CONE_DIM.v[cix]; i++)
                     nrm += r[i] * r[i];
                 const double cres = r[0] - sqrt(nrm);
                 if (cres <= 0. && -cres > alpha)
                     alpha = -cres;
             }
-        if ((act & 64u) && v[L1] <= 0. && -v[L1] > alpha)
-            alpha = -v[L1];
-        if ((act & 128u) && v[L2] <= 0. && -v[L2] > alpha)
-            alpha = -v[L2];
+#pragma unroll
+        for (int l = 0; l < P::NLP; l++)
+            if ((act & (1u << (L::NCONES + l))) && v[L::LP0 + l] <= 0. && -v[L::LP0 + l] > alpha)
+                alpha = -v[L::LP0 + l];
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
+            const double a = sg[g1 * L::NL + i], b = sg[g2 * L::NL + i];
             if (a <= 0. && -a > alpha)
                 alpha = -a;
             if (b <= 0. && -b > alpha)
@@ -310,23 +326,24 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
     alpha = wave_max(alpha) + 1.;
     if (k < K)
     {
-        const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
-        for (int cix = 0; cix < NCONE; cix++)
+        const unsigned act = L::activeMask(k, K);
+        const SV v = makeSV(c.st, L::STREC, unsigned(k), c.pitch) + f;
+#pragma unroll
+        for (int cix = 0; cix < L::NCONES; cix++)
             if (act & (1u << cix))
-                v[coneOff(cix)] += alpha;
-        if (act & 64u)
-            v[L1] += alpha;
-        if (act & 128u)
-            v[L2] += alpha;
+                v[L::CONE_OFF.v[cix]] += alpha;
+#pragma unroll
+        for (int l = 0; l < P::NLP; l++)
+            if (act & (1u << (L::NCONES + l)))
+                v[L::LP0 + l] += alpha;
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[g1 * NL + i] += alpha;
-            sg[g2 * NL + i] += alpha;
+            sg[g1 * L::NL + i] += alpha;
+            sg[g2 * L::NL + i] += alpha;
         }
     }
     vs += alpha;
@@ -336,36 +353,39 @@ __device__ inline void bring2cone(const Ctx &c, double gamma, int f, int g1, int
 
 
 // warm start: v += (theta + largest violation) e over the whole product cone (oracle/structured_ipm.hpp: shiftToCone)
+template <class P>
 __device__ inline void shiftToCone(const Ctx &c, double theta, int f, int g1, int g2, double &vs, double &v3, double *vc)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double alpha = 0.;
     if (k < K)
     {
-        const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
-        for (int cix = 0; cix < NCONE; cix++)
+        const unsigned act = L::activeMask(k, K);
+        const SV v = makeSV(c.st, L::STREC, unsigned(k), c.pitch) + f;
+#pragma unroll
+        for (int cix = 0; cix < L::NCONES; cix++)
             if (act & (1u << cix))
             {
-                const SV r = v + coneOff(cix);
+                const SV r = v + L::CONE_OFF.v[cix];
                 double nrm = 0.;
-                for (int i = 1; i < coneDim(cix); i++)
+                for (int i = 1; i < L::CONE_DIM.v[cix]; i++)
                     nrm += r[i] * r[i];
                 const double cres = r[0] - sqrt(nrm);
                 if (-cres > alpha)
                     alpha = -cres;
             }
-        if ((act & 64u) && -v[L1] > alpha)
-            alpha = -v[L1];
-        if ((act & 128u) && -v[L2] > alpha)
-            alpha = -v[L2];
+#pragma unroll
+        for (int l = 0; l < P::NLP; l++)
+            if ((act & (1u << (L::NCONES + l))) && -v[L::LP0 + l] > alpha)
+                alpha = -v[L::LP0 + l];
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            const double a = sg[g1 * NL + i], b = sg[g2 * NL + i];
+            const double a = sg[g1 * L::NL + i], b = sg[g2 * L::NL + i];
             if (-a > alpha)
                 alpha = -a;
             if (-b > alpha)
@@ -384,28 +404,40 @@ __device__ inline void shiftToCone(const Ctx &c, double theta, int f, int g1, in
     alpha = wave_max(alpha) + theta;
     if (k < K)
     {
-        const unsigned act = activeMask(k, K);
-        const SV v = makeSV(c.st, STREC, unsigned(k), c.pitch) + f;
-        for (int cix = 0; cix < NCONE; cix++)
+        const unsigned act = L::activeMask(k, K);
+        const SV v = makeSV(c.st, L::STREC, unsigned(k), c.pitch) + f;
+#pragma unroll
+        for (int cix = 0; cix < L::NCONES; cix++)
             if (act & (1u << cix))
-                v[coneOff(cix)] += alpha;
-        if (act & 64u)
-            v[L1] += alpha;
-        if (act & 128u)
-            v[L2] += alpha;
+                v[L::CONE_OFF.v[cix]] += alpha;
+#pragma unroll
+        for (int l = 0; l < P::NLP; l++)
+            if (act & (1u << (L::NCONES + l)))
+                v[L::LP0 + l] += alpha;
     }
     if (k < K - 1)
     {
-        const SV sg = makeSV(c.sg, SEGREC, unsigned(k), c.pitch);
-        for (int i = 0; i < NL; i++)
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[g1 * NL + i] += alpha;
-            sg[g2 * NL + i] += alpha;
+            sg[g1 * L::NL + i] += alpha;
+            sg[g2 * L::NL + i] += alpha;
         }
     }
     vs += alpha;
     v3 += alpha;
     vc[0] += alpha;
+}
+
+// f(integral_constant<int, C>) for every cone C of the model's problem (0 = trust region, then the table's cones)
+template <class P, int C = 0, class F>
+__device__ inline void forEachCone(F &&f)
+{
+    if constexpr (C < Lay<P>::NCONES)
+    {
+        f(std::integral_constant<int, C>{});
+        forEachCone<P, C + 1>(f);
+    }
 }
 
 // ---- per-cone work on register arrays (compile-time offset / dimension) ----
@@ -424,28 +456,30 @@ __device__ inline void stv(const SV &st, int f, const double (&v)[D])
         st[f + OFF + i] = v[i];
 }
 // NT scaling of one cone + lambda = W z ; returns 1 if the iterate left the cone
-template <int OFF, int D>
+template <class P, int OFF, int D>
 __device__ inline int coneScaling(const SV &st, int cix)
 {
+    using L = Lay<P>;
     double s[D], z[D], w[D], ls[D], eta;
-    ldv<OFF, D>(st, F_S, s);
-    ldv<OFF, D>(st, F_Z, z);
+    ldv<OFF, D>(st, L::F_S, s);
+    ldv<OFF, D>(st, L::F_Z, z);
     if (!cone::nt_scalingS<D>(s, z, eta, w))
         return 1;
     cone::applyWS<D>(eta, w, z, ls);
-    st[F_ETA + cix] = eta;
-    stv<OFF, D>(st, F_WB, w);
-    stv<OFF, D>(st, F_LS, ls);
+    st[L::F_ETA + cix] = eta;
+    stv<OFF, D>(st, L::F_WB, w);
+    stv<OFF, D>(st, L::F_LS, ls);
     return 0;
 }
 // t = W^-2 rz' + W^-1(lambda \ ds) of one cone
-template <int OFF, int D>
+template <class P, int OFF, int D>
 __device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu)
 {
+    using L = Lay<P>;
     double w[D], rz[D], b2[D], t[D];
-    const double eta = st[F_ETA + cix];
-    ldv<OFF, D>(st, F_WB, w);
-    ldv<OFF, D>(st, F_RZ, rz);
+    const double eta = st[L::F_ETA + cix];
+    ldv<OFF, D>(st, L::F_WB, w);
+    ldv<OFF, D>(st, L::F_RZ, rz);
 #pragma unroll
     for (int i = 0; i < D; i++)
         rz[i] *= om;
@@ -453,7 +487,7 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     if (pass == 0)
     {
         double z[D];
-        ldv<OFF, D>(st, F_Z, z);
+        ldv<OFF, D>(st, L::F_Z, z);
 #pragma unroll
         for (int i = 0; i < D; i++)
             t[i] = b2[i] - z[i];
@@ -461,9 +495,9 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     else
     {
         double dss[D], dzs[D], ls[D], dsv[D], aa[D];
-        ldv<OFF, D>(st, F_DSS, dss);
-        ldv<OFF, D>(st, F_DZS, dzs);
-        ldv<OFF, D>(st, F_LS, ls);
+        ldv<OFF, D>(st, L::F_DSS, dss);
+        ldv<OFF, D>(st, L::F_DZS, dzs);
+        ldv<OFF, D>(st, L::F_LS, ls);
         cone::conicProductS<D>(dss, dzs, dsv);
 #pragma unroll
         for (int i = 0; i < D; i++)
@@ -478,19 +512,20 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
         for (int i = 0; i < D; i++)
             t[i] = b2[i] + aa[i];
     }
-    stv<OFF, D>(st, F_TZ, t);
+    stv<OFF, D>(st, L::F_TZ, t);
 }
 // dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
 // store_final = false (predictor pass): only the scaled directions are needed afterwards (corrector term)
-template <int OFF, int D>
+template <class P, int OFF, int D>
 __device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final)
 {
+    using L = Lay<P>;
     double w[D], Ld[D], aa[D], t[D], rz[D], dz[D], ds[D], dss[D], dzs[D], ls[D];
-    const double eta = st[F_ETA + cix];
-    ldv<OFF, D>(st, F_WB, w);
-    ldv<OFF, D>(st, F_TZ, t);
-    ldv<OFF, D>(st, F_RZ, rz);
-    ldv<OFF, D>(st, F_LS, ls);
+    const double eta = st[L::F_ETA + cix];
+    ldv<OFF, D>(st, L::F_WB, w);
+    ldv<OFF, D>(st, L::F_TZ, t);
+    ldv<OFF, D>(st, L::F_RZ, rz);
+    ldv<OFF, D>(st, L::F_LS, ls);
 #pragma unroll
     for (int i = 0; i < D; i++)
         Ld[i] = Ldall[OFF + i];
@@ -505,20 +540,21 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
     cone::applyWS<D>(eta, w, dz, dzs);
     if (store_final)
     {
-        stv<OFF, D>(st, F_DZ, dz);
-        stv<OFF, D>(st, F_DS, ds);
+        stv<OFF, D>(st, L::F_DZ, dz);
+        stv<OFF, D>(st, L::F_DS, ds);
     }
-    stv<OFF, D>(st, F_DSS, dss);
-    stv<OFF, D>(st, F_DZS, dzs);
+    stv<OFF, D>(st, L::F_DSS, dss);
+    stv<OFF, D>(st, L::F_DZS, dzs);
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
     return a1 > a2 ? a1 : a2;
 }
-template <int OFF, int D>
+template <class P, int OFF, int D>
 __device__ inline void zeroT(const SV &st)
 {
+    using L = Lay<P>;
 #pragma unroll
     for (int i = 0; i < D; i++)
-        st[F_TZ + OFF + i] = 0.;
+        st[L::F_TZ + OFF + i] = 0.;
 }
 
 
@@ -547,7 +583,7 @@ struct Iter
     double sigma_c, alpha, tzs, tzc[3];
     Rhs b;
     double bts;
-    // ECOS-style safeguarding: scalars of the last iterate that met the reduced tolerances (its W / delta are in F_WBK)
+    // ECOS-style safeguarding: scalars of the last iterate that met the reduced tolerances (its W / delta are in L::F_WBK)
     double bk_sig, bk_dsg, bk_n1, pres_prev;
     int D, bad, bk_valid;
 };
@@ -575,31 +611,36 @@ struct Views
     unsigned fm, act;
     SV st, stN, sg, sgP, dy, dyP;
 };
+template <class P>
 __device__ inline Views makeViews(const Ctx &c)
 {
+    using L = Lay<P>;
     const int k = c.lane, K = c.K;
     Views v{k,
             K,
             k < K,
             k < K - 1,
-            (k < K) ? fixedMask(k, K) : 0u,
-            (k < K) ? activeMask(k, K) : 0u,
-            makeSV(c.st, STREC, unsigned(k < K ? k : 0), c.pitch),
-            makeSV(c.st, STREC, unsigned(k < K - 1 ? k + 1 : 0), c.pitch),
-            makeSV(c.sg, SEGREC, unsigned(k < K - 1 ? k : 0), c.pitch),
-            makeSV(c.sg, SEGREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch),
-            makeSV(c.dy, DYNREC, unsigned(k < K - 1 ? k : 0), c.pitch),
-            makeSV(c.dy, DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch)};
+            (k < K) ? L::fixedMask(k, K) : 0u,
+            (k < K) ? L::activeMask(k, K) : 0u,
+            makeSV(c.st, L::STREC, unsigned(k < K ? k : 0), c.pitch),
+            makeSV(c.st, L::STREC, unsigned(k < K - 1 ? k + 1 : 0), c.pitch),
+            makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k < K - 1 ? k : 0), c.pitch),
+            makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch),
+            makeSV(c.dy, L::DYNREC, unsigned(k < K - 1 ? k : 0), c.pitch),
+            makeSV(c.dy, L::DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch)};
     return v;
 }
 
 // ---- setup: clear records, field-major copy of the dynamics, trust-region centre, fixed values ----
+template <class P>
 PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
     const bool warm = uniformInt(warmIn) != 0;
     const Ctx c = uniformCtx(cin);
     const double *X = uniformPtr(Xin), *U = uniformPtr(Uin), *uhat = uniformPtr(uhatIn);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const int k = v.k, K = v.K;
     const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
@@ -637,58 +678,61 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
     // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
     // never written afterwards but are swept by the vector updates)
     if (v.vst && !warm)
-        for (int i = 0; i < STREC; i++)
+        for (int i = 0; i < L::STREC; i++)
             st[i] = 0.;
     if (v.vsg)
     {
         if (!warm)
-            for (int i = 0; i < SEGREC; i++)
+            for (int i = 0; i < (G_NFIELDS * L::NL); i++)
                 sg[i] = 0.;
         // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
         const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
         for (int e = 0; e < NX * NX; e++)
-            dy[DY_A + e] = Ak[e];
+            dy[L::DY_A + e] = Ak[e];
         for (int e = 0; e < NX * NU; e++)
         {
-            dy[DY_B + e] = Bk[e];
-            dy[DY_C + e] = Ck[e];
+            dy[L::DY_B + e] = Bk[e];
+            dy[L::DY_C + e] = Ck[e];
         }
         for (int e = 0; e < NX; e++)
         {
-            dy[DY_S + e] = c.S[k * NX + e];
-            dy[DY_Z + e] = c.Z[k * NX + e];
+            dy[L::DY_S + e] = c.S[k * NX + e];
+            dy[L::DY_Z + e] = c.Z[k * NX + e];
         }
     }
     if (v.vst)
     {
         const double *Xb = X + size_t(k) * NX, *Ub = U + size_t(k) * NU;
-        for (int j = 0; j < 13; j++)
-            st[F_WBAR + j] = Xb[j];
+#pragma unroll
+        for (int j = 0; j < P::NXV; j++)
+            st[L::F_WBAR + j] = Xb[P::XMAP[j]];
+#pragma unroll
+        for (int j = 0; j < P::NUV; j++)
+            st[L::F_WBAR + P::NXV + j] = Ub[P::UMAP[j]];
         for (int j = 0; j < 3; j++)
-            st[F_WBAR + 13 + j] = Ub[j];
-        for (int j = 0; j < 3; j++)
-            st[F_UHAT + j] = uhat[size_t(k) * 3 + j];
-        if (k == 0)
-            for (int j = 0; j < 13; j++)
-                st[F_W + j] = ip[IP_XINIT + j];
-        if (k == K - 1)
-            for (int j = 0; j < 13; j++)
-                if (v.fm & (1u << j))
-                    st[F_W + j] = ip[IP_XFINAL + j];
-        for (int b = 0; b < 8; b++)
-            if (v.act & (1u << b))
-                Dcount++;
+            st[L::F_UHAT + j] = uhat[size_t(k) * 3 + j];
+        // presolved variables (the table's equalTo rows): x_init at the first node, x_final components / zero inputs at the last
+#pragma unroll
+        for (int j = 0; j < L::NVU; j++)
+        {
+            if (k == 0 && (P::FIXED_FIRST & (1u << j)))
+                st[L::F_W + j] = j < P::NXV ? ip[IP_XINIT + P::XMAP[j < P::NXV ? j : 0]] : 0.;
+            if (k == K - 1 && (P::FIXED_LAST & (1u << j)))
+                st[L::F_W + j] = j < P::NXV ? ip[IP_XFINAL + P::XMAP[j < P::NXV ? j : 0]] : 0.;
+        }
+        Dcount += __builtin_popcount(v.act);
         // identity scalings
         if (!warm)
         {
-            for (int i = 0; i < 6; i++)
-                st[F_ETA + i] = 1.;
-            for (int cix = 0; cix < NCONE; cix++)
-                st[F_WB + coneOff(cix)] = 1.;
+            for (int i = 0; i < L::NCONES; i++)
+                st[L::F_ETA + i] = 1.;
+    #pragma unroll
+        for (int cix = 0; cix < L::NCONES; cix++)
+                st[L::F_WB + L::CONE_OFF.v[cix]] = 1.;
         }
     }
     if (v.vsg)
-        Dcount += 2 * NL;
+        Dcount += 2 * L::NL;
     {
         const double dsum = wave_sum(double(Dcount));
         it.D = int(dsum + 0.5) + 3;
@@ -700,65 +744,71 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
 }
 
 // ---- ECOS init, primal part: rhs of  min ||x||^2 + ||s||^2  s.t. equalities (W = I) ----
+template <class P>
 PHASE_FN void phInitPrimalRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
-    prepareFactor(c, true, g);
+    prepareFactor<P>(c, true, g);
     Rhs b;
     if (v.vst)
     {
-        double r[NS], gw[NV], gdl;
-        saff(ip, v.act, st + F_W, st[F_DL], st + F_WBAR, st + F_UHAT, r);
-        LTmul(ip, v.fm, r, st + F_UHAT, gw, &gdl);
+        double r[L::NS], gw[NV], gdl;
+        saff<P>(ip, v.act, st + L::F_W, st[L::F_DL], st + L::F_WBAR, st + L::F_UHAT, r);
+        LTmul<P>(ip, v.fm, r, st + L::F_UHAT, gw, &gdl);
         for (int j = 0; j < NV; j++)
-            st[F_BXW + j] = -gw[j];
-        st[F_BXD] = -gdl;
+            st[L::F_BXW + j] = -gw[j];
+        st[L::F_BXD] = -gdl;
     }
     if (v.vsg)
     {
-        double res[NL];
-        dynResF(dy, st + F_W, stN + F_W, sg + G_NU * NL, g.sig, res);
-        for (int i = 0; i < NL; i++)
+        double res[L::NL];
+        dynResF<P>(dy, st + L::F_W, stN + L::F_W, sg + G_NU * L::NL, g.sig, res);
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[G_BXNU * NL + i] = 0.;
-            sg[G_BXNUB * NL + i] = 0.;
-            sg[G_BY * NL + i] = -res[i];
+            sg[G_BXNU * L::NL + i] = 0.;
+            sg[G_BXNUB * L::NL + i] = 0.;
+            sg[G_BY * L::NL + i] = -res[i];
         }
     }
     b.s = -((g.sig - 0.001) + (g.sig - it.sigbar));
     b.ds = -(0.5 * (0.5 + 0.5 * g.dsg) - 0.5 * (0.5 - 0.5 * g.dsg));
     b.n1 = 0.;
     b.rhs3 = g.n1;
-    it.bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+    it.bts = kktPrep<P>(c, true, g, b, L::F_BETA, G_RHO);
     it.b = b;
     storePriv(gp, g);
     storePriv(ip_, it);
     WAVE_SYNC();
 }
+template <class P>
 PHASE_FN void phInitPrimalFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
     const Iter it = loadPriv(ip_);
-    borderSchur(c, g);
-    kktFinish(c, true, g, it.b, it.bts, F_VW, G_VL);
-    applyPrimalStep(c, g, 1.);
+    borderSchur<P>(c, g);
+    kktFinish<P>(c, true, g, it.b, it.bts, L::F_VW, G_VL);
+    applyPrimalStep<P>(c, g, 1.);
     WAVE_SYNC();
-    evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
-    bring2cone(c, it.gamma, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    evalAllSaff<P>(c, g, L::F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    bring2cone<P>(c, it.gamma, L::F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
     storePriv(gp, g);
     WAVE_SYNC();
 }
 // ---- ECOS init, dual part: H x' + A'y = -c ; z = -L x' ----
+template <class P>
 PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg;
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
@@ -766,79 +816,85 @@ PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     if (v.vst)
     {
         for (int j = 0; j < NV; j++)
-            st[F_BXW + j] = 0.;
-        st[F_BXD] = -it.wtrx;
+            st[L::F_BXW + j] = 0.;
+        st[L::F_BXD] = -it.wtrx;
     }
     if (v.vsg)
-        for (int i = 0; i < NL; i++)
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[G_BXNU * NL + i] = 0.;
-            sg[G_BXNUB * NL + i] = 0.;
-            sg[G_BY * NL + i] = 0.;
+            sg[G_BXNU * L::NL + i] = 0.;
+            sg[G_BXNUB * L::NL + i] = 0.;
+            sg[G_BY * L::NL + i] = 0.;
         }
     b.s = -it.w_t;
     b.ds = -it.w_trt;
     b.n1 = -it.w_vc;
     b.rhs3 = 0.;
-    it.bts = kktPrep(c, true, g, b, F_BETA, G_RHO);
+    it.bts = kktPrep<P>(c, true, g, b, L::F_BETA, G_RHO);
     it.b = b;
     storePriv(gp, g);
     storePriv(ip_, it);
     WAVE_SYNC();
 }
+template <class P>
 PHASE_FN void phInitDualFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const int K = v.K;
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
-    kktFinish(c, true, g, it.b, it.bts, F_VW, G_VL);
+    kktFinish<P>(c, true, g, it.b, it.bts, L::F_VW, G_VL);
     if (v.vst)
     {
-        double t[NS];
-        Lmul(ip, v.act, st + F_DW, st[F_DDL], st + F_UHAT, t);
-        for (int i = 0; i < NS; i++)
-            st[F_Z + i] = -t[i];
+        double t[L::NS];
+        Lmul<P>(ip, v.act, st + L::F_DW, st[L::F_DDL], st + L::F_UHAT, t);
+        for (int i = 0; i < L::NS; i++)
+            st[L::F_Z + i] = -t[i];
     }
     if (v.vsg)
-        for (int i = 0; i < NL; i++)
+        for (int i = 0; i < L::NL; i++)
         {
-            sg[G_LAM * NL + i] = sg[G_DLAM * NL + i];
-            const double dnu = sg[G_DNU * NL + i], dnub = sg[G_DNUB * NL + i];
-            sg[G_Z1 * NL + i] = -(dnub - dnu);
-            sg[G_Z2 * NL + i] = -(dnub + dnu);
+            sg[G_LAM * L::NL + i] = sg[G_DLAM * L::NL + i];
+            const double dnu = sg[G_DNU * L::NL + i], dnub = sg[G_DNUB * L::NL + i];
+            sg[G_Z1 * L::NL + i] = -(dnub - dnu);
+            sg[G_Z2 * L::NL + i] = -(dnub + dnu);
         }
     g.zs = -g.dsig;
     g.z3 = g.dz3;
     g.zc3[0] = -0.5 * g.ddsg;
     g.zc3[1] = 0.5 * g.ddsg;
     g.zc3[2] = -g.dsig;
-    bring2cone(c, it.gamma, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+    bring2cone<P>(c, it.gamma, L::F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
     storePriv(gp, g);
     storePriv(ip_, it);
     WAVE_SYNC();
 }
 // ---- warm start: slacks re-evaluated on the new data and pushed theta into the interior, duals likewise ----
+template <class P>
 PHASE_FN void phWarmInit(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
     const double theta = 1e-2;
-    evalAllSaff(c, g, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    evalAllSaff<P>(c, g, L::F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
     WAVE_SYNC();
-    shiftToCone(c, theta, F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
-    shiftToCone(c, theta, F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
+    shiftToCone<P>(c, theta, L::F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
+    shiftToCone<P>(c, theta, L::F_Z, G_Z1, G_Z2, g.zs, g.z3, g.zc3);
     storePriv(gp, g);
     WAVE_SYNC();
 }
 // ---- data norms for the termination test (ECOS-style scaling) ----
+template <class P>
 PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const int K = v.K;
     const SV &st = v.st, &stN = v.stN, &dy = v.dy;
     const double *ip = c.ip;
@@ -854,22 +910,22 @@ PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         if (v.vst)
         {
             for (int j = 0; j < NV; j++)
-                w0[j] = (v.fm & (1u << j)) ? double(st[F_W + j]) : 0.;
-            double r[NS];
-            saff(ip, v.act, w0, 0., st + F_WBAR, st + F_UHAT, r);
-            for (int i = 0; i < NS; i++)
+                w0[j] = (v.fm & (1u << j)) ? double(st[L::F_W + j]) : 0.;
+            double r[L::NS];
+            saff<P>(ip, v.act, w0, 0., st + L::F_WBAR, st + L::F_UHAT, r);
+            for (int i = 0; i < L::NS; i++)
                 nh += r[i] * r[i];
         }
         if (v.vsg)
         {
-            const unsigned fmn = fixedMask(v.k + 1, K);
+            const unsigned fmn = L::fixedMask(v.k + 1, K);
             for (int j = 0; j < NV; j++)
-                w1[j] = (fmn & (1u << j)) ? double(stN[F_W + j]) : 0.;
-            double zero[NL], res[NL];
-            for (int i = 0; i < NL; i++)
+                w1[j] = (fmn & (1u << j)) ? double(stN[L::F_W + j]) : 0.;
+            double zero[L::NL], res[L::NL];
+            for (int i = 0; i < L::NL; i++)
                 zero[i] = 0.;
-            dynResF(dy, w0, w1, zero, 0., res);
-            for (int i = 0; i < NL; i++)
+            dynResF<P>(dy, w0, w1, zero, 0., res);
+            for (int i = 0; i < L::NL; i++)
                 nb += res[i] * res[i];
         }
         nb = wave_sum(nb);
@@ -905,18 +961,19 @@ struct ResAcc
 {
     double gap, rx, ry, rz, xx, yy, zz, ss, rxs, sumnb;
 };
-template <int I0, int N>
+template <class P, int I0, int N>
 __device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc &p)
 {
+    using L = Lay<P>;
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N], S[N];
-    ldf<N>(sg, G_NU * NL + I0, nu);
-    ldf<N>(sg, G_NUB * NL + I0, nub);
-    ldf<N>(sg, G_S1 * NL + I0, s1);
-    ldf<N>(sg, G_Z1 * NL + I0, z1);
-    ldf<N>(sg, G_S2 * NL + I0, s2);
-    ldf<N>(sg, G_Z2 * NL + I0, z2);
-    ldf<N>(sg, G_LAM * NL + I0, lam);
-    ldf<N>(dy, DY_S + I0, S);
+    ldf<N>(sg, G_NU * L::NL + I0, nu);
+    ldf<N>(sg, G_NUB * L::NL + I0, nub);
+    ldf<N>(sg, G_S1 * L::NL + I0, s1);
+    ldf<N>(sg, G_Z1 * L::NL + I0, z1);
+    ldf<N>(sg, G_S2 * L::NL + I0, s2);
+    ldf<N>(sg, G_Z2 * L::NL + I0, z2);
+    ldf<N>(sg, G_LAM * L::NL + I0, lam);
+    ldf<N>(dy, L::DY_S + I0, S);
     double r1[N], r2[N], rnu[N], rnub[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
@@ -935,15 +992,18 @@ __device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc
         p.xx += nu[i] * nu[i] + nub[i] * nub[i];
         p.rxs += S[i] * lam[i];
     }
-    stf<N>(sg, G_RZ1 * NL + I0, r1);
-    stf<N>(sg, G_RZ2 * NL + I0, r2);
-    stf<N>(sg, G_RXNU * NL + I0, rnu);
-    stf<N>(sg, G_RXNUB * NL + I0, rnub);
+    stf<N>(sg, G_RZ1 * L::NL + I0, r1);
+    stf<N>(sg, G_RZ2 * L::NL + I0, r2);
+    stf<N>(sg, G_RXNU * L::NL + I0, rnu);
+    stf<N>(sg, G_RXNUB * L::NL + I0, rnub);
 }
+template <class P>
 PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const int k = v.k;
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &sgP = v.sgP, &dy = v.dy, &dyP = v.dyP;
     const double *ip = c.ip;
@@ -955,73 +1015,75 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     double p_dl = 0.;
     if (v.vsg)
     {
-        resSegChunk<0, 5>(sg, dy, g.z3, p);
-        resSegChunk<5, 5>(sg, dy, g.z3, p);
-        resSegChunk<10, 4>(sg, dy, g.z3, p);
+        resSegChunk<P, 0, L::SC1>(sg, dy, g.z3, p);
+        resSegChunk<P, L::SC1, L::SC2>(sg, dy, g.z3, p);
+        resSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, dy, g.z3, p);
     }
     if (v.vst)
     {
         double x0[NV], gw[NV], gdl, dl;
         {
-            // rz = s - saff(x) ; gap ; L'z
-            double wbar[NV], uh[3], sa[NS], sv[NS];
-            ldf<NV>(st, F_W, x0);
-            ldf<NV>(st, F_WBAR, wbar);
-            ldf<3>(st, F_UHAT, uh);
-            dl = st[F_DL];
-            ldf<NS>(st, F_S, sv);
-            saff(ip, v.act, x0, dl, wbar, uh, sa);
+            // rz = s - saff<P>(x) ; gap ; L'z
+            double wbar[NV], uh[3], sa[L::NS], sv[L::NS];
+            ldf<NV>(st, L::F_W, x0);
+            ldf<NV>(st, L::F_WBAR, wbar);
+            ldf<3>(st, L::F_UHAT, uh);
+            dl = st[L::F_DL];
+            ldf<L::NS>(st, L::F_S, sv);
+            saff<P>(ip, v.act, x0, dl, wbar, uh, sa);
 #pragma unroll
-            for (int i = 0; i < NS; i++)
+            for (int i = 0; i < L::NS; i++)
             {
                 sa[i] = sv[i] - sa[i];
                 p.rz += sa[i] * sa[i];
                 p.ss += sv[i] * sv[i];
             }
-            stf<NS>(st, F_RZ, sa);
-            double zv[NS];
-            ldf<NS>(st, F_Z, zv);
+            stf<L::NS>(st, L::F_RZ, sa);
+            double zv[L::NS];
+            ldf<L::NS>(st, L::F_Z, zv);
 #pragma unroll
-            for (int i = 0; i < NS; i++)
+            for (int i = 0; i < L::NS; i++)
             {
                 p.gap += sv[i] * zv[i];
                 p.zz += zv[i] * zv[i];
             }
-            LTmul(ip, fm, zv, uh, gw, &gdl);
+            LTmul<P>(ip, fm, zv, uh, gw, &gdl);
         }
         const double rxd = (ip[IP_SCVX] != 0.) ? 0. : it.wtrx - gdl; // SCvx: delta_k is not a variable
         // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
         // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
-        double acc[NV], u1[3], resv[NL];
+        constexpr int NXV = P::NXV, NUV = P::NUV;
+        double acc[NV], u1[NUV], resv[L::NL];
 #pragma unroll
         for (int j = 0; j < NV; j++)
             acc[j] = 0.;
-        ldf<3>(stN, F_W + 13, u1);
+        ldf<NUV>(stN, L::F_W + NXV, u1);
         const double mk = v.vsg ? 1. : 0., mp = k > 0 ? 1. : 0.;
 #pragma unroll
-        for (int i = 0; i < NL; i++)
+        for (int i = 0; i < L::NL; i++)
         {
-            double ra[13], rb[3], rc[3], rcp[3];
-            ldf<13>(dy, DY_A + i * NX, ra);
-            ldf<3>(dy, DY_B + i * NU, rb);
-            ldf<3>(dy, DY_C + i * NU, rc);
-            ldf<3>(dyP, DY_C + i * NU, rcp);
-            const double l = mk * double(sg[G_LAM * NL + i]), lp = mp * double(sgP[G_LAM * NL + i]);
-            double rr = (i < 13 ? double(stN[F_W + (i < 13 ? i : 0)]) : 0.) - dy[DY_S + i] * g.sig - sg[G_NU * NL + i] - dy[DY_Z + i];
+            double ra[NXV], rb[NUV], rc[NUV], rcp[NUV];
+            sfor<NXV>([&](auto jt) { ra[decltype(jt)::value] = dy[L::DY_A + i * NX + P::XMAP[decltype(jt)::value]]; });
+            sfor<NUV>([&](auto jt) { rb[decltype(jt)::value] = dy[L::DY_B + i * NU + P::UMAP[decltype(jt)::value]]; });
+            sfor<NUV>([&](auto jt) { rc[decltype(jt)::value] = dy[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
+            sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = dyP[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
+            const double l = mk * double(sg[G_LAM * L::NL + i]), lp = mp * double(sgP[G_LAM * L::NL + i]);
+            const int xi = L::XINV.v[i]; // stage variable of state i, -1: pinned
+            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dy[L::DY_S + i] * g.sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
 #pragma unroll
-            for (int j = 0; j < 13; j++)
+            for (int j = 0; j < NXV; j++)
             {
                 acc[j] -= ra[j] * l;
                 rr -= ra[j] * x0[j];
             }
 #pragma unroll
-            for (int j = 0; j < 3; j++)
+            for (int j = 0; j < NUV; j++)
             {
-                acc[13 + j] -= rb[j] * l + rcp[j] * lp;
-                rr -= rb[j] * x0[13 + j] + rc[j] * u1[j];
+                acc[NXV + j] -= rb[j] * l + rcp[j] * lp;
+                rr -= rb[j] * x0[NXV + j] + rc[j] * u1[j];
             }
-            if (i < 13)
-                acc[i] += lp;
+            if (xi >= 0)
+                acc[xi >= 0 ? xi : 0] += lp;
             resv[i] = rr;
             p.ry += v.vsg ? rr * rr : 0.;
         }
@@ -1038,10 +1100,10 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             p.rx += fx ? 0. : r * r;
             p.xx += fx ? 0. : x0[j] * x0[j];
         }
-        st[F_RXD] = rxd;
-        stf<NV>(st, F_RXW, rxw);
+        st[L::F_RXD] = rxd;
+        stf<NV>(st, L::F_RXW, rxw);
         if (v.vsg)
-            stf<NL>(sg, G_RY * NL, resv);
+            stf<L::NL>(sg, G_RY * L::NL, resv);
     }
     p.gap = wave_sum(p.gap);
     p.rx = wave_sum(p.rx);
@@ -1097,8 +1159,8 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             if (v.vst)
             {
                 double xw[NV + 1];
-                ldf<NV + 1>(st, F_W, xw); // W[16], delta
-                stf<NV + 1>(st, F_WBK, xw);
+                ldf<NV + 1>(st, L::F_W, xw); // W[16], delta
+                stf<NV + 1>(st, L::F_WBK, xw);
             }
             it.bk_sig = g.sig;
             it.bk_dsg = g.dsg;
@@ -1111,25 +1173,23 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 }
 
 // ---- Nesterov-Todd scalings and the per-stage factorisation inputs ----
+template <class P>
 PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st;
     const unsigned act = v.act;
     Glob g = loadPriv(gp);
     int bad = 0;
     if (v.vst)
     {
-        bad |= coneScaling<C1, 17>(st, 0);
-        if (act & 2u)
-            bad |= coneScaling<C2, 3>(st, 1);
-        if (act & 4u)
-            bad |= coneScaling<C3, 3>(st, 2);
-        if (act & 8u)
-            bad |= coneScaling<C4, 3>(st, 3);
-        bad |= coneScaling<C5, 4>(st, 4);
-        bad |= coneScaling<C6, 3>(st, 5);
+        forEachCone<P>([&](auto ci) {
+            constexpr int C = decltype(ci)::value;
+            if (act & (1u << C))
+                bad |= coneScaling<P, L::coneOff(C), L::coneDim(C)>(st, C);
+        });
     }
 #ifdef SCPP_HIP_EMU
     if (bad && getenv("SCPP_EMU_DEBUG"))
@@ -1148,7 +1208,7 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     {
         cone::applyW(g.seta, g.sw, 3, g.zc3, g.lamC);
         WAVE_SYNC();
-        prepareFactor(c, false, g);
+        prepareFactor<P>(c, false, g);
     }
     ip_->bad = bad;
     storePriv(gp, g);
@@ -1157,29 +1217,30 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
 // segment rows [I0, I0+N): LP blocks of nu / nu_b, fused with the condensation (kktPrep) of those rows
-template <int I0, int N>
+template <class P, int I0, int N>
 __device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sigmu, double dz3)
 {
+    using L = Lay<P>;
     double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N], qv[N], einv[N];
-    ldf<N>(sg, G_S1 * NL + I0, s1);
-    ldf<N>(sg, G_Z1 * NL + I0, z1);
-    ldf<N>(sg, G_S2 * NL + I0, s2);
-    ldf<N>(sg, G_Z2 * NL + I0, z2);
-    ldf<N>(sg, G_RZ1 * NL + I0, rz1);
-    ldf<N>(sg, G_RZ2 * NL + I0, rz2);
-    ldf<N>(sg, G_RXNU * NL + I0, rxnu);
-    ldf<N>(sg, G_RXNUB * NL + I0, rxnub);
-    ldf<N>(sg, G_RY * NL + I0, ry);
-    ldf<N>(sg, G_QV * NL + I0, qv);
-    ldf<N>(sg, G_EINV * NL + I0, einv);
+    ldf<N>(sg, G_S1 * L::NL + I0, s1);
+    ldf<N>(sg, G_Z1 * L::NL + I0, z1);
+    ldf<N>(sg, G_S2 * L::NL + I0, s2);
+    ldf<N>(sg, G_Z2 * L::NL + I0, z2);
+    ldf<N>(sg, G_RZ1 * L::NL + I0, rz1);
+    ldf<N>(sg, G_RZ2 * L::NL + I0, rz2);
+    ldf<N>(sg, G_RXNU * L::NL + I0, rxnu);
+    ldf<N>(sg, G_RXNUB * L::NL + I0, rxnub);
+    ldf<N>(sg, G_RY * L::NL + I0, ry);
+    ldf<N>(sg, G_QV * L::NL + I0, qv);
+    ldf<N>(sg, G_EINV * L::NL + I0, einv);
     double c1[N], c2[N];
     if (pass)
     {
         double ds1[N], dz1[N], ds2[N], dz2[N];
-        ldf<N>(sg, G_DS1 * NL + I0, ds1);
-        ldf<N>(sg, G_DZ1 * NL + I0, dz1);
-        ldf<N>(sg, G_DS2 * NL + I0, ds2);
-        ldf<N>(sg, G_DZ2 * NL + I0, dz2);
+        ldf<N>(sg, G_DS1 * L::NL + I0, ds1);
+        ldf<N>(sg, G_DZ1 * L::NL + I0, dz1);
+        ldf<N>(sg, G_DS2 * L::NL + I0, ds2);
+        ldf<N>(sg, G_DZ2 * L::NL + I0, dz2);
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
@@ -1208,18 +1269,20 @@ __device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sig
         btn[i] = bxnu - qv[i] * bnb[i];
         rho[i] = by + einv[i] * btn[i];
     }
-    stf<N>(sg, G_TZ1 * NL + I0, t1);
-    stf<N>(sg, G_TZ2 * NL + I0, t2);
-    stf<N>(sg, G_DINV * NL + I0, dinv);
-    stf<N>(sg, G_BNB * NL + I0, bnb);
-    stf<N>(sg, G_BTN * NL + I0, btn);
-    stf<N>(sg, G_RHO * NL + I0, rho);
+    stf<N>(sg, G_TZ1 * L::NL + I0, t1);
+    stf<N>(sg, G_TZ2 * L::NL + I0, t2);
+    stf<N>(sg, G_DINV * L::NL + I0, dinv);
+    stf<N>(sg, G_BNB * L::NL + I0, bnb);
+    stf<N>(sg, G_BTN * L::NL + I0, btn);
+    stf<N>(sg, G_RHO * L::NL + I0, rho);
 }
+template <class P>
 PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const int pass = uniformInt(passIn);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg;
     const double *ip = c.ip;
     const unsigned fm = v.fm, act = v.act;
@@ -1264,45 +1327,38 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
     // ---- stages ----
     if (v.vst)
     {
-        coneT<C1, 17>(st, 0, pass, om, sigmu);
-        if (act & 2u)
-            coneT<C2, 3>(st, 1, pass, om, sigmu);
-        else
-            zeroT<C2, 3>(st);
-        if (act & 4u)
-            coneT<C3, 3>(st, 2, pass, om, sigmu);
-        else
-            zeroT<C3, 3>(st);
-        if (act & 8u)
-            coneT<C4, 3>(st, 3, pass, om, sigmu);
-        else
-            zeroT<C4, 3>(st);
-        coneT<C5, 4>(st, 4, pass, om, sigmu);
-        coneT<C6, 3>(st, 5, pass, om, sigmu);
+        forEachCone<P>([&](auto ci) {
+            constexpr int C = decltype(ci)::value;
+            if (act & (1u << C))
+                coneT<P, L::coneOff(C), L::coneDim(C)>(st, C, pass, om, sigmu);
+            else
+                zeroT<P, L::coneOff(C), L::coneDim(C)>(st);
+        });
         {
-            // the two LP rows (mass, minimum thrust)
-            double sv[2], zv[2], rz[2], dsv[2], dzv[2], tz[2];
-            ldf<2>(st, F_S + L1, sv);
-            ldf<2>(st, F_Z + L1, zv);
-            ldf<2>(st, F_RZ + L1, rz);
-            ldf<2>(st, F_DS + L1, dsv);
-            ldf<2>(st, F_DZ + L1, dzv);
+            // the LP rows of the table
+            constexpr int NLP = P::NLP, LP0 = L::LP0;
+            double sv[NLP], zv[NLP], rz[NLP], dsv[NLP], dzv[NLP], tz[NLP];
+            ldf<NLP>(st, L::F_S + LP0, sv);
+            ldf<NLP>(st, L::F_Z + LP0, zv);
+            ldf<NLP>(st, L::F_RZ + LP0, rz);
+            ldf<NLP>(st, L::F_DS + LP0, dsv);
+            ldf<NLP>(st, L::F_DZ + LP0, dzv);
 #pragma unroll
-            for (int w = 0; w < 2; w++)
+            for (int w = 0; w < NLP; w++)
             {
                 const double corr = pass ? (sigmu - dsv[w] * dzv[w]) / sv[w] : 0.;
-                tz[w] = (act & (1u << (6 + w))) ? (zv[w] / sv[w]) * om * rz[w] - zv[w] + corr : 0.;
+                tz[w] = (act & (1u << (L::NCONES + w))) ? (zv[w] / sv[w]) * om * rz[w] - zv[w] + corr : 0.;
             }
-            stf<2>(st, F_TZ + L1, tz);
+            stf<NLP>(st, L::F_TZ + LP0, tz);
         }
-        double tzv[NS], uh[3], gw[NV], gdl;
-        ldf<NS>(st, F_TZ, tzv);
-        ldf<3>(st, F_UHAT, uh);
-        LTmul(ip, fm, tzv, uh, gw, &gdl);
+        double tzv[L::NS], uh[3], gw[NV], gdl;
+        ldf<L::NS>(st, L::F_TZ, tzv);
+        ldf<3>(st, L::F_UHAT, uh);
+        LTmul<P>(ip, fm, tzv, uh, gw, &gdl);
         double rxw[NV], hdw[NV], beta[NV];
-        ldf<NV>(st, F_RXW, rxw);
-        ldf<NV>(st, F_HDW, hdw);
-        const double rxd = st[F_RXD], hdd = st[F_HDD];
+        ldf<NV>(st, L::F_RXW, rxw);
+        ldf<NV>(st, L::F_HDW, hdw);
+        const double rxd = st[L::F_RXD], hdd = st[L::F_HDD];
         const double bxd = -om * rxd + gdl;
         const double q = bxd / hdd;
 #pragma unroll
@@ -1311,15 +1367,15 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
             rxw[j] = -om * rxw[j] + gw[j];
             beta[j] = (fm & (1u << j)) ? 0. : rxw[j] - hdw[j] * q;
         }
-        stf<NV>(st, F_BXW, rxw);
-        st[F_BXD] = bxd;
-        stf<NV>(st, F_BETA, beta);
+        stf<NV>(st, L::F_BXW, rxw);
+        st[L::F_BXD] = bxd;
+        stf<NV>(st, L::F_BETA, beta);
     }
     if (v.vsg)
     {
-        rhsSegChunk<0, 5>(sg, pass, om, sigmu, g.dz3);
-        rhsSegChunk<5, 5>(sg, pass, om, sigmu, g.dz3);
-        rhsSegChunk<10, 4>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<P, 0, L::SC1>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<P, L::SC1, L::SC2>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, pass, om, sigmu, g.dz3);
     }
     storePriv(gp, g);
     storePriv(ip_, it);
@@ -1327,26 +1383,27 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
 }
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
-template <int I0, int N>
+template <class P, int I0, int N>
 __device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
 {
+    using L = Lay<P>;
     double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
     double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
-    ldf<N>(sg, G_VL * NL + I0, vl);
-    ldf<N>(sg, G_BCL * NL + I0, bcl);
-    ldf<N>(sg, G_EINV * NL + I0, einv);
-    ldf<N>(sg, G_BTN * NL + I0, btn);
-    ldf<N>(sg, G_BNB * NL + I0, bnb);
-    ldf<N>(sg, G_DINV * NL + I0, dinv);
-    ldf<N>(sg, G_QV * NL + I0, qv);
-    ldf<N>(sg, G_S1 * NL + I0, s1);
-    ldf<N>(sg, G_Z1 * NL + I0, z1);
-    ldf<N>(sg, G_S2 * NL + I0, s2);
-    ldf<N>(sg, G_Z2 * NL + I0, z2);
-    ldf<N>(sg, G_TZ1 * NL + I0, tz1);
-    ldf<N>(sg, G_TZ2 * NL + I0, tz2);
-    ldf<N>(sg, G_RZ1 * NL + I0, rz1);
-    ldf<N>(sg, G_RZ2 * NL + I0, rz2);
+    ldf<N>(sg, G_VL * L::NL + I0, vl);
+    ldf<N>(sg, G_BCL * L::NL + I0, bcl);
+    ldf<N>(sg, G_EINV * L::NL + I0, einv);
+    ldf<N>(sg, G_BTN * L::NL + I0, btn);
+    ldf<N>(sg, G_BNB * L::NL + I0, bnb);
+    ldf<N>(sg, G_DINV * L::NL + I0, dinv);
+    ldf<N>(sg, G_QV * L::NL + I0, qv);
+    ldf<N>(sg, G_S1 * L::NL + I0, s1);
+    ldf<N>(sg, G_Z1 * L::NL + I0, z1);
+    ldf<N>(sg, G_S2 * L::NL + I0, s2);
+    ldf<N>(sg, G_Z2 * L::NL + I0, z2);
+    ldf<N>(sg, G_TZ1 * L::NL + I0, tz1);
+    ldf<N>(sg, G_TZ2 * L::NL + I0, tz2);
+    ldf<N>(sg, G_RZ1 * L::NL + I0, rz1);
+    ldf<N>(sg, G_RZ2 * L::NL + I0, rz2);
     double dlam[N], dnu[N], dnub[N], dz1[N], ds1[N], dz2[N], ds2[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
@@ -1368,20 +1425,22 @@ __device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double 
     }
     if (store_final)
     {
-        stf<N>(sg, G_DLAM * NL + I0, dlam);
-        stf<N>(sg, G_DNU * NL + I0, dnu);
-        stf<N>(sg, G_DNUB * NL + I0, dnub);
+        stf<N>(sg, G_DLAM * L::NL + I0, dlam);
+        stf<N>(sg, G_DNU * L::NL + I0, dnu);
+        stf<N>(sg, G_DNUB * L::NL + I0, dnub);
     }
-    stf<N>(sg, G_DZ1 * NL + I0, dz1);
-    stf<N>(sg, G_DS1 * NL + I0, ds1);
-    stf<N>(sg, G_DZ2 * NL + I0, dz2);
-    stf<N>(sg, G_DS2 * NL + I0, ds2);
+    stf<N>(sg, G_DZ1 * L::NL + I0, dz1);
+    stf<N>(sg, G_DS1 * L::NL + I0, ds1);
+    stf<N>(sg, G_DZ2 * L::NL + I0, dz2);
+    stf<N>(sg, G_DS2 * L::NL + I0, ds2);
 }
+template <class P>
 PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const int pass = uniformInt(passIn);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     const unsigned act = v.act;
@@ -1394,12 +1453,12 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
         double cv = 0., bs = 0.;
         if (v.vsg)
         {
-            double S[NL], vl[NL], bcl[NL];
-            ldf<NL>(dy, DY_S, S);
-            ldf<NL>(sg, G_VL * NL, vl);
-            ldf<NL>(sg, G_BCL * NL, bcl);
+            double S[L::NL], vl[L::NL], bcl[L::NL];
+            ldf<L::NL>(dy, L::DY_S, S);
+            ldf<L::NL>(sg, G_VL * L::NL, vl);
+            ldf<L::NL>(sg, G_BCL * L::NL, bcl);
 #pragma unroll
-            for (int i = 0; i < NL; i++)
+            for (int i = 0; i < L::NL; i++)
             {
                 cv -= S[i] * vl[i];
                 bs -= S[i] * bcl[i];
@@ -1425,14 +1484,14 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
     double ainv = 0., finite_chk = g.dsig * 0. + g.ddsg * 0.;
     if (v.vst)
     {
-        double Ld[NS];
+        double Ld[L::NS];
         {
             double dw[NV], bcw[NV], hdw[NV], uh[3];
-            ldf<NV>(st, F_VW, dw);
-            ldf<NV>(st, F_BCW, bcw);
-            ldf<NV>(st, F_HDW, hdw);
-            ldf<3>(st, F_UHAT, uh);
-            const double bxd = st[F_BXD], hdd = st[F_HDD];
+            ldf<NV>(st, L::F_VW, dw);
+            ldf<NV>(st, L::F_BCW, bcw);
+            ldf<NV>(st, L::F_HDW, hdw);
+            ldf<3>(st, L::F_UHAT, uh);
+            const double bxd = st[L::F_BXD], hdd = st[L::F_HDD];
             double acc = 0.;
 #pragma unroll
             for (int j = 0; j < NV; j++)
@@ -1444,58 +1503,46 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
             const double ddl = (ip[IP_SCVX] != 0.) ? 0. : (bxd - acc) / hdd;
             if (pass != 0) // the predictor's dw / ddelta are consumed in this phase only
             {
-                stf<NV>(st, F_DW, dw);
-                st[F_DDL] = ddl;
+                stf<NV>(st, L::F_DW, dw);
+                st[L::F_DDL] = ddl;
             }
-            Lmul(ip, act, dw, ddl, uh, Ld);
+            Lmul<P>(ip, act, dw, ddl, uh, Ld);
         }
-        double a0 = coneDir<C1, 17>(st, 0, om, Ld, pass != 0);
-        ainv = a0 > ainv ? a0 : ainv;
-        if (act & 2u)
-        {
-            a0 = coneDir<C2, 3>(st, 1, om, Ld, pass != 0);
-            ainv = a0 > ainv ? a0 : ainv;
-        }
-        if (act & 4u)
-        {
-            a0 = coneDir<C3, 3>(st, 2, om, Ld, pass != 0);
-            ainv = a0 > ainv ? a0 : ainv;
-        }
-        if (act & 8u)
-        {
-            a0 = coneDir<C4, 3>(st, 3, om, Ld, pass != 0);
-            ainv = a0 > ainv ? a0 : ainv;
-        }
-        a0 = coneDir<C5, 4>(st, 4, om, Ld, pass != 0);
-        ainv = a0 > ainv ? a0 : ainv;
-        a0 = coneDir<C6, 3>(st, 5, om, Ld, pass != 0);
-        ainv = a0 > ainv ? a0 : ainv;
-        {
-            double sv[2], zv[2], rz[2], tz[2], dzv[2], dsv[2];
-            ldf<2>(st, F_S + L1, sv);
-            ldf<2>(st, F_Z + L1, zv);
-            ldf<2>(st, F_RZ + L1, rz);
-            ldf<2>(st, F_TZ + L1, tz);
-#pragma unroll
-            for (int w = 0; w < 2; w++)
+        forEachCone<P>([&](auto ci) {
+            constexpr int C = decltype(ci)::value;
+            if (act & (1u << C))
             {
-                const bool on = act & (1u << (6 + w));
-                dzv[w] = on ? -(zv[w] / sv[w]) * Ld[L1 + w] + tz[w] : 0.;
-                dsv[w] = on ? -om * rz[w] + Ld[L1 + w] : 0.;
+                const double a0 = coneDir<P, L::coneOff(C), L::coneDim(C)>(st, C, om, Ld, pass != 0);
+                ainv = a0 > ainv ? a0 : ainv;
+            }
+        });
+        {
+            constexpr int NLP = P::NLP, LP0 = L::LP0;
+            double sv[NLP], zv[NLP], rz[NLP], tz[NLP], dzv[NLP], dsv[NLP];
+            ldf<NLP>(st, L::F_S + LP0, sv);
+            ldf<NLP>(st, L::F_Z + LP0, zv);
+            ldf<NLP>(st, L::F_RZ + LP0, rz);
+            ldf<NLP>(st, L::F_TZ + LP0, tz);
+#pragma unroll
+            for (int w = 0; w < NLP; w++)
+            {
+                const bool on = act & (1u << (L::NCONES + w));
+                dzv[w] = on ? -(zv[w] / sv[w]) * Ld[LP0 + w] + tz[w] : 0.;
+                dsv[w] = on ? -om * rz[w] + Ld[LP0 + w] : 0.;
                 const double a1 = on ? -dsv[w] / sv[w] : 0., a2 = on ? -dzv[w] / zv[w] : 0.;
                 ainv = a1 > ainv ? a1 : ainv;
                 ainv = a2 > ainv ? a2 : ainv;
             }
-            stf<2>(st, F_DZ + L1, dzv);
-            stf<2>(st, F_DS + L1, dsv);
+            stf<NLP>(st, L::F_DZ + LP0, dzv);
+            stf<NLP>(st, L::F_DS + LP0, dsv);
         }
     }
     double sumdnb = 0.;
     if (v.vsg)
     {
-        dirSegChunk<0, 5>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
-        dirSegChunk<5, 5>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
-        dirSegChunk<10, 4>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        dirSegChunk<P, 0, L::SC1>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        dirSegChunk<P, L::SC1, L::SC2>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        dirSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
     }
     sumdnb = wave_sum(sumdnb);
     // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
@@ -1570,10 +1617,12 @@ __device__ inline void axpyFields(const SV &rec, int fDst, int fSrc, double alph
     for (int i = 0; i < N; i++)
         rec[fDst + i] = d[i] + alpha * x[i];
 }
+template <class P>
 PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const Views v = makeViews(c);
+    const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg;
     Glob g = loadPriv(gp);
     const double alpha = ip_->alpha;
@@ -1583,27 +1632,28 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 #pragma unroll
         for (int j = 0; j < NV; j++)
         {
-            d[j] = st[F_W + j];
-            x[j] = st[F_DW + j];
+            d[j] = st[L::F_W + j];
+            x[j] = st[L::F_DW + j];
         }
 #pragma unroll
         for (int j = 0; j < NV; j++)
-            st[F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
-        axpyFields<1>(st, F_DL, F_DDL, alpha);
-        axpyFields<18>(st, F_S, F_DS, alpha);
-        axpyFields<NS - 18>(st, F_S + 18, F_DS + 18, alpha);
-        axpyFields<18>(st, F_Z, F_DZ, alpha);
-        axpyFields<NS - 18>(st, F_Z + 18, F_DZ + 18, alpha);
+            st[L::F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
+        axpyFields<1>(st, L::F_DL, L::F_DDL, alpha);
+        constexpr int H1 = (L::NS + 1) / 2, H2 = L::NS - H1;
+        axpyFields<H1>(st, L::F_S, L::F_DS, alpha);
+        axpyFields<H2>(st, L::F_S + H1, L::F_DS + H1, alpha);
+        axpyFields<H1>(st, L::F_Z, L::F_DZ, alpha);
+        axpyFields<H2>(st, L::F_Z + H1, L::F_DZ + H1, alpha);
     }
     if (v.vsg)
     {
-        axpyFields<NL>(sg, G_NU * NL, G_DNU * NL, alpha);
-        axpyFields<NL>(sg, G_NUB * NL, G_DNUB * NL, alpha);
-        axpyFields<NL>(sg, G_LAM * NL, G_DLAM * NL, alpha);
-        axpyFields<NL>(sg, G_S1 * NL, G_DS1 * NL, alpha);
-        axpyFields<NL>(sg, G_Z1 * NL, G_DZ1 * NL, alpha);
-        axpyFields<NL>(sg, G_S2 * NL, G_DS2 * NL, alpha);
-        axpyFields<NL>(sg, G_Z2 * NL, G_DZ2 * NL, alpha);
+        axpyFields<L::NL>(sg, G_NU * L::NL, G_DNU * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_NUB * L::NL, G_DNUB * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_LAM * L::NL, G_DLAM * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_S1 * L::NL, G_DS1 * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_Z1 * L::NL, G_DZ1 * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_S2 * L::NL, G_DS2 * L::NL, alpha);
+        axpyFields<L::NL>(sg, G_Z2 * L::NL, G_DZ2 * L::NL, alpha);
     }
     g.sig += alpha * g.dsig;
     g.dsg += alpha * g.ddsg;
@@ -1631,8 +1681,11 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 #define PROF_T(var)
 #define PROF_ADD(slot, t0, t1)
 #endif
+template <class P>
 __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArgs a)
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
 #ifdef IPM_PROFILE
     double prof[12] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
     const long long t_kernel0 = clock64();
@@ -1647,13 +1700,13 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     Ctx c;
     c.K = K;
     c.lane = lane;
-    double *ws = a.ws + size_t(inst) * workspaceDoubles(K);
+    double *ws = a.ws + size_t(inst) * workspaceDoubles<P>(K);
     c.st = ws;
     c.pitch = recPitch(K);
-    c.sg = ws + size_t(c.pitch) * STREC;
-    c.dy = c.sg + size_t(c.pitch) * SEGREC;
-    c.fac = c.dy + size_t(c.pitch) * DYNREC;
-    c.sv = c.fac + size_t(K) * FACREC;
+    c.sg = ws + size_t(c.pitch) * L::STREC;
+    c.dy = c.sg + size_t(c.pitch) * (G_NFIELDS * L::NL);
+    c.fac = c.dy + size_t(c.pitch) * L::DYNREC;
+    c.sv = c.fac + size_t(K) * L::FACREC;
     c.gsave = c.sv + size_t(K) * SVREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
     c.B = a.Bm + size_t(inst) * (K - 1) * NX * NU;
@@ -1700,31 +1753,31 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     // a warm start that breaks down is repeated from ECOS's cold initialisation (attempt 1)
     for (int attempt = 0; attempt < 2; attempt++)
     {
-    phSetup(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
+    phSetup<P>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
     if (warm)
     {
         // sub-problems of consecutive SC iterations are close: restart from the previous primal-dual point
-        phWarmInit(cs, gp, itp);
+        phWarmInit<P>(cs, gp, itp);
     }
     else
     {
         // =============== initialisation (ECOS init, W = I) ===============
-        phInitPrimalRhs(cs, gp, itp);
+        phInitPrimalRhs<P>(cs, gp, itp);
         {
-            const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-            factorSweepFused(cs, sh, sp);
-            bwdSweep(cs, sp);
+            const RhsSpec sp = specBorderPlus(L::F_BETA, G_RHO, L::F_VW, G_VL);
+            factorSweepFused<P>(cs, sh, sp);
+            bwdSweep<P>(cs, sp);
         }
-        phInitPrimalFinish(cs, gp, itp);
-        phInitDualRhs(cs, gp, itp);
+        phInitPrimalFinish<P>(cs, gp, itp);
+        phInitDualRhs<P>(cs, gp, itp);
         {
-            const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-            fwdSweep(cs, sp);
-            bwdSweep(cs, sp);
+            const RhsSpec sp = specSingle(L::F_BETA, G_RHO, L::F_VW, G_VL);
+            fwdSweep<P>(cs, sp);
+            bwdSweep<P>(cs, sp);
         }
-        phInitDualFinish(cs, gp, itp);
+        phInitDualFinish<P>(cs, gp, itp);
     }
-    phDataNorms(cs, gp, itp);
+    phDataNorms<P>(cs, gp, itp);
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
 
@@ -1738,7 +1791,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     for (iter = 0;; iter++)
     {
         PROF_T(tr0);
-        phResiduals(cs, gp, itp);
+        phResiduals<P>(cs, gp, itp);
         PROF_T(tr1);
         PROF_ADD(1, tr0, tr1);
         {
@@ -1769,7 +1822,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 break;
             }
         }
-        phScalings(cs, gp, itp);
+        phScalings<P>(cs, gp, itp);
         PROF_T(tr2);
         PROF_ADD(2, tr1, tr2);
         if (it.bad)
@@ -1780,34 +1833,34 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         for (int pass = 0; pass < 2; pass++)
         {
             PROF_T(tq0);
-            phRhs(cs, gp, itp, pass);
+            phRhs<P>(cs, gp, itp, pass);
             PROF_T(tq1);
             PROF_ADD(4, tq0, tq1);
             if (pass == 0)
             {
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
                 // column and of the affine right-hand side
-                const RhsSpec sp = specBorderPlus(F_BETA, G_RHO, F_VW, G_VL);
-                factorSweepFused(cs, sh, sp);
+                const RhsSpec sp = specBorderPlus(L::F_BETA, G_RHO, L::F_VW, G_VL);
+                factorSweepFused<P>(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
-                bwdSweep(cs, sp);
+                bwdSweep<P>(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             else
             {
-                const RhsSpec sp = specSingle(F_BETA, G_RHO, F_VW, G_VL);
-                fwdSweep(cs, sp);
+                const RhsSpec sp = specSingle(L::F_BETA, G_RHO, L::F_VW, G_VL);
+                fwdSweep<P>(cs, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
-                bwdSweep(cs, sp);
+                bwdSweep<P>(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             PROF_T(tq2);
             PROF_ADD(5, tq1, tq2);
-            phDirection(cs, gp, itp, pass);
+            phDirection<P>(cs, gp, itp, pass);
             PROF_T(tq3);
             PROF_ADD(6, tq2, tq3);
             if (it.bad)
@@ -1819,7 +1872,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             break;
         }
         PROF_T(tu0);
-        phUpdate(cs, gp, itp);
+        phUpdate<P>(cs, gp, itp);
         PROF_T(tu1);
         PROF_ADD(7, tu0, tu1);
     }
@@ -1832,9 +1885,9 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     iter = iter_total;
     // =============== outputs: readSolution + SC bookkeeping ===============
     const bool vst = k < K;
-    const SV st = makeSV(c.st, STREC, unsigned(vst ? k : 0), c.pitch);
+    const SV st = makeSV(c.st, L::STREC, unsigned(vst ? k : 0), c.pitch);
     // W / delta to report: the current iterate, or the restored best one (use_backup)
-    const int fW = use_backup ? int(F_WBK) : int(F_W);
+    const int fW = use_backup ? int(L::F_WBK) : int(L::F_W);
     double sum_delta = 0.;
     if (vst)
         sum_delta = st[fW + 16];
@@ -1866,12 +1919,13 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         if (vst)
         {
             double *Xo = a.X + (size_t(inst) * K + k) * NX, *Uo = a.U + (size_t(inst) * K + k) * NU;
-            for (int j = 0; j < 13; j++)
-                Xo[j] = st[fW + j];
-            Xo[13] = 0.;
-            for (int j = 0; j < 3; j++)
-                Uo[j] = st[fW + 13 + j];
-            Uo[3] = 0.;
+            // states / inputs the table pins for the whole horizon are written as their constant (0)
+#pragma unroll
+            for (int i = 0; i < NX; i++)
+                Xo[i] = L::XINV.v[i] >= 0 ? double(st[fW + (L::XINV.v[i] >= 0 ? L::XINV.v[i] : 0)]) : 0.;
+#pragma unroll
+            for (int i = 0; i < NU; i++)
+                Uo[i] = L::UINV.v[i] >= 0 ? double(st[fW + (L::UINV.v[i] >= 0 ? L::UINV.v[i] : 0)]) : 0.;
         }
         if (lane == 0 && c.ip[IP_SCVX] == 0.)
             a.sigma[inst] = sig; // SCvx: fixed final time (the sigma block is a decoupled dummy)

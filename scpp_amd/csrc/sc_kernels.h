@@ -176,6 +176,118 @@ __global__ void sc_setup_kernel(SCBuffers b, scpp_rocketquat_params mp, scpp_sc_
     scSetupOne(b, mp, so, warm, i, b.x_init_dim + i * 14, 0, 1);
 }
 
+// ---- Rocket2d: Parameters::nondimensionalize (rocket2d.cpp:200-216), getInitializedTrajectory (:120-135),
+//      getNewModelParameters (:143-148), (non|re)dimensionalizeTrajectory (:96-118).  One thread per instance. ----
+__device__ inline void scSetupOneR2d(const SCBuffers &b, const scpp_rocket2d_params &mp, const scpp_sc_opts &so, int warm, long i,
+                                     const double *xi)
+{
+    using namespace ipm;
+    const int K = b.K;
+    double *ip = b.ip + i * IP_N;
+    double m_scale = 1., r_scale = 1.;
+    if (so.nondimensionalize)
+    {
+        r_scale = sqrt(xi[0] * xi[0] + xi[1] * xi[1]);
+        m_scale = mp.m;
+    }
+    double x0[6], xf[6];
+    for (int j = 0; j < 6; j++)
+    {
+        x0[j] = xi[j];
+        xf[j] = mp.x_final[j];
+    }
+    for (int j = 0; j < 4; j++)
+    {
+        x0[j] /= r_scale;
+        xf[j] /= r_scale;
+    }
+    for (int j = 0; j < IP_N; j++)
+        ip[j] = 0.;
+    for (int j = 0; j < 6; j++)
+    {
+        ip[IP_XINIT + j] = x0[j];
+        ip[IP_XFINAL + j] = xf[j];
+    }
+    const double T_min = mp.T_min / (m_scale * r_scale), T_max = mp.T_max / (m_scale * r_scale);
+    ip[IP_GS] = tan(mp.gamma_gs);
+    ip[IP_TILT] = mp.theta_max;
+    ip[IP_WMAX] = mp.w_B_max;
+    ip[IP_TMIN] = T_min;
+    ip[IP_TMAX] = T_max;
+    ip[IP_GIM] = mp.gimbal_max;
+    ip[IP_WT] = so.weight_time;
+    ip[IP_WTRT] = so.weight_trust_region_time;
+    ip[IP_WTRX] = so.weight_trust_region_trajectory;
+    ip[IP_WVC] = so.weight_virtual_control;
+    ip[IP_PAR + 0] = mp.m / m_scale;
+    ip[IP_PAR + 1] = mp.J_B / (m_scale * r_scale * r_scale);
+    ip[IP_PAR + 2] = mp.g_I[0] / r_scale;
+    ip[IP_PAR + 3] = mp.g_I[1] / r_scale;
+    ip[IP_PAR + 4] = mp.r_T_B[0] / r_scale;
+    ip[IP_PAR + 5] = mp.r_T_B[1] / r_scale;
+    ip[IP_MSCALE] = m_scale;
+    ip[IP_RSCALE] = r_scale;
+    ip[IP_FINALTIME] = mp.final_time;
+    double *X = b.X + i * K * 6, *U = b.U + i * K * 2;
+    for (int k = 0; k < K; k++)
+    {
+        double *x = X + k * 6, *u = U + k * 2;
+        if (!warm)
+        {
+            const double a1 = double(K - k) / K, a2 = double(k) / K;
+            for (int j = 0; j < 6; j++)
+                x[j] = a1 * x0[j] + a2 * xf[j];
+            u[0] = 0.;
+            u[1] = (T_max + T_min) / 2.;
+        }
+        else
+        {
+            for (int j = 0; j < 4; j++)
+                x[j] /= r_scale;
+            u[1] /= m_scale * r_scale;
+        }
+        double *uh = b.uhat + (i * K + k) * 3; // no linearised-thrust row in this model's table
+        uh[0] = 0.;
+        uh[1] = 0.;
+        uh[2] = 1.;
+    }
+    if (!warm)
+    {
+        b.sigma[i] = mp.final_time;
+        b.wtrx[i] = so.weight_trust_region_trajectory;
+    }
+    b.active[i] = 1;
+    b.converged[i] = 0;
+    b.sc_iters[i] = 0;
+    b.ipm_iters[i] = 0;
+    b.status[i] = 0;
+    b.norm1_nu[i] = 0.;
+    b.sum_delta[i] = 0.;
+    b.delta_sigma[i] = 0.;
+}
+__global__ void sc_setup_r2d_kernel(SCBuffers b, scpp_rocket2d_params mp, scpp_sc_opts so, int warm)
+{
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    scSetupOneR2d(b, mp, so, warm, i, b.x_init_dim + i * 6);
+}
+__global__ void sc_redim_r2d_kernel(SCBuffers b)
+{
+    using namespace ipm;
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.B)
+        return;
+    const double m_scale = b.ip[i * IP_N + IP_MSCALE], r_scale = b.ip[i * IP_N + IP_RSCALE];
+    for (int k = 0; k < b.K; k++)
+    {
+        double *x = b.X + (i * b.K + k) * 6, *u = b.U + (i * b.K + k) * 2;
+        for (int j = 0; j < 4; j++)
+            x[j] *= r_scale;
+        u[1] *= m_scale * r_scale;
+    }
+}
+
 // factor that redimensionalises entry j of a state (input) vector
 __device__ inline double redimX(int j, double m_scale, double r_scale) { return j == 0 ? m_scale : (j < 7 ? r_scale : 1.); }
 __device__ inline double redimU(int j, double m_scale, double r_scale)

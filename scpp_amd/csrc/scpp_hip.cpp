@@ -68,6 +68,7 @@ struct scpp_hip_ctx
     double *sim_dt = nullptr, *sim_u0 = nullptr, *sim_u1 = nullptr, *sim_x = nullptr;
     scpp_sc_opts sc{};
     scpp_rocketquat_params mp{};
+    scpp_rocket2d_params mp2{};
     scpp_socp_opts socp{1e-8, 1e-7, 1e-7, 60, 1};
     bool sc_ready = false, par_from_ip = false;
     int mode = SCPP_MODE_FOH | SCPP_MODE_VT;
@@ -267,9 +268,9 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
     SCBuffers b = scBuffers(c);
     const size_t f = size_t(r.first), K = size_t(c->K);
     b.B = r.count;
-    b.x_init_dim += f * 14;
-    b.X += f * K * 14;
-    b.U += f * K * 4;
+    b.x_init_dim += f * size_t(c->nx);
+    b.X += f * K * size_t(c->nx);
+    b.U += f * K * size_t(c->nu);
     b.sigma += f;
     b.ip += f * ipm::IP_N;
     b.uhat += f * K * 3;
@@ -288,20 +289,21 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
 int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0, bool snapshot = false)
 {
     ipm::KernelArgs a;
-    const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1;
+    const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1, nx = size_t(c->nx), nu = size_t(c->nu);
+    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
     a.B = r.count;
     a.K = c->K;
-    a.X = c->X + f * K * 14;
-    a.U = c->U + f * K * 4;
+    a.X = c->X + f * K * nx;
+    a.U = c->U + f * K * nu;
     a.sigma = c->sigma + f;
-    a.A = c->A + f * seg * 14 * 14;
-    a.Bm = c->Bm + f * seg * 14 * 4;
-    a.C = c->C + f * seg * 14 * 4;
-    a.S = c->S + f * seg * 14;
-    a.Z = c->Z + f * seg * 14;
+    a.A = c->A + f * seg * nx * nx;
+    a.Bm = c->Bm + f * seg * nx * nu;
+    a.C = c->C + f * seg * nx * nu;
+    a.S = c->S + f * seg * nx;
+    a.Z = c->Z + f * seg * nx;
     a.ip = c->ip + f * ipm::IP_N;
     a.uhat = c->uhat + f * K * 3;
-    a.ws = c->ws + f * ipm::workspaceDoubles(c->K);
+    a.ws = c->ws + f * (rq ? ipm::workspaceDoubles<ipm::RocketQuatSC>(c->K) : ipm::workspaceDoubles<ipm::Rocket2dSC>(c->K));
     a.wtrx = c->wtrx + f;
     a.active = (do_sc_update || masked) ? c->active + f : nullptr;
     a.converged = c->converged + f;
@@ -316,8 +318,8 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     a.max_sc_iterations = c->sc.max_iterations;
     a.warm = c->ipm_warm + f;
     a.do_sc_update = do_sc_update;
-    a.Xold = snapshot ? c->vx_Xold + f * K * 14 : nullptr;
-    a.Uold = snapshot ? c->vx_Uold + f * K * 4 : nullptr;
+    a.Xold = snapshot ? c->vx_Xold + f * K * nx : nullptr;
+    a.Uold = snapshot ? c->vx_Uold + f * K * nu : nullptr;
     a.opt.feastol = c->socp.feastol;
     a.opt.abstol = c->socp.abstol;
     a.opt.reltol = c->socp.reltol;
@@ -327,13 +329,28 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     a.dbg = c->dbg + f * 32;
     const bool timed = spanBegin(c, 1, ninst, r.stream);
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
-    hipLaunchKernelGGL(ipm::ipm_kernel, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+    // one instantiation of the solver per model table (csrc/constraint_table.h)
+    if (rq)
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+    else
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::Rocket2dSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
     spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked = false)
 {
     return launchIpm(c, do_sc_update, ninst, masked, fullRange(c));
+}
+
+// the interior-point workspace (0.77 MB per RocketQuat instance at K = 50) is allocated by the first SC / SCvx set-up, so that
+// contexts used for discretisation or linear MPC only do not carry it
+int ensureWorkspace(scpp_hip_ctx *c)
+{
+    if (c->ws)
+        return 0;
+    const size_t per = c->model == SCPP_MODEL_ROCKETQUAT ? ipm::workspaceDoubles<ipm::RocketQuatSC>(c->K)
+                                                          : ipm::workspaceDoubles<ipm::Rocket2dSC>(c->K);
+    return devAlloc(&c->ws, size_t(c->Bmax) * per) ? SCPP_E_HIP : 0;
 }
 
 int countActive(scpp_hip_ctx *c, int *n)
@@ -426,13 +443,11 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     rc |= devAlloc(&c->norm1_nu, B);
     rc |= devAlloc(&c->sum_delta, B);
     rc |= devAlloc(&c->delta_sigma, B);
-    if (model_id == SCPP_MODEL_ROCKETQUAT)
     {
-        rc |= devAlloc(&c->x_init, B * 14);
+        rc |= devAlloc(&c->x_init, B * nx);
         rc |= devAlloc(&c->ip, B * ipm::IP_N);
         rc |= devAlloc(&c->uhat, B * K * 3);
         rc |= devAlloc(&c->wtrx, B);
-        rc |= devAlloc(&c->ws, B * ipm::workspaceDoubles(K));
         rc |= devAlloc(&c->dbg, B * 32);
     }
     if (rc)
@@ -596,6 +611,8 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
+    if (int rc = ensureWorkspace(c))
+        return rc;
     c->B = B;
     c->mp = *mp;
     c->sc = *so;
@@ -606,6 +623,37 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     c->scvx_ready = false;
     SCBuffers b = scBuffers(c);
     hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
+    c->sc_ready = true;
+    c->par_from_ip = true;
+    c->last_active = B;
+    return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
+}
+
+int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_sc_opts *so, const double *x_init,
+                               int B, int warm_start)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKET2D)
+        return SCPP_E_UNSUPPORTED;
+    /* the configuration SC_oneshot runs for Rocket2d: free final time, first-order hold (config/Rocket2D/SC.info) */
+    if (so->K != c->K || !so->free_final_time || !so->interpolate_input)
+        return SCPP_E_UNSUPPORTED;
+    if (warm_start && (!c->sc_ready || B != c->B))
+        return SCPP_E_STATE;
+    if (int rc = ensureWorkspace(c))
+        return rc;
+    c->B = B;
+    c->mp2 = *mp;
+    c->sc = *so;
+    c->mode = SCPP_MODE_FOH | SCPP_MODE_VT;
+    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!warm_start)
+        CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
+    c->scvx_ready = false;
+    SCBuffers b = scBuffers(c);
+    hipLaunchKernelGGL(sc_setup_r2d_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp2, c->sc, warm_start);
     c->sc_ready = true;
     c->par_from_ip = true;
     c->last_active = B;
@@ -661,7 +709,10 @@ int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
     if (c->sc.nondimensionalize)
     {
         SCBuffers b = scBuffers(c);
-        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
+        if (c->model == SCPP_MODEL_ROCKETQUAT)
+            hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
+        else
+            hipLaunchKernelGGL(sc_redim_r2d_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
     }
     CHECK_HIP(hipStreamSynchronize(c->stream));
     if (n_converged)
@@ -775,6 +826,8 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->scvx_ready || B != c->B))
         return SCPP_E_STATE;
+    if (int rc = ensureWorkspace(c))
+        return rc;
     if (!c->vx_tr)
     {
         const size_t Bm = size_t(c->Bmax), K = size_t(c->K);

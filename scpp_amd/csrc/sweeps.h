@@ -75,6 +75,7 @@ __device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 r
     return i == 0 ? 2 : 0;
 }
 
+template <class P>
 __device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
@@ -87,8 +88,10 @@ __device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane
     }
     return t;
 }
+template <class P>
 __device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
+    constexpr int NL = Lay<P>::NL, NX = P::NX;
     const int g = lane >> 4, i = lane & 15;
     Tile t = tileZero();
     const int kind = colKind(sp, i);
@@ -163,38 +166,56 @@ struct HRaw
 {
     double e2, cc, wcol, wrow[4], hs[4];
 };
-__device__ inline HRaw loadHRaw(const Ctx &c, int k, int lane)
+// position of this lane's four tile entries (g + 4r, i) in the small-block record (-1: outside the pattern); depends on the
+// lane only, so a sweep looks it up once instead of once per stage
+struct HsLane
+{
+    int idx[4];
+};
+template <class P>
+__device__ inline HsLane hsLane(int lane)
 {
     const int g = lane >> 4, i = lane & 15;
-    const SV st = makeSV(c.st, STREC, unsigned(k), c.pitch);
+    HsLane h;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        h.idx[r] = hsIndex<P>(g + 4 * r, i);
+    return h;
+}
+template <class P>
+__device__ inline HRaw loadHRaw(const Ctx &c, const HsLane &hl, int k, int lane)
+{
+    using L = Lay<P>;
+    const int g = lane >> 4, i = lane & 15;
+    const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
     HRaw h;
-    h.e2 = st[F_HC];
-    h.cc = st[F_HC + 1];
-    h.wcol = st.dyn(F_WB + 1 + i);
+    h.e2 = st[L::F_HC];
+    h.cc = st[L::F_HC + 1];
+    h.wcol = st.dyn(L::F_WB + 1 + i);
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
         const int row = g + 4 * r;
-        h.wrow[r] = st.dyn(F_WB + 1 + row);
-        const int idx = hsIndex(row, i);
-        h.hs[r] = st.dyn(F_HS + (idx >= 0 ? idx : 0));
+        h.wrow[r] = st.dyn(L::F_WB + 1 + row);
+        h.hs[r] = st.dyn(L::F_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0));
     }
     return h;
 }
 // H_k (16x16, delta_k eliminated, fixed variables -> identity rows) as a D-layout tile
-__device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane, bool scvx)
+template <class P>
+__device__ inline Tile buildHTile(const HRaw &h, const HsLane &hl, int k, int K, int lane, bool scvx)
 {
     const int g = lane >> 4, i = lane & 15;
-    const unsigned fm = fixedMask(k, K);
+    const unsigned fm = Lay<P>::fixedMask(k, K);
     Tile t;
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
         const int row = g + 4 * r;
         double v = h.e2 * ((row == i ? 1. : 0.) - h.cc * h.wrow[r] * h.wcol);
-        if (scvx && (row < 13 || i < 13)) // SCvx: the trust cone has no state rows
+        if (scvx && (row < P::NXV || i < P::NXV)) // SCvx: the trust cone has no state rows
             v = 0.;
-        if (hsIndex(row, i) >= 0)
+        if (hl.idx[r] >= 0)
             v += h.hs[r];
         if ((fm & (1u << row)) || (fm & (1u << i)))
             v = (row == i) ? 1. : 0.;
@@ -203,17 +224,31 @@ __device__ inline Tile buildHTile(const HRaw &h, int k, int K, int lane, bool sc
     return t;
 }
 // raw entries of [A|B] / C arranged for the M' and N tiles (mask and sign applied at use)
+// state / input column a stage variable reads from A / B (lane-dependent index: small constant table)
+template <class P>
+__device__ inline int varColumn(int j)
+{
+    using L = Lay<P>;
+    if constexpr (L::IDENTITY_MAPS)
+        return j < P::NXV ? j : (j < L::NVU ? j - P::NXV : 0); // no table look-up on the sweeps' critical path
+    else
+        return j < P::NXV ? P::XMAP[j] : (j < L::NVU ? P::UMAP[j - P::NXV] : 0);
+}
+template <class P>
 __device__ inline Tile loadMtRaw(const Ctx &c, int k, int lane) // entry (var j = g+4r, dyn row i)
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
     Tile t = tileZero();
-    if (i < NL)
+    if (i < L::NL)
     {
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
             const int j = g + 4 * r;
-            t.v[r] = j < 13 ? c.A[size_t(k) * NX * NX + i * NX + j] : c.B[size_t(k) * NX * NU + i * NU + (j - 13)];
+            if (j < L::NVU)
+                t.v[r] = j < P::NXV ? c.A[size_t(k) * NX * NX + i * NX + varColumn<P>(j)] : c.B[size_t(k) * NX * NU + i * NU + varColumn<P>(j)];
         }
     }
     return t;
@@ -227,24 +262,29 @@ __device__ inline Tile finishMt(const Tile &raw, unsigned fm, int lane)
         t.v[r] = (fm & (1u << (g + 4 * r))) ? 0. : -raw.v[r];
     return t;
 }
+template <class P>
 __device__ inline Tile loadNRaw(const Ctx &c, int k, int lane) // entry (dyn row g+4r, var i): only the C part is loaded
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
     Tile t = tileZero();
-    if (i >= 13)
+    if (i >= P::NXV && i < L::NVU)
     {
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
             const int row = g + 4 * r;
-            if (row < NL)
-                t.v[r] = c.C[size_t(k) * NX * NU + row * NU + (i - 13)];
+            if (row < L::NL)
+                t.v[r] = c.C[size_t(k) * NX * NU + row * NU + varColumn<P>(i)];
         }
     }
     return t;
 }
+template <class P>
 __device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
 {
+    using L = Lay<P>;
     const int g = lane >> 4, i = lane & 15;
     Tile t;
 #pragma unroll
@@ -252,29 +292,37 @@ __device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
     {
         const int row = g + 4 * r;
         double v = 0.;
-        if (row < NL && !(fmn & (1u << i)))
-            v = i < 13 ? (row == i ? 1. : 0.) : -raw.v[r];
+        if (row < L::NL && !(fmn & (1u << i)))
+            v = i < P::NXV ? (row == varColumn<P>(i) ? 1. : 0.) : -raw.v[r];
         t.v[r] = v;
     }
     return t;
 }
 
 // N' tile: entry (var a = g+4r, dyn row b = i) = N[b][a]; only the C part is loaded
+template <class P>
 __device__ inline Tile loadNtRaw(const Ctx &c, int k, int lane)
 {
+    using L = Lay<P>;
+    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
     Tile t = tileZero();
 #pragma unroll
-    for (int r = 3; r < 4; r++) // variables 13..15 live in register 3 (a = 12 + g)
+    for (int r = 0; r < 4; r++)
     {
+        if (4 * r + 3 < P::NXV || 4 * r >= L::NVU) // this register holds no input variable (RocketQuat: inputs 13..15 live in register 3)
+            continue;
         const int a = g + 4 * r;
-        const double v = c.C[size_t(k) * NX * NU + (i < NL ? i : 0) * NU + (a >= 13 ? a - 13 : 0)];
-        t.v[r] = (i < NL && a >= 13) ? v : 0.;
+        const bool in = i < L::NL && a >= P::NXV && a < L::NVU;
+        const double v = c.C[size_t(k) * NX * NU + (i < L::NL ? i : 0) * NU + (in ? varColumn<P>(a) : 0)];
+        t.v[r] = in ? v : 0.;
     }
     return t;
 }
+template <class P>
 __device__ inline Tile finishNt(const Tile &raw, unsigned fmn, int lane)
 {
+    using L = Lay<P>;
     const int g = lane >> 4, i = lane & 15;
     Tile t;
 #pragma unroll
@@ -282,8 +330,8 @@ __device__ inline Tile finishNt(const Tile &raw, unsigned fmn, int lane)
     {
         const int a = g + 4 * r;
         double v = 0.;
-        if (i < NL && !(fmn & (1u << a)))
-            v = a < 13 ? (a == i ? 1. : 0.) : -raw.v[r];
+        if (i < L::NL && !(fmn & (1u << a)))
+            v = a < P::NXV ? (varColumn<P>(a) == i ? 1. : 0.) : -raw.v[r];
         t.v[r] = v;
     }
     return t;
@@ -298,16 +346,18 @@ struct FactorRest
     Tile mt, n, rl, rwn;
     double einv;
 };
+template <class P>
 __device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
+    constexpr int NL = Lay<P>::NL;
     const int i = lane & 15;
     FactorRest f;
     if (k < c.K - 1)
     {
-        f.mt = loadMtRaw(c, k, lane);
-        f.n = loadNRaw(c, k, lane);
-        f.rl = loadRhsL(c, sp, k, lane);
-        f.rwn = loadRhsW(c, sp, k + 1, lane);
+        f.mt = loadMtRaw<P>(c, k, lane);
+        f.n = loadNRaw<P>(c, k, lane);
+        f.rl = loadRhsL<P>(c, sp, k, lane);
+        f.rwn = loadRhsW<P>(c, sp, k + 1, lane);
         f.einv = c.sg[size_t(G_EINV * NL + (i < NL ? i : 0)) * c.pitch + k];
     }
     else
@@ -318,8 +368,11 @@ __device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int
     return f;
 }
 
+template <class P>
 SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
+    using L = Lay<P>;
+    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
@@ -328,17 +381,18 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
     const double dual_reg = scvx ? 1e-9 : 0.;
-    Tile Z = tileZero(), G = loadRhsW(c, sp, 0, lane);
-    HRaw hcur = loadHRaw(c, 0, lane);
+    Tile Z = tileZero(), G = loadRhsW<P>(c, sp, 0, lane);
+    const HsLane hl = hsLane<P>(lane);
+    HRaw hcur = loadHRaw<P>(c, hl, 0, lane);
     for (int k = 0; k < K; k++)
     {
-        const FactorRest cur = loadFactorRest(c, sp, k, lane); // arrives during the first elimination below
+        const FactorRest cur = loadFactorRest<P>(c, sp, k, lane); // arrives during the first elimination below
         HRaw hnxt = hcur;
         if (k + 1 < K)
-            hnxt = loadHRaw(c, k + 1, lane); // prefetch
+            hnxt = loadHRaw<P>(c, hl, k + 1, lane); // prefetch
         double *fk = c.fac + size_t(k) * FACREC;
         double *svk = c.sv + size_t(k) * SVREC;
-        Tile Phi = buildHTile(hcur, k, K, lane, scvx);
+        Tile Phi = buildHTile<P>(hcur, hl, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
         const Tile Li = INVCHOL<NV>(Phi, sh, lane);
@@ -348,9 +402,9 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         saveCols(svk, sp.n, lane, a);
         if (k == K - 1)
             break;
-        const unsigned fm = fixedMask(k, K), fmn = fixedMask(k + 1, K);
+        const unsigned fm = L::fixedMask(k, K), fmn = L::fixedMask(k + 1, K);
         const Tile Yt = mm(Lit, finishMt(cur.mt, fm, lane));
-        storeYt(fk + FAC_YT, lane, Yt);
+        storeYt<NL>(fk + FAC_YT, lane, Yt);
         Tile Th = mm(Yt, Yt);
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -362,7 +416,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const Tile Ti = INVCHOL<NL>(Th, sh, lane);
         storeTri<NL>(fk + FAC_TI, lane, Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
-        Z = mm(Tit, finishN(cur.n, fmn, lane));
+        Z = mm(Tit, finishN<P>(cur.n, fmn, lane));
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(Yt, a));
         const Tile cc = mm(Tit, gl);
         saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
@@ -376,39 +430,44 @@ struct FwdIn
 {
     Tile lit, yt, tit, ti, n, rl, rwn;
 };
+template <class P>
 __device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
+    using L = Lay<P>;
+    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
     const double *fk = c.fac + size_t(k) * FACREC;
     FwdIn f;
     f.lit = loadTriT<NV>(fk + FAC_LI, lane);
     if (k < c.K - 1)
     {
-        f.yt = loadYt(fk + FAC_YT, lane);
+        f.yt = loadYt<NL>(fk + FAC_YT, lane);
         f.tit = loadTriT<NL>(fk + FAC_TI, lane);
         f.ti = loadTri<NL>(fk + FAC_TI, lane);
-        f.n = loadNRaw(c, k, lane);
-        f.rl = loadRhsL(c, sp, k, lane);
-        f.rwn = loadRhsW(c, sp, k + 1, lane);
+        f.n = loadNRaw<P>(c, k, lane);
+        f.rl = loadRhsL<P>(c, sp, k, lane);
+        f.rwn = loadRhsW<P>(c, sp, k + 1, lane);
     }
     else
         f.yt = f.tit = f.ti = f.n = f.rl = f.rwn = tileZero();
     return f;
 }
+template <class P>
 SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
-    Tile G = loadRhsW(c, sp, 0, lane);
+    Tile G = loadRhsW<P>(c, sp, 0, lane);
     // two stages of loads in flight: the per-stage MFMA chain (~1k cycles) is much shorter than the loaded-HBM
     // latency, so a distance-1 prefetch still stalls every stage
-    FwdIn cur = loadFwdIn(c, sp, 0, lane);
-    FwdIn nx1 = K > 1 ? loadFwdIn(c, sp, 1, lane) : cur;
+    FwdIn cur = loadFwdIn<P>(c, sp, 0, lane);
+    FwdIn nx1 = K > 1 ? loadFwdIn<P>(c, sp, 1, lane) : cur;
     for (int k = 0; k < K; k++)
     {
         FwdIn nxt = nx1;
         if (k + 2 < K)
-            nx1 = loadFwdIn(c, sp, k + 2, lane);
+            nx1 = loadFwdIn<P>(c, sp, k + 2, lane);
         double *svk = c.sv + size_t(k) * SVREC;
         const Tile a = mm(cur.lit, G);
         saveCols(svk, sp.n, lane, a);
@@ -418,26 +477,29 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         const Tile cc = mm(cur.tit, gl);
         saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
         // Z' cc = N' (Ti' cc)
-        G = tileAdd(cur.rwn, mm(finishN(cur.n, fixedMask(k + 1, K), lane), mm(cur.ti, cc)));
+        G = tileAdd(cur.rwn, mm(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mm(cur.ti, cc)));
         cur = nxt;
     }
     WAVE_SYNC();
 }
 
+template <class P>
 __device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &x)
 {
     const int g = lane >> 4, i = lane & 15;
     const int kind = colKind(sp, i);
     if (kind)
     {
-        const int f = kind == 1 ? int(F_BCW) : sp.fOut;
+        const int f = kind == 1 ? int(Lay<P>::F_BCW) : sp.fOut;
 #pragma unroll
         for (int r = 0; r < 4; r++)
             c.st[size_t(f + g + 4 * r) * c.pitch + k] = x.v[r];
     }
 }
+template <class P>
 __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &l)
 {
+    constexpr int NL = Lay<P>::NL;
     const int g = lane >> 4, i = lane & 15;
     const int kind = colKind(sp, i);
     if (kind)
@@ -457,8 +519,11 @@ struct BwdIn
 {
     Tile nt, tit, ti, y, li, cs, as;
 };
+template <class P>
 __device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
 {
+    using L = Lay<P>;
+    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
     const double *fk = c.fac + size_t(k) * FACREC;
     const double *svk = c.sv + size_t(k) * SVREC;
     BwdIn b;
@@ -466,29 +531,31 @@ __device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
     b.as = loadCols(svk, sp.n, lane);
     if (k < c.K - 1)
     {
-        b.nt = loadNtRaw(c, k, lane);
+        b.nt = loadNtRaw<P>(c, k, lane);
         b.tit = loadTriT<NL>(fk + FAC_TI, lane);
         b.ti = loadTri<NL>(fk + FAC_TI, lane);
-        b.y = loadYtT(fk + FAC_YT, lane);
+        b.y = loadYtT<NL>(fk + FAC_YT, lane);
         b.cs = loadCols(svk + NRHS_MAX * 16, sp.n, lane);
     }
     else
         b.nt = b.tit = b.ti = b.y = b.cs = tileZero();
     return b;
 }
+template <class P>
 SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
+    using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
-    BwdIn cur = loadBwdIn(c, sp, K - 1, lane);
-    BwdIn nx1 = K > 1 ? loadBwdIn(c, sp, K - 2, lane) : cur;
+    BwdIn cur = loadBwdIn<P>(c, sp, K - 1, lane);
+    BwdIn nx1 = K > 1 ? loadBwdIn<P>(c, sp, K - 2, lane) : cur;
     Tile x = tileZero();
     for (int k = K - 1; k >= 0; k--)
     {
         BwdIn nxt = nx1;
         if (k > 1)
-            nx1 = loadBwdIn(c, sp, k - 2, lane);
+            nx1 = loadBwdIn<P>(c, sp, k - 2, lane);
         if (k == K - 1)
         {
             x = mm(cur.li, cur.as); // Li' a = L^-T a
@@ -496,13 +563,13 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         else
         {
             // Z x' - c  with  Z x' = Ti (N x')
-            const Tile t = tileSub(mm(cur.tit, mm(finishNt(cur.nt, fixedMask(k + 1, K), lane), x)), cur.cs);
+            const Tile t = tileSub(mm(cur.tit, mm(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x)), cur.cs);
             const Tile lam = mm(cur.ti, t);                 // Ti' t = T^-T t
             const Tile s = tileSub(cur.as, mm(cur.y, lam)); // a - Y' lam
             x = mm(cur.li, s);
-            storeSolL(c, sp, k, lane, lam);
+            storeSolL<P>(c, sp, k, lane, lam);
         }
-        storeSolW(c, sp, k, lane, x);
+        storeSolW<P>(c, sp, k, lane, x);
         cur = nxt;
     }
     WAVE_SYNC();

@@ -119,6 +119,7 @@ __device__ inline Tile loadTriT(const double *p, int lane) // tile[a][b] = L[b][
     return t;
 }
 // Yt (16 variables x NL dynamics rows), row-major with pitch NL
+template <int NL>
 __device__ inline void storeYt(double *p, int lane, const Tile &t)
 {
     const int g = lane >> 4, i = lane & 15;
@@ -129,6 +130,7 @@ __device__ inline void storeYt(double *p, int lane, const Tile &t)
             p[(g + 4 * r) * NL + i] = t.v[r];
     }
 }
+template <int NL>
 __device__ inline Tile loadYt(const double *p, int lane) // tile[a][b] = Yt[a][b]
 {
     const int g = lane >> 4, i = lane & 15;
@@ -141,6 +143,7 @@ __device__ inline Tile loadYt(const double *p, int lane) // tile[a][b] = Yt[a][b
     }
     return t;
 }
+template <int NL>
 __device__ inline Tile loadYtT(const double *p, int lane) // tile[a][b] = Yt[b][a]
 {
     const int g = lane >> 4, i = lane & 15;
@@ -151,41 +154,6 @@ __device__ inline Tile loadYtT(const double *p, int lane) // tile[a][b] = Yt[b][
         const int a = g + 4 * r;
         const double v = p[i * NL + (a < NL ? a : 0)];
         t.v[r] = a < NL ? v : 0.;
-    }
-    return t;
-}
-
-// dynamics coupling tiles of segment k
-__device__ inline Tile loadM(const Ctx &c, int k, unsigned fm, int lane) // M[row][var]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int row = g + 4 * r;
-        t.v[r] = row < NL ? Ment(c, k, fm, row, i) : 0.;
-    }
-    return t;
-}
-__device__ inline Tile loadMt(const Ctx &c, int k, unsigned fm, int lane) // M'[var][row]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-        t.v[r] = i < NL ? Ment(c, k, fm, i, g + 4 * r) : 0.;
-    return t;
-}
-__device__ inline Tile loadN(const Ctx &c, int k, unsigned fmn, int lane) // N[row][var]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int row = g + 4 * r;
-        t.v[r] = row < NL ? Nent(c, k, fmn, row, i) : 0.;
     }
     return t;
 }
@@ -296,128 +264,7 @@ __device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
     return Li;
 }
 
-#ifdef INVCHOL_PAIRED
-// Variant: TWO pivots per LDS exchange (raw columns j, j+1 of A and rows j, j+1 of R are published together; every lane
-// applies step j to the broadcast column / row j+1 itself).  Halves the chain of dependent LDS round trips; measured
-// slower when its extra live values spill, kept for experiments.
-template <int n>
-__device__ inline Tile invCholFactorPaired(Tile A, TileShared &sh, int lane)
-{
-    static_assert(n % 2 == 0, "pivots are processed in pairs");
-    const int g = lane >> 4, i = lane & 15;
-    Tile R;
-    double od = 0.;
-    double pvr[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        R.v[r] = (g + 4 * r == i) ? 1. : 0.;
-        pvr[r] = 1.;
-        od = (g + 4 * r == i) ? A.v[r] : od;
-    }
-    WAVE_SYNC();
-    if (g == (i & 3))
-        sh.od[i] = od;
-    WAVE_SYNC();
-#pragma unroll
-    for (int j = 0; j < n; j += 2)
-    {
-        const int j1 = j + 1, rj0_ = j >> 2, rj1_ = j1 >> 2;
-        if (i == j || i == j1)
-        {
-            const int b = (i == j) ? 0 : 1;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (4 * r + 3 >= j)
-                    sh.colA[b][g + 4 * r] = A.v[r];
-        }
-        if (g == (j & 3))
-            sh.rowR[0][i] = rj0_ == 0 ? R.v[0] : rj0_ == 1 ? R.v[1] : rj0_ == 2 ? R.v[2] : R.v[3];
-        if (g == (j1 & 3))
-            sh.rowR[1][i] = rj1_ == 0 ? R.v[0] : rj1_ == 1 ? R.v[1] : rj1_ == 2 ? R.v[2] : R.v[3];
-        WAVE_SYNC();
-        double d0 = sh.colA[0][j];
-        const double a01 = sh.colA[1][j], d1raw = sh.colA[1][j1];
-        const double orig0 = sh.od[j], orig1 = sh.od[j1];
-        const double aj0 = sh.colA[0][i], aj1raw = sh.colA[1][i];
-        const double rj0 = sh.rowR[0][i], rj1raw = sh.rowR[1][i];
-        double c0[4], c1[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            c0[r] = (4 * r + 3 > j) ? sh.colA[0][g + 4 * r] : 0.;
-            c1[r] = (4 * r + 3 > j) ? sh.colA[1][g + 4 * r] : 0.;
-        }
-        WAVE_SYNC(); // the next pair overwrites the exchange buffers
-        d0 = fmax(d0, 1e-14 * orig0);
-        const double p0 = fastRcp(d0);
-        const double m01 = a01 * p0; // multiplier of row j+1 in step j
-        double d1 = d1raw - m01 * a01;
-        d1 = fmax(d1, 1e-14 * orig1);
-        const double p1 = fastRcp(d1);
-        const double aj0m = (i > j) ? aj0 : 0.;
-        const double rj0m = (i > j) ? 0. : rj0;
-        const double aj1 = aj1raw - m01 * aj0m, rj1 = rj1raw - m01 * rj0m;
-        const double aj1m = (i > j1) ? aj1 : 0.;
-        const double rj1m = (i > j1) ? 0. : rj1;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            if (4 * r + 3 > j)
-            {
-                const int row = g + 4 * r;
-                const double m0 = (row > j && row < n) ? c0[r] * p0 : 0.;
-                const double c1u = c1[r] - m0 * a01;
-                const double m1 = (row > j1 && row < n) ? c1u * p1 : 0.;
-                A.v[r] -= m0 * aj0m;
-                A.v[r] -= m1 * aj1m;
-                R.v[r] -= m0 * rj0m;
-                R.v[r] -= m1 * rj1m;
-            }
-            if (r == rj0_)
-                pvr[r] = (g + 4 * r == j) ? d0 : pvr[r];
-            if (r == rj1_)
-                pvr[r] = (g + 4 * r == j1) ? d1 : pvr[r];
-        }
-    }
-    Tile Li;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int row = g + 4 * r;
-        if (row < n)
-            Li.v[r] = (i <= row) ? R.v[r] * fastRsqrt(pvr[r]) : 0.;
-        else
-            Li.v[r] = (i == row) ? 1. : 0.;
-    }
-    return Li;
-}
-#define INVCHOL invCholFactorPaired
-#else
 #define INVCHOL invCholFactor
-#endif
-
-// index of H entry (va, vb) inside the stage's small-block record, or -1
-//   block 1: vars {1,2,3} (glide slope)      offset 0  (3x3)
-//   block 2: vars {8,9}   (tilt)             offset 9  (2x2)
-//   block 3: vars {11,12} (angular rate)     offset 13 (2x2)
-//   block 4: vars {13,14,15} (thrust cones + min-thrust row) offset 17 (3x3)
-//   block 5: var {0} (mass row)              offset 26
-constexpr int HS_N = 27;
-__device__ inline int hsIndex(int a, int b)
-{
-    if (a >= 1 && a <= 3 && b >= 1 && b <= 3)
-        return (a - 1) * 3 + (b - 1);
-    if (a >= 8 && a <= 9 && b >= 8 && b <= 9)
-        return 9 + (a - 8) * 2 + (b - 8);
-    if (a >= 11 && a <= 12 && b >= 11 && b <= 12)
-        return 13 + (a - 11) * 2 + (b - 11);
-    if (a >= 13 && b >= 13)
-        return 17 + (a - 13) * 3 + (b - 13);
-    if (a == 0 && b == 0)
-        return 26;
-    return -1;
-}
 
 } // namespace ipm
 } // namespace scpp

@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from ._lib import RocketQuatParams
+from ._lib import MODEL_ROCKET2D, MODEL_ROCKETQUAT, Rocket2dParams, RocketQuatParams
 from .parameter_server import ParameterServer
 
 CONFIG_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
@@ -34,7 +34,12 @@ def euler_to_quaternion_xyz(eta):
 
 class RocketQuat:
     modelName = "RocketQuat"
+    model_id = MODEL_ROCKETQUAT
     state_dim, input_dim, param_dim = 14, 4, 10
+
+    def sc_params(self):
+        """the C-ABI parameter struct of this model for scpp_hip_sc_setup"""
+        return self.p
 
     def __init__(self, param_folder=CONFIG_ROOT):
         self.param_folder = param_folder
@@ -117,7 +122,23 @@ class Rocket2D:
     """Host-side configuration half of the Rocket2d plugin (scpp_models/src/rocket2d.cpp:40-44,143-198); the flow map is
     device code (csrc/model_rocketquat.h: Rocket2dModel)."""
     modelName = "Rocket2D"
+    model_id = MODEL_ROCKET2D
     state_dim, input_dim, param_dim = 6, 2, 6
+
+    @property
+    def x_init(self):
+        return self.p.x_init
+
+    def sc_params(self):
+        """scpp_rocket2d_params for scpp_hip_sc_setup_rocket2d"""
+        p, q = self.p, Rocket2dParams()
+        q.g_I[:] = p.g_I
+        q.r_T_B[:] = p.r_T_B
+        q.m, q.J_B, q.T_min, q.T_max = p.m, p.J_B, p.T_min, p.T_max
+        q.gimbal_max, q.theta_max, q.gamma_gs, q.w_B_max = p.gimbal_max, p.theta_max, p.gamma_gs, p.w_B_max
+        q.x_final[:] = list(p.x_final)
+        q.final_time = p.final_time
+        return q
 
     def __init__(self, param_folder=CONFIG_ROOT):
         self.param_folder = param_folder

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from ._lib import MODEL_ROCKETQUAT, Context, SCOpts
+from ._lib import Context, SCOpts
 from .parameter_server import ParameterServer
 
 
@@ -38,17 +38,17 @@ class SCAlgorithm:
 
     def initialize(self):
         """SCAlgorithm::initialize (SCAlgorithm.cpp:48-64): allocates the device context."""
-        self.ctx = Context(MODEL_ROCKETQUAT, self.opts.K, self.batch_max, self.device, self.library)
+        self.ctx = Context(self.model.model_id, self.opts.K, self.batch_max, self.device, self.library)
         return self
 
     def solve(self, x_init=None, warm_start=False):
-        """SCAlgorithm::solve for every row of x_init [B][14] (dimensional). Returns #converged."""
+        """SCAlgorithm::solve for every row of x_init [B][state_dim] (dimensional). Returns #converged."""
         if x_init is None:
             x_init = self.model.x_init[None, :]
         x_init = np.atleast_2d(np.asarray(x_init, dtype=np.float64))
         if not warm_start:
             self.opts = load_sc_opts(self.model.getParameterFolder(), self.opts.K)  # loadParameters() on cold start
-        self.ctx.sc_setup(self.model.p, self.opts, x_init, warm_start=warm_start)
+        self.ctx.sc_setup(self.model.sc_params(), self.opts, x_init, warm_start=warm_start)
         return self.ctx.sc_solve()
 
     def getSolution(self):

@@ -189,3 +189,21 @@ def test_emu_discretize_fixed_time_and_rocket2d(oracle, emu_lib):
     for a, o in zip(out, ref):
         assert np.abs(a[0] - o).max() <= 1e-10 * max(1.0, np.abs(o).max())
     ctx.close()
+
+
+def test_emu_rocket2d_sc_matches_oracle_literal(oracle, emu_lib):
+    """The structured solver instantiated for Rocket2d's constraint table (csrc/constraint_table.h) against the oracle's
+    literal reference-shaped run: same SC iteration count, converged, trajectories to 1e-5."""
+    m = scpp_amd.Rocket2D().loadParameters()
+    K = 10
+    alg = scpp_amd.SCAlgorithm(m, K=K, batch_max=2, library=emu_lib).initialize()
+    x0 = np.stack([m.x_init, m.randomized_initial_states(1, first=3)[0]])
+    assert alg.solve(x0) == 2
+    out = alg.getSolution()
+    for b in range(2):
+        sc = oracle.SC(oracle.ROCKET2D, K=K); sc.set_x_init(x0[b]); sc.solve()
+        X, U, t = sc.solution()
+        assert out["sc_iters"][b] == sc.meta()["iterations"] and sc.meta()["converged"] == 1
+        assert abs(out["sigma"][b] - t) <= 1e-6 * t
+        assert np.abs(out["X"][b] - X).max() <= 1e-5 * np.abs(X).max()
+        assert np.abs(out["U"][b] - U).max() <= 1e-4 * np.abs(U).max()

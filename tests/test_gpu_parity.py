@@ -320,3 +320,32 @@ def test_scvx_stream_equals_batch_on_gpu(model, hip_lib):
                     "ipm_iters"):
             assert np.array_equal(o[key], r[key]), (slots, pools, key)
     alg.ctx.close()
+
+
+def test_rocket2d_sc_oneshot_matches_oracle_on_gpu(oracle, hip_lib):
+    """BASELINE configs[0] through a PRODUCT entry point: Rocket2D (the reference's default active model, activeModel.hpp:10)
+    SC_oneshot, K=30, on the device solver instantiated for Rocket2d's constraint table.  Checker: the oracle's literal
+    (reference-shaped, ECOS-style) run of the same scenario, which converges in 5 iterations (tests/golden/sc_regression.json)."""
+    m = scpp_amd.Rocket2D().loadParameters()
+    B = 64
+    alg = scpp_amd.SCAlgorithm(m, K=30, batch_max=B, library=hip_lib).initialize()
+    x0 = np.tile(m.x_init, (B, 1))
+    x0[1:] = m.randomized_initial_states(B - 1, first=1)
+    n = alg.solve(x0)
+    out = alg.getSolution()
+    assert (out["status"] == 0).all()
+    sc = oracle.SC(oracle.ROCKET2D, K=30); sc.solve()
+    mt, inf = sc.meta(), sc.info()
+    X, U, t = sc.solution()
+    assert out["converged"][0] == 1 and mt["converged"] == 1 and out["sc_iters"][0] == mt["iterations"] == 5
+    assert abs(out["sigma"][0] - t) <= 1e-6 * t
+    assert np.abs(out["X"][0] - X).max() <= 1e-5 * np.abs(X).max()
+    assert np.abs(out["U"][0] - U).max() <= 1e-4 * np.abs(U).max()  # flat optimum in the gimbal angle: two solvers agree to ~2e-5
+    assert n >= 0.5 * B  # most randomised neighbours converge within max_iterations too
+    # a randomised instance against the oracle as well
+    for b in (1, 2):
+        s2 = oracle.SC(oracle.ROCKET2D, K=30); s2.set_x_init(x0[b]); s2.solve()
+        X2, U2, t2 = s2.solution()
+        assert out["sc_iters"][b] == s2.meta()["iterations"] and out["converged"][b] == s2.meta()["converged"]
+        assert np.abs(out["X"][b] - X2).max() <= 1e-5 * np.abs(X2).max() and abs(out["sigma"][b] - t2) <= 1e-6 * t2
+    alg.ctx.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # one A/B point of the ipm_kernel work: GPU parity subset, PMC traffic summary, short bench.   usage: r02_ab.sh <tag> [full]
 TAG=$1; ROOT=$PWD; OUT=$ROOT/gpurun_out/ab_$TAG; mkdir -p $OUT
-if [ "$2" == "full" ]; then SEL=""; else SEL='-k "twin or scvx or batch256 or stream"'; fi
+if [ "$2" == "full" ]; then SEL=""; else SEL='-k "twin or scvx or batch256 or stream or rocket2d"'; fi
 eval timeout -k 5 600 python -m pytest tests -m gpu -x -q $SEL > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest.log
 bash tools/pmc_hbm.sh $TAG 4096 > $OUT/pmc.log 2>&1
 python - <<PY
