@@ -22,6 +22,8 @@ class Rocket2d
 {
 public:
     static constexpr int state_dim = 6, input_dim = 2, param_dim = 6;
+    static constexpr int model_id = SCPP_MODEL_ROCKET2D;
+    static constexpr bool has_scvx = false; // the reference ships no SCvx.info for this model
     using state_vector_t = std::array<double, 6>;
     using input_vector_t = std::array<double, 2>;
     using param_vector_t = std::array<double, 6>;
@@ -34,7 +36,64 @@ public:
         double final_time = 0.;
         state_vector_t x_init{}, x_final{};
         bool constrain_initial_final = true, add_slack_variables = false;
+        // synthetic neighbours of the shipped x_init (the reference has no recipe for this model)
+        void randomizeInitialState(uint64_t seed, uint64_t instance)
+        {
+            x_init[0] *= counterUniform(seed, instance, 0);
+            x_init[2] = 0.05 * std::fabs(x_init[3]) * counterUniform(seed, instance, 1);
+            x_init[3] *= 1. + 0.2 * counterUniform(seed, instance, 2);
+            x_init[4] *= counterUniform(seed, instance, 3);
+        }
     } p;
+
+    // what scpp_hip_sc_setup_rocket2d consumes (SI units, radians)
+    scpp_rocket2d_params abi() const
+    {
+        scpp_rocket2d_params a{};
+        for (int j = 0; j < 2; j++)
+        {
+            a.g_I[j] = p.g_I[j];
+            a.r_T_B[j] = p.r_T_B[j];
+        }
+        a.m = p.m;
+        a.J_B = p.J_B;
+        a.T_min = p.T_min;
+        a.T_max = p.T_max;
+        a.gimbal_max = p.gimbal_max;
+        a.theta_max = p.theta_max;
+        a.gamma_gs = p.gamma_gs;
+        a.w_B_max = p.w_B_max;
+        for (int j = 0; j < 6; j++)
+            a.x_final[j] = p.x_final[size_t(j)];
+        a.final_time = p.final_time;
+        return a;
+    }
+    int scSetup(scpp_hip_ctx *ctx, const scpp_sc_opts *opts, const double *x_init, int B, int warm) const
+    {
+        if (!p.constrain_initial_final)
+            return SCPP_E_UNSUPPORTED; // model.info:55-56: "enable for SC and disable for MPC/LQR"
+        const scpp_rocket2d_params a = abi();
+        return scpp_hip_sc_setup_rocket2d(ctx, &a, opts, x_init, B, warm);
+    }
+    // Parameters::nondimensionalize (rocket2d.cpp:200-203) and redimensionalizeTrajectory (:108-118)
+    static void scales(const state_vector_t &x, const Rocket2d &m, double &m_scale, double &r_scale)
+    {
+        m_scale = m.p.m;
+        r_scale = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+    }
+    static void redimensionalize(state_vector_t &x, input_vector_t &u, double m_scale, double r_scale)
+    {
+        for (int j = 0; j < 4; j++)
+            x[size_t(j)] *= r_scale;
+        u[1] *= m_scale * r_scale;
+    }
+    void flowParams(double *par) const
+    {
+        param_vector_t q;
+        getNewModelParameters(q);
+        for (int j = 0; j < 6; j++)
+            par[j] = q[size_t(j)];
+    }
 
     static std::string getModelName() { return "Rocket2D"; }
     static std::string &parameterFolder()

@@ -42,6 +42,8 @@ class RocketQuat
 {
 public:
     static constexpr int state_dim = 14, input_dim = 4, param_dim = 10;
+    static constexpr int model_id = SCPP_MODEL_ROCKETQUAT;
+    static constexpr bool has_scvx = true; // ships an SCvx.info
     using state_vector_t = std::array<double, 14>;
     using input_vector_t = std::array<double, 4>;
     using ptr_t = std::shared_ptr<RocketQuat>;
@@ -144,6 +146,27 @@ public:
         }
         for (int j = 0; j < 14; j++)
             a.x_final[j] = p.x_final[j];
+    }
+
+    // the C-ABI set-up call of this model (scpp_hip_sc_setup) and the scales of Parameters::nondimensionalize (:291-294)
+    int scSetup(scpp_hip_ctx *ctx, const scpp_sc_opts *opts, const double *x_init, int B, int warm) const
+    {
+        return scpp_hip_sc_setup(ctx, &p.abi, opts, x_init, B, warm);
+    }
+    static void scales(const state_vector_t &x, const RocketQuat &, double &m_scale, double &r_scale)
+    {
+        m_scale = x[0];
+        r_scale = std::sqrt(x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    }
+    // redimensionalizeTrajectory (rocketQuat.cpp:188-201) of one node
+    static void redimensionalize(state_vector_t &x, input_vector_t &u, double m_scale, double r_scale)
+    {
+        x[0] *= m_scale;
+        for (int j = 1; j < 7; j++)
+            x[size_t(j)] *= r_scale;
+        for (int j = 0; j < 3; j++)
+            u[size_t(j)] *= m_scale * r_scale;
+        u[3] *= m_scale * r_scale * r_scale;
     }
 
     // flow-map parameters in SI units for the plant simulation (rocketQuat.cpp:168-173 without scaling)

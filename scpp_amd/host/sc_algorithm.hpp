@@ -12,10 +12,18 @@
 #include <vector>
 
 #include "parameter_server.hpp"
+#include "rocket_2d.hpp"
 #include "rocket_quat.hpp"
 #include "scpp_hip.h"
 
-using Model = scpp::models::RocketQuat; // the reference selects the model with a compile definition (CMakeLists.txt:33-55)
+// The reference selects the active model with a compile definition (CMakeLists.txt:33-55, scpp_core/include/activeModel.hpp:
+// its default is Rocket2d).  Same here: -DSCPP_ACTIVE_MODEL_ROCKET2D builds the front end for Rocket2d, otherwise RocketQuat.
+// On the device both run the same solver, instantiated for the model's constraint table (csrc/constraint_table.h).
+#ifdef SCPP_ACTIVE_MODEL_ROCKET2D
+using Model = scpp::models::Rocket2d;
+#else
+using Model = scpp::models::RocketQuat;
+#endif
 
 // trajectoryData.hpp:8-32
 struct trajectory_data_t
@@ -82,7 +90,7 @@ public:
     void initialize()
     {
         loadParameters();
-        check(scpp_hip_create(&ctx, device, SCPP_MODEL_ROCKETQUAT, opts.K, batch_max, 0), "scpp_hip_create");
+        check(scpp_hip_create(&ctx, device, Model::model_id, opts.K, batch_max, 0), "scpp_hip_create");
         td.initialize(size_t(opts.K), opts.interpolate_input != 0);
     }
 
@@ -126,9 +134,9 @@ public:
                        std::vector<Model::state_vector_t> &x)
     {
         const int B = int(x.size());
-        std::vector<double> par(size_t(B) * 10), dts(size_t(B), dt);
+        std::vector<double> par(size_t(B) * Model::param_dim), dts(size_t(B), dt);
         for (int b = 0; b < B; b++)
-            model->flowParams(&par[size_t(b) * 10]);
+            model->flowParams(&par[size_t(b) * Model::param_dim]);
         check(scpp_hip_set_flow_params(ctx, par.data(), B), "scpp_hip_set_flow_params");
         check(scpp_hip_simulate(ctx, dts.data(), &u0[0][0], &u1[0][0], &x[0][0], B), "scpp_hip_simulate");
     }
@@ -147,17 +155,17 @@ private:
         if (!ctx)
             throw std::runtime_error("SCAlgorithm::initialize() has not been called");
         const int B = int(x.size());
-        check(scpp_hip_sc_setup(ctx, &model->p.abi, &opts, &x[0][0], B, warm_start ? 1 : 0), "scpp_hip_sc_setup");
+        check(model->scSetup(ctx, &opts, &x[0][0], B, warm_start ? 1 : 0), "scpp_hip_sc_setup");
         if (active)
             check(scpp_hip_sc_set_active(ctx, active->data(), B), "scpp_hip_sc_set_active");
-        scale_m = x[0][0];
-        scale_r = std::sqrt(x[0][1] * x[0][1] + x[0][2] * x[0][2] + x[0][3] * x[0][3]);
+        Model::scales(x[0], *model, scale_m, scale_r);
     }
     void download(int B, batch_result_t &out)
     {
         const size_t K = size_t(opts.K);
         const size_t nB = size_t(B);
-        std::vector<double> X(nB * K * 14), U(nB * K * 4), sigma(nB, 0.);
+        constexpr size_t NX = Model::state_dim, NU = Model::input_dim;
+        std::vector<double> X(nB * K * NX), U(nB * K * NU), sigma(nB, 0.);
         out.sc_iterations.assign(size_t(B), 0);
         out.converged.assign(size_t(B), 0);
         out.status.assign(size_t(B), 0);
@@ -174,10 +182,10 @@ private:
             t.initialize(K, true);
             for (size_t k = 0; k < K; k++)
             {
-                for (int j = 0; j < 14; j++)
-                    t.X[k][size_t(j)] = X[(size_t(b) * K + k) * 14 + size_t(j)];
-                for (int j = 0; j < 4; j++)
-                    t.U[k][size_t(j)] = U[(size_t(b) * K + k) * 4 + size_t(j)];
+                for (size_t j = 0; j < NX; j++)
+                    t.X[k][j] = X[(size_t(b) * K + k) * NX + j];
+                for (size_t j = 0; j < NU; j++)
+                    t.U[k][j] = U[(size_t(b) * K + k) * NU + j];
             }
             t.t = sigma[size_t(b)];
         }
@@ -190,14 +198,7 @@ private:
         trajectory_data_t t = r.td[0];
         if (redimensionalize && opts.nondimensionalize)
             for (size_t k = 0; k < t.X.size(); k++)
-            {
-                t.X[k][0] *= scale_m;
-                for (int j = 1; j < 7; j++)
-                    t.X[k][size_t(j)] *= scale_r;
-                for (int j = 0; j < 3; j++)
-                    t.U[k][size_t(j)] *= scale_m * scale_r;
-                t.U[k][3] *= scale_m * scale_r * scale_r;
-            }
+                Model::redimensionalize(t.X[k], t.U[k], scale_m, scale_r);
         return t;
     }
 
@@ -257,7 +258,9 @@ public:
     void initialize()
     {
         loadParameters();
-        const int rc = scpp_hip_create(&ctx, device, SCPP_MODEL_ROCKETQUAT, opts.K, batch_max, 0);
+        if (!Model::has_scvx)
+            throw std::runtime_error("SCvxAlgorithm: the active model ships no SCvx configuration");
+        const int rc = scpp_hip_create(&ctx, device, Model::model_id, opts.K, batch_max, 0);
         if (rc != SCPP_OK)
             throw std::runtime_error("scpp_hip_create failed with code " + std::to_string(rc));
     }
@@ -280,14 +283,15 @@ public:
         if (!warm_start)
             loadParameters(); // cold start re-reads SCvx.info (:179)
         const int B = int(x_inits.size());
-        int rc = scpp_hip_scvx_setup(ctx, &model->p.abi, &opts, &x_inits[0][0], B, warm_start ? 1 : 0);
+        int rc = scvxSetup(*model, &x_inits[0][0], B, warm_start);
         int nconv = 0;
         if (rc == SCPP_OK)
             rc = scpp_hip_scvx_solve(ctx, &nconv);
         if (rc != SCPP_OK)
             throw std::runtime_error("scpp_hip_scvx solve failed with code " + std::to_string(rc));
         const size_t K = size_t(opts.K), nB = size_t(B);
-        std::vector<double> X(nB * K * 14), U(nB * K * 4), sigma(nB, 0.);
+        constexpr size_t NX = Model::state_dim, NU = Model::input_dim;
+        std::vector<double> X(nB * K * NX), U(nB * K * NU), sigma(nB, 0.);
         out.sc_iterations.assign(nB, 0);
         out.converged.assign(nB, 0);
         out.status.assign(nB, 0);
@@ -310,10 +314,10 @@ public:
             t.initialize(K, true);
             for (size_t k = 0; k < K; k++)
             {
-                for (size_t j = 0; j < 14; j++)
-                    t.X[k][j] = X[(b * K + k) * 14 + j];
-                for (size_t j = 0; j < 4; j++)
-                    t.U[k][j] = U[(b * K + k) * 4 + j];
+                for (size_t j = 0; j < NX; j++)
+                    t.X[k][j] = X[(b * K + k) * NX + j];
+                for (size_t j = 0; j < NU; j++)
+                    t.U[k][j] = U[(b * K + k) * NU + j];
             }
             t.t = sigma[b];
         }
@@ -323,6 +327,11 @@ public:
     Model::ptr_t model;
 
 private:
+    int scvxSetup(const scpp::models::RocketQuat &m, const double *x, int B, bool warm)
+    {
+        return scpp_hip_scvx_setup(ctx, &m.p.abi, &opts, x, B, warm ? 1 : 0);
+    }
+    int scvxSetup(const scpp::models::Rocket2d &, const double *, int, bool) { return SCPP_E_UNSUPPORTED; }
     int batch_max, device, K_override;
     scpp_hip_ctx *ctx = nullptr;
     trajectory_data_t td;
@@ -341,7 +350,7 @@ inline Model::input_vector_t interpolatedInput(const std::vector<Model::input_ve
     const Model::input_vector_t u1 = first_order_hold ? U.at(i + 1) : u0;
     const double t_intermediate = std::fmod(t, time_step) / time_step;
     Model::input_vector_t u;
-    for (size_t j = 0; j < 4; j++)
+    for (size_t j = 0; j < size_t(Model::input_dim); j++)
         u[j] = u0[j] + (u1[j] - u0[j]) * t_intermediate;
     return u;
 }

@@ -5,6 +5,8 @@
 //                       instance 0 is written to the same tree under iteration index 0, a summary goes to stdout
 //   --scvx            : run the SCvx variant (SCvxAlgorithm, SCvx.info) instead of SCAlgorithm; output under .../SCvx/
 //   --config DIR --out DIR --K n --device d
+// The active model is a compile definition like in the reference (CMakeLists.txt:33-55): `sc_oneshot` is built for RocketQuat,
+// `sc_oneshot_rocket2d` (-DSCPP_ACTIVE_MODEL_ROCKET2D) for Rocket2d, the reference's default (activeModel.hpp:10).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -157,25 +157,91 @@ class SubProblem:
             r.append(X[k + 1] - (A[k] @ X[k] + B[k] @ U[k] + C[k] @ U[k + 1] + S[k] * sig + Z[k] + P[k] - M[k]))
         return np.concatenate(r)
 
-    def ineq(self, v):  # >= 0
-        X, U, P, M, D, sig, dsg = self.split(v)
+    # ---- inequalities >= 0: linear rows and squared second-order cones t^2 - ||w||^2 >= 0, each entry a sparse linear form
+    #      const + sum coef * v[idx]; values and the exact Jacobian come from the same description ----
+    def _forms(self):
+        if hasattr(self, "_lin"):
+            return self._lin, self._soc
         sc = self.sc
-        r = [P.ravel(), M.ravel(), X[:, 0] - sc["x_final"][0]]
+        iX = lambda k, j: k * NX + j
+        iU = lambda k, j: self.oU + k * NU + j
+        lin, soc = [], []  # lin: (const, [(idx, coef)]) ; soc: (t_form, [w_forms])
+        for i in range(self.nN):
+            lin.append((0.0, [(self.oP + i, 1.0)]))
+        for i in range(self.nN):
+            lin.append((0.0, [(self.oM + i, 1.0)]))
+        for k in range(K):
+            lin.append((-sc["x_final"][0], [(iX(k, 0), 1.0)]))  # mass >= m_dry
         free = range(1, K - 1)  # nodes 0 and K-1 have r, q_xy, w fixed by the equalities: their cones are constants
-        r.append(np.array([(sc["gs"] * X[k, 3]) ** 2 - X[k, 1] ** 2 - X[k, 2] ** 2 for k in free]))
-        r.append(np.array([X[k, 3] for k in free]))
-        r.append(np.array([sc["tilt"] ** 2 - X[k, 8] ** 2 - X[k, 9] ** 2 for k in free]))
-        r.append(np.array([sc["wmax"] ** 2 - X[k, 11:14] @ X[k, 11:14] for k in free]))
-        r.append(U[:, 2] - sc["T_min"])  # linearised minimum thrust with thrust_const = (0, 0, 1) (rocketQuat.cpp:113-121,156-173)
-        r.append(np.array([sc["T_max"] ** 2 - U[k, :3] @ U[k, :3] for k in range(K)]))
-        r.append(np.array([(sc["gim"] * U[k, 2]) ** 2 - U[k, 0] ** 2 - U[k, 1] ** 2 for k in range(K)]))
+        for k in free:
+            soc.append(((0.0, [(iX(k, 3), sc["gs"])]), [(0.0, [(iX(k, 1), 1.0)]), (0.0, [(iX(k, 2), 1.0)])]))
+            lin.append((0.0, [(iX(k, 3), 1.0)]))
+            soc.append(((sc["tilt"], []), [(0.0, [(iX(k, 8), 1.0)]), (0.0, [(iX(k, 9), 1.0)])]))
+            soc.append(((sc["wmax"], []), [(0.0, [(iX(k, 11 + j), 1.0)]) for j in range(3)]))
+        for k in range(K):
+            lin.append((-sc["T_min"], [(iU(k, 2), 1.0)]))  # linearised minimum thrust with thrust_const = (0, 0, 1) (rocketQuat.cpp:113-121,156-173)
+            soc.append(((sc["T_max"], []), [(0.0, [(iU(k, j), 1.0)]) for j in range(3)]))
+            soc.append(((0.0, [(iU(k, 2), sc["gim"])]), [(0.0, [(iU(k, 0), 1.0)]), (0.0, [(iU(k, 1), 1.0)])]))
         if self.mode == "sc":
-            r.append(np.array([sig - 0.001, dsg - (sig - self.sb) ** 2]))
-            dn = np.array([(X[k] - self.Xb[k]) @ (X[k] - self.Xb[k]) + (U[k] - self.Ub[k]) @ (U[k] - self.Ub[k]) for k in range(K)])
-            r.append(D ** 2 - dn); r.append(D)
+            oD = self.oD
+            lin.append((-0.001, [(oD + K, 1.0)]))  # sigma >= 0.001
+            # (sigma - sigma0)^2 <= delta_sigma  as  delta_sigma - (sigma - sigma0)^2 >= 0: a "cone" with t^2 replaced by a linear term
+            self._dsg_row = (oD + K + 1, (-self.sb, [(oD + K, 1.0)]))
+            for k in range(K):
+                w = [(-self.Xb[k, j], [(iX(k, j), 1.0)]) for j in range(NX)] + [(-self.Ub[k, j], [(iU(k, j), 1.0)]) for j in range(NU)]
+                soc.append(((0.0, [(oD + k, 1.0)]), w))
+                lin.append((0.0, [(oD + k, 1.0)]))
         else:
-            r.append(np.array([self.w["tr"] ** 2 - (U[k] - self.Ub[k]) @ (U[k] - self.Ub[k]) for k in range(K)]))
-        return np.concatenate(r)
+            for k in range(K):
+                soc.append(((self.w["tr"], []), [(-self.Ub[k, j], [(iU(k, j), 1.0)]) for j in range(NU)]))
+        self._lin, self._soc = lin, soc
+        return lin, soc
+
+    @staticmethod
+    def _val(form, v):
+        c, terms = form
+        return c + sum(cf * v[i] for i, cf in terms)
+
+    def ineq(self, v):  # >= 0
+        lin, soc = self._forms()
+        r = [self._val(f, v) for f in lin]
+        for t, ws in soc:
+            r.append(self._val(t, v) ** 2 - sum(self._val(w, v) ** 2 for w in ws))
+        if self.mode == "sc":
+            idx, f = self._dsg_row
+            r.append(v[idx] - self._val(f, v) ** 2)
+        return np.array(r)
+
+    def ineq_jac(self, v):
+        lin, soc = self._forms()
+        n_rows = len(lin) + len(soc) + (1 if self.mode == "sc" else 0)
+        J = np.zeros((n_rows, self.n))
+        r = 0
+        for c, terms in lin:
+            for i, cf in terms:
+                J[r, i] += cf
+            r += 1
+        for t, ws in soc:
+            tv = self._val(t, v)
+            for i, cf in t[1]:
+                J[r, i] += 2 * tv * cf
+            for w in ws:
+                wv = self._val(w, v)
+                for i, cf in w[1]:
+                    J[r, i] -= 2 * wv * cf
+            r += 1
+        if self.mode == "sc":
+            idx, f = self._dsg_row
+            J[r, idx] += 1.0
+            fv = self._val(f, v)
+            for i, cf in f[1]:
+                J[r, i] -= 2 * fv * cf
+        return J
+
+    def eq_jac(self, v):
+        if not hasattr(self, "_Je"):
+            self._Je = _jac(self.eq, np.zeros(self.n))  # the equalities are linear: constant Jacobian
+        return self._Je
 
     def start(self):
         """the linearisation point itself with the dynamics defect absorbed by the virtual control: strictly inside the cones"""
@@ -193,8 +259,7 @@ class SubProblem:
         return v
 
     def solve(self):
-        num_jac = lambda f: (lambda v: _jac(f, v))
-        cons = [{"type": "eq", "fun": self.eq, "jac": num_jac(self.eq)}, {"type": "ineq", "fun": self.ineq, "jac": num_jac(self.ineq)}]
+        cons = [{"type": "eq", "fun": self.eq, "jac": self.eq_jac}, {"type": "ineq", "fun": self.ineq, "jac": self.ineq_jac}]
         v = self.start()
         best = None
         for rep in range(6):  # SLSQP restarts from its own solution until the objective stops moving
@@ -222,7 +287,8 @@ def kkt_report(pb, v):
     """first-order optimality of the recorded point, independent of the optimiser that produced it: least-squares
     multipliers of the active set, then stationarity and sign conditions"""
     g = pb.cost_grad(v)
-    Je, Ji, ci = _jac(pb.eq, v), _jac(pb.ineq, v), pb.ineq(v)
+    Je, Ji, ci = pb.eq_jac(v), pb.ineq_jac(v), pb.ineq(v)
+    assert np.abs(Ji - _jac(pb.ineq, v)).max() < 1e-8  # the analytic Jacobian against exact central differences
     act = ci < 1e-7
     Jn = np.vstack([Je, Ji[act]])
     lam = np.linalg.lstsq(Jn.T, g, rcond=None)[0]
@@ -247,7 +313,7 @@ def main():
     print("SC  :", r.message, "obj %.12f" % r.fun, rep)
     # cross-check with a different algorithm (interior-point trust-constr) from the cold start
     r2 = minimize(pb.cost, pb.start(), jac=pb.cost_grad, method="trust-constr",
-                  constraints=[{"type": "eq", "fun": pb.eq, "jac": lambda v: _jac(pb.eq, v)}, {"type": "ineq", "fun": pb.ineq, "jac": lambda v: _jac(pb.ineq, v)}],
+                  constraints=[{"type": "eq", "fun": pb.eq, "jac": pb.eq_jac}, {"type": "ineq", "fun": pb.ineq, "jac": pb.ineq_jac}],
                   options=dict(maxiter=3000, gtol=1e-10, xtol=1e-12, barrier_tol=1e-10))
     print("SC  : trust-constr obj %.12f  (|diff| %.2e)" % (r2.fun, abs(r2.fun - r.fun)))
     for n, a in zip("ABCSZ", dd):
@@ -264,7 +330,7 @@ def main():
     repv = kkt_report(pv, vv)
     print("SCvx:", rv.message, "obj %.12f" % rv.fun, repv)
     rv2 = minimize(pv.cost, pv.start(), jac=pv.cost_grad, method="trust-constr",
-                   constraints=[{"type": "eq", "fun": pv.eq, "jac": lambda v: _jac(pv.eq, v)}, {"type": "ineq", "fun": pv.ineq, "jac": lambda v: _jac(pv.ineq, v)}],
+                   constraints=[{"type": "eq", "fun": pv.eq, "jac": pv.eq_jac}, {"type": "ineq", "fun": pv.ineq, "jac": pv.ineq_jac}],
                    options=dict(maxiter=3000, gtol=1e-10, xtol=1e-12, barrier_tol=1e-10))
     print("SCvx: trust-constr obj %.12f  (|diff| %.2e)" % (rv2.fun, abs(rv2.fun - rv.fun)))
     for n, a in zip("ABCSZ", ddv):

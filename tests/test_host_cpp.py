@@ -86,6 +86,32 @@ def test_host_executables_on_gpu(oracle, tmp_path):
     assert "batch 512:" in out and "solver failures 0" in out
     out = subprocess.check_output([os.path.join(HOST, "sc_sim"), "--batch", "64", "--steps", "3", "--config", CONFIG, "--out", str(tmp_path)], text=True)
     assert "64 closed loops, 192 solves" in out
+    # BASELINE configs[0]: the reference's default build (activeModel.hpp:10 = Rocket2d) of SC_oneshot, K = 30
+    _check_rocket2d_oneshot(oracle, os.path.join(HOST, "sc_oneshot_rocket2d"), tmp_path)
+
+
+def _check_rocket2d_oneshot(oracle, exe, tmp_path, K=30):
+    out = subprocess.check_output([exe, "--K", str(K), "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    sc = oracle.SC(oracle.ROCKET2D, K=K); sc.solve()
+    m = sc.meta()
+    assert m["converged"] == 1 and ("Converged after %d iterations." % m["iterations"]) in out
+    run = glob.glob(str(tmp_path / "output" / "Rocket2D" / "SC" / "*"))[0]
+    iters = sorted(int(os.path.basename(d)) for d in glob.glob(os.path.join(run, "*")))
+    assert iters == list(range(m["n_all_td"]))
+    X, U, t = sc.solution()
+    last = m["n_all_td"] - 1
+    Xf, Uf = _read(os.path.join(run, str(last), "X.txt")), _read(os.path.join(run, str(last), "U.txt"))
+    assert Xf.shape == (K, 6) and Uf.shape == (K, 2)
+    assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
+    assert np.allclose(Uf, U, rtol=1e-4, atol=1e-4 * np.abs(U).max())
+    assert abs(float(open(os.path.join(run, str(last), "t.txt")).read()) - t) <= 2e-5 * t
+
+
+def test_sc_oneshot_rocket2d_default_model(oracle, host_emu, tmp_path):
+    """The front end compiled for the reference's DEFAULT active model (-DSCPP_ACTIVE_MODEL_ROCKET2D): Rocket2D SC_oneshot through
+    the device solver instantiated for Rocket2d's constraint table, output tree under output/Rocket2D/SC, against the oracle's
+    literal reference-shaped run (CPU: emulation build of the kernels, K = 12)."""
+    _check_rocket2d_oneshot(oracle, os.path.join(host_emu, "sc_oneshot_rocket2d_emu"), tmp_path, K=12)
 
 
 def test_sc_oneshot_scvx_mode(oracle, host_emu, tmp_path):
