@@ -310,7 +310,7 @@ class SCAlgorithm
         solver.opt = socp_settings;
         SocpResult r = solver.solve();
         last_result = r;
-        if (r.exitflag != 0)
+        if (r.exitflag != 0 && r.exitflag != 10) // 10 = ECOS_OPTIMAL + ECOS_INACC_OFFSET: accepted like the twin / device do
         {
             solver_failed = true; // reference: std::terminate() (SCAlgorithm.cpp:94-98)
             SCIterationInfo inf{0, 0, 0, td.t, r.iter, r.exitflag, r.pres, r.dres, r.gap};

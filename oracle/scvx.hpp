@@ -220,7 +220,9 @@ class SCvxAlgorithm
         SocpResult r = solver.solve();
         ipm_iters = r.iter;
         exitflag = r.exitflag;
-        if (r.exitflag != 0)
+        // ECOS_OPTIMAL, or ECOS_OPTIMAL + ECOS_INACC_OFFSET ("close to optimal": a breakdown / iteration limit at an iterate that
+        // meets the reduced tolerances) -- the same acceptance rule as the structured twin and the device solver
+        if (r.exitflag != 0 && r.exitflag != 10)
             return false;
         // readSolution  SCvxAlgorithm.cpp:229-243
         for (int k = 0; k < td.K; k++)

@@ -854,6 +854,29 @@ inline SocpResult SocpSolver::solve()
 
     std::vector<double> rx(n), ry(p), rz(m), x1, y1, z1, x2, y2, z2;
     std::vector<double> dx(n), dy(p), dz(m), ds(m), dsa_s, dza_s, tmp, tmp2;
+    // ECOS keeps the best iterate seen so far and returns it when the path breaks down later ("close to optimal",
+    // ECOS_OPTIMAL + ECOS_INACC_OFFSET): here the last iterate that met the reduced tolerances
+    struct Best
+    {
+        std::vector<double> x, y, z, s;
+        double tau = 1., kap = 1., pcost = 0., dcost = 0., pres = 0., dres = 0., gap = 0., relgap = 0.;
+        bool valid = false;
+    } best;
+    double pres_prev = 0.;
+    auto restoreBest = [&]() {
+        x = best.x;
+        y = best.y;
+        z = best.z;
+        s = best.s;
+        tau = best.tau;
+        kap = best.kap;
+        R.pcost = best.pcost;
+        R.dcost = best.dcost;
+        R.pres = best.pres;
+        R.dres = best.dres;
+        R.gap = best.gap;
+        R.relgap = best.relgap;
+    };
 
     for (int iter = 0;; iter++)
     {
@@ -894,11 +917,16 @@ inline SocpResult SocpSolver::solve()
         if (opt.verbose)
             std::printf("%3d  pcost %+.6e dcost %+.6e gap %.2e pres %.2e dres %.2e k/t %.2e mu %.2e\n", iter, pcost,
                         dcost, gap, pres, dres, kap / tau, mu);
-        if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap))
+        if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) ||
+            (best.valid && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
         {
-            R.exitflag = -2;
+            // residual explosion after an acceptable iterate: return that iterate
+            R.exitflag = best.valid ? 10 : -2;
+            if (best.valid)
+                restoreBest();
             break;
         }
+        pres_prev = pres;
         if ((-cx > 0. || -by - hz >= -opt.abstol) && pres < opt.feastol && dres < opt.feastol &&
             (gap < opt.abstol || relgap < opt.reltol))
         {
@@ -941,6 +969,22 @@ inline SocpResult SocpSolver::solve()
         // numerical breakdown is hit at an iterate that already satisfies the relaxed tolerances, ECOS returns it as
         // "close to optimal" (exitflag ECOS_OPTIMAL + ECOS_INACC_OFFSET = 10) instead of failing
         const bool inacc_ok = (-cx > 0. || -by - hz >= -5e-5) && pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
+        if (inacc_ok)
+        {
+            best.x = x;
+            best.y = y;
+            best.z = z;
+            best.s = s;
+            best.tau = tau;
+            best.kap = kap;
+            best.pcost = pcost;
+            best.dcost = dcost;
+            best.pres = pres;
+            best.dres = dres;
+            best.gap = gap;
+            best.relgap = relgap;
+            best.valid = true;
+        }
         if (iter >= opt.maxit)
         {
             R.exitflag = inacc_ok ? 10 : -1;
