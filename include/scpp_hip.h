@@ -141,6 +141,10 @@ extern "C"
     /* ---- multipleShooting / simulate boundary (any model) ---- */
     int scpp_hip_set_flow_params(scpp_hip_ctx *ctx, const double *par /* [B][np] */, int B);
     int scpp_hip_upload_traj(scpp_hip_ctx *ctx, const double *X, const double *U, const double *sigma, int B);
+    /* zero-order-hold input: K-1 inputs per trajectory, U [B][K-1][nu] (trajectoryData.hpp:27-32, td.interpolatedInput() == false);
+       follow with scpp_hip_discretize(mode without SCPP_MODE_FOH): multipleShootingImplementation<false, VT>
+       (discretization.cpp:42-55, discretizationImplementation.hpp:96-101); dd.C reads back as zeros */
+    int scpp_hip_upload_traj_zoh(scpp_hip_ctx *ctx, const double *X, const double *U, const double *sigma, int B);
     int scpp_hip_discretize(scpp_hip_ctx *ctx, int mode);
     int scpp_hip_download_dd(scpp_hip_ctx *ctx, double *A, double *B, double *C, double *S, double *Z);
     int scpp_hip_simulate(scpp_hip_ctx *ctx, const double *dt /* [B] */, const double *u0, const double *u1,

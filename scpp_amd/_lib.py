@@ -113,7 +113,7 @@ _lib = None
 _lib_path = None
 
 SYMBOLS = [
-    "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj",
+    "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj", "scpp_hip_upload_traj_zoh",
     "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
@@ -186,11 +186,17 @@ class Context:
         _chk(self.lib.scpp_hip_set_flow_params(self.h, _p(par), int(par.shape[0])), "set_flow_params")
 
     def upload_traj(self, X, U, sigma):
+        """U [B][K][nu] (first-order hold) or [B][K-1][nu] (zero-order hold, trajectoryData.hpp:27-32)"""
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, self.K, self.nx)
-        U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, self.K, self.nu)
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        U = U.reshape(X.shape[0], -1, self.nu)
         sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(-1)
         self.B = X.shape[0]
-        _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
+        if U.shape[1] == self.K - 1:
+            _chk(self.lib.scpp_hip_upload_traj_zoh(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj_zoh")
+        else:
+            assert U.shape[1] == self.K
+            _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
 
     def discretize(self, mode=MODE_FOH | MODE_VT):
         _chk(self.lib.scpp_hip_discretize(self.h, int(mode)), "discretize")

@@ -528,13 +528,33 @@ int scpp_hip_upload_traj(scpp_hip_ctx *c, const double *X, const double *U, cons
     return SCPP_OK;
 }
 
+int scpp_hip_upload_traj_zoh(scpp_hip_ctx *c, const double *X, const double *U, const double *sigma, int B)
+{
+    DeviceGuard guard(c);
+    if (!c || !X || !U || !sigma || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    c->B = B;
+    const size_t K = size_t(c->K), nu = size_t(c->nu);
+    CHECK_HIP(hipMemcpyAsync(c->X, X, size_t(B) * K * c->nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // td.U holds K-1 inputs under zero-order hold (trajectoryData.hpp:27-32); the device keeps the [B][K][nu] pitch
+    CHECK_HIP(hipMemsetAsync(c->U, 0, size_t(B) * K * nu * sizeof(double), c->stream));
+    CHECK_HIP(hipMemcpy2DAsync(c->U, K * nu * sizeof(double), U, (K - 1) * nu * sizeof(double), (K - 1) * nu * sizeof(double), size_t(B),
+                               hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->sigma, sigma, size_t(B) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return SCPP_OK;
+}
+
 int scpp_hip_discretize(scpp_hip_ctx *c, int mode)
 {
     DeviceGuard guard(c);
     if (!c || c->B < 1 || mode < 0 || mode > 3)
         return SCPP_E_ARG;
     if (!(mode & SCPP_MODE_FOH))
-        return SCPP_E_UNSUPPORTED; /* U is stored [B][K][nu]; zero-order hold needs K-1 inputs: not wired yet */
+    {
+        /* zero-order hold: K-1 inputs per trajectory (scpp_hip_upload_traj_zoh); dd.C is empty in the reference
+           (discretizationData.hpp:56-59) -- here it reads back as zeros */
+        CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(c->B) * (c->K - 1) * c->nx * c->nu * sizeof(double), c->stream));
+    }
     const double *par = c->par_from_ip ? c->ip + ipm::IP_PAR : c->par;
     const int stride = c->par_from_ip ? ipm::IP_N : c->np;
     int rc = discretizeDispatch(c, mode, par, stride, nullptr, c->B);

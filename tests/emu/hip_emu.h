@@ -318,6 +318,10 @@ inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size_t spit
     return 0;
 }
 // lanes run as fibers of one host thread: a plain read-modify-write is atomic
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, int k, hipStream_t)
+{
+    return hipMemcpy2D(d, dpitch, s, spitch, width, height, k);
+}
 inline int atomicAdd(int *p, int v)
 {
     const int o = *p;

@@ -9,7 +9,7 @@ from conftest import ROOT
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "scpp_hip.h")).read()
-    return sorted(set(re.findall(r"\b(scpp_hip_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(scpp_hip_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported(hip_lib):

@@ -207,3 +207,34 @@ def test_emu_rocket2d_sc_matches_oracle_literal(oracle, emu_lib):
         assert abs(out["sigma"][b] - t) <= 1e-6 * t
         assert np.abs(out["X"][b] - X).max() <= 1e-5 * np.abs(X).max()
         assert np.abs(out["U"][b] - U).max() <= 1e-4 * np.abs(U).max()
+
+
+def _zoh_case(oracle, lib, tol):
+    """zero-order-hold input (td.U has K-1 entries, dd.C empty): both remaining instantiations <false, VT> / <false, fixed>"""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rocketquat_dd_K15.npz"))
+    K = 15
+    rng = np.random.default_rng(3)
+    U = g["U"][:K - 1] * (1.0 + 0.05 * rng.standard_normal((K - 1, 4)))  # non-constant inputs
+    U[:, 3] = 0.0
+    for mode, vt in ((scpp_amd.MODE_VT, True), (0, False)):
+        ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K, 2, library=lib)
+        ctx.set_flow_params(np.tile(g["par"], (2, 1)))
+        ctx.upload_traj(np.tile(g["X"], (2, 1, 1)), np.tile(U, (2, 1, 1)), np.full(2, float(g["t"])))
+        ctx.discretize(mode)
+        A, Bm, Cm, S, Z = ctx.download_dd()
+        ref = oracle.discretize(0, g["par"], g["X"], U, float(g["t"]), foh=False, vt=vt)
+        for b in range(2):
+            assert np.abs(A[b] - ref[0]).max() <= tol * max(1.0, np.abs(ref[0]).max())
+            assert np.abs(Bm[b] - ref[1]).max() <= tol * max(1.0, np.abs(ref[1]).max())
+            assert np.abs(Z[b] - ref[4]).max() <= tol * max(1.0, np.abs(ref[4]).max())
+            if vt:
+                assert np.abs(S[b] - ref[3]).max() <= tol * max(1.0, np.abs(ref[3]).max())
+            assert not Cm[b].any()  # dd.C is empty under zero-order hold (discretizationData.hpp:56-59)
+            # the linearisation identity at the linearisation point: x_prop = A x + B u + s sigma + z
+        ctx.close()
+
+
+def test_emu_discretize_zero_order_hold(oracle, emu_lib):
+    _zoh_case(oracle, emu_lib, 1e-10)

@@ -369,3 +369,60 @@ def test_whole_sc_run_matches_literal_reference_shaped_solver(oracle, model, alg
     assert _rel(out["U"], ref["U"]) <= 1e-4
     assert np.abs(out["sigma"] - ref["t"]).max() <= 1e-5 * np.abs(ref["t"]).max()
     assert np.abs(out["nu_norm"] - ref["nu"]).max() <= 1e-5 * np.abs(ref["nu"]).max()
+
+
+def test_discretize_zero_order_hold_on_gpu(oracle, hip_lib):
+    """zero-order-hold input through the ABI (scpp_hip_upload_traj_zoh + discretize without SCPP_MODE_FOH)"""
+    from test_emu_kernels import _zoh_case
+
+    _zoh_case(oracle, hip_lib, 1e-9)
+
+
+def test_sc_sim_runs_to_the_stop_rule_like_the_oracle(oracle, model, alg):
+    """BASELINE configs[3] end to end: receding-horizon loops driven until the reference's own stop rule fires
+    (||x - x_final|| < 0.02 or planned time < 0.25 s, SC_sim.cpp:57) -- some 230 warm-started SC solves per loop with the
+    persistent doubled weight_trust_region_trajectory and the per-solve thrust_const refresh -- against the oracle's driver."""
+    B = 4
+    x0 = model.randomized_initial_states(B, first=40)
+    r = scpp_amd.SCSim(alg, time_step=0.05, max_steps=400).run(x0)
+    assert not r["solver_failed"].any() and r["reached_end"].all()
+    worst = 0.0
+    for b in range(B):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=int(alg.opts.K)); sc.randomize(20260927, 40 + b); sc.set_solver(1)
+        o = sc.sim(0.05, 400)
+        assert o["reached_end"] == 1
+        assert abs(o["steps"] - r["steps"][b]) <= 1   # the stop rule fires at the same step (+- one at the threshold)
+        n = min(o["steps"], int(r["steps"][b]))
+        assert 150 <= n <= 300
+        dev = np.abs(o["X_sim"][:n] - r["X_sim"][b][:n]).max(axis=1) / np.abs(o["X_sim"][:n]).max()
+        # iterate-for-iterate over the first 20 solves, then bounded drift: every step re-solves from the simulated state,
+        # so differences of the interior-point termination (1e-8) are fed back through ~200 closed-loop steps
+        assert dev[:20].max() <= 1e-6
+        assert dev.max() <= 1e-3
+        assert list(o["sc_iters"][:20]) == list(r["sc_iters"][b][:20])
+        worst = max(worst, float(dev.max()))
+    print("SC_sim closed loops to the stop rule: worst relative state deviation vs oracle %.2e" % worst)
+
+
+def test_sc_sim_monte_carlo_4096_loops_properties(model, hip_lib):
+    """configs[3] at its batch size: 4096 closed loops x 20 receding-horizon steps.  Size-independent properties: no solver
+    failure, the stop mask only ever shrinks, duplicated initial states give bitwise identical closed loops, and every loop's
+    plant state follows its plan (the first simulated step lands on the planned trajectory to discretisation accuracy)."""
+    B, steps = 4096, 20
+    a = scpp_amd.SCAlgorithm(model, K=50, batch_max=B, library=hip_lib).initialize()
+    x0 = model.randomized_initial_states(B, first=90_000)
+    x0[B // 2:] = x0[:B // 2]  # second half duplicates the first
+    r = scpp_amd.SCSim(a, time_step=0.05, max_steps=steps).run(x0)
+    assert not r["solver_failed"].any()
+    assert (r["steps"] == steps).all()  # nobody reaches the target within 1 s of a 12 s descent
+    h = B // 2
+    for b in range(0, h, 97):
+        assert np.array_equal(r["X_sim"][b], r["X_sim"][b + h]) and np.array_equal(r["U_sim"][b], r["U_sim"][b + h])
+        assert np.array_equal(r["t_plan"][b], r["t_plan"][b + h])
+    # planned final time shrinks by about the elapsed time from solve to solve (free final time, receding horizon)
+    tp = np.array([r["t_plan"][b] for b in range(0, h, 97)])
+    assert (np.abs(np.diff(tp, axis=1) + 0.05) < 0.2).all()
+    # altitude decreases monotonically along every sampled closed loop (descent scenario)
+    for b in range(0, h, 97):
+        assert (np.diff(r["X_sim"][b][:, 3]) < 0).all()
+    a.ctx.close()
