@@ -2,7 +2,7 @@
 
 Nothing here imports the oracle, the HIP library or scpp_amd: the scenario, the nondimensionalisation, the initial-guess
 trajectory, the discretisation and the two convex sub-problems are restated from the reference text in numpy / sympy and
-solved with general-purpose scipy optimisers (SLSQP on a smooth reformulation, cross-checked by trust-constr), so that the
+solved with a general-purpose scipy optimiser (trust-constr on the epigraph form with concave cone functions), so that the
 optimum recorded in rocketquat_subproblem_K5.npz owes nothing to the interior-point solvers it is used to check.
 
   scenario        scpp_models/config/RocketQuat/model.info:109-213 (the active "FALCON 9" block), SC.info, SCvx.info
@@ -152,7 +152,9 @@ class SubProblem:
     def eq(self, v):
         X, U, P, M, D, sig, dsg = self.split(v)
         A, B, C, S, Z = self.dd
-        r = [X[0] - self.sc["x_init"], X[K - 1][FINAL_FIXED] - self.sc["x_final"][FINAL_FIXED], U[K - 1][[0, 1, 3]], X[:, 13], U[:, 3]]
+        # (the reference states some of these twice -- X(13,0) through x_init and through X.row(13) = 0, U(3,K-1) through the final
+        #  input and through U.row(3) = 0; each is kept once so that the equality Jacobian has full row rank)
+        r = [X[0] - self.sc["x_init"], X[K - 1][FINAL_FIXED] - self.sc["x_final"][FINAL_FIXED], U[K - 1][[0, 1, 3]], X[1:K - 1, 13], U[:K - 1, 3]]
         for k in range(K - 1):
             r.append(X[k + 1] - (A[k] @ X[k] + B[k] @ U[k] + C[k] @ U[k + 1] + S[k] * sig + Z[k] + P[k] - M[k]))
         return np.concatenate(r)
@@ -202,11 +204,13 @@ class SubProblem:
         c, terms = form
         return c + sum(cf * v[i] for i, cf in terms)
 
-    def ineq(self, v):  # >= 0
+    EPS = 1e-12  # smoothing of ||w|| at w = 0 (a trust-region cone whose node does not move)
+
+    def ineq(self, v):  # >= 0 ; cones as the CONCAVE functions t - ||w||: every SQP linearisation is an outer approximation
         lin, soc = self._forms()
         r = [self._val(f, v) for f in lin]
         for t, ws in soc:
-            r.append(self._val(t, v) ** 2 - sum(self._val(w, v) ** 2 for w in ws))
+            r.append(self._val(t, v) - np.sqrt(sum(self._val(w, v) ** 2 for w in ws) + self.EPS ** 2))
         if self.mode == "sc":
             idx, f = self._dsg_row
             r.append(v[idx] - self._val(f, v) ** 2)
@@ -222,13 +226,13 @@ class SubProblem:
                 J[r, i] += cf
             r += 1
         for t, ws in soc:
-            tv = self._val(t, v)
             for i, cf in t[1]:
-                J[r, i] += 2 * tv * cf
-            for w in ws:
-                wv = self._val(w, v)
+                J[r, i] += cf
+            wvs = [self._val(w, v) for w in ws]
+            nrm = np.sqrt(sum(x * x for x in wvs) + self.EPS ** 2)
+            for w, wv in zip(ws, wvs):
                 for i, cf in w[1]:
-                    J[r, i] -= 2 * wv * cf
+                    J[r, i] -= wv / nrm * cf
             r += 1
         if self.mode == "sc":
             idx, f = self._dsg_row
@@ -259,24 +263,25 @@ class SubProblem:
         return v
 
     def solve(self):
+        """scipy trust-constr (an interior-point / SQP trust-region method for general NLPs) from the cold start, then a
+        second run from its own solution with the barrier restarted: the objective must not move."""
         cons = [{"type": "eq", "fun": self.eq, "jac": self.eq_jac}, {"type": "ineq", "fun": self.ineq, "jac": self.ineq_jac}]
-        v = self.start()
-        best = None
-        for rep in range(6):  # SLSQP restarts from its own solution until the objective stops moving
-            r = minimize(self.cost, v, jac=self.cost_grad, constraints=cons, method="SLSQP", options=dict(maxiter=800, ftol=1e-15))
-            v = r.x
-            if best is not None and abs(best - r.fun) <= 1e-11 * max(1.0, abs(r.fun)):
-                break
-            best = r.fun
-        return v, r
+        v0 = self.start()
+        assert np.abs(self.ineq_jac(v0) - _jac(self.ineq, v0)).max() < 1e-5  # analytic cone gradients vs central differences (smooth point)
+        opts = dict(maxiter=4000, gtol=1e-11, xtol=1e-14, barrier_tol=1e-11, initial_barrier_parameter=0.1)
+        r = minimize(self.cost, self.start(), jac=self.cost_grad, method="trust-constr", constraints=cons, options=opts)
+        print("  trust-constr pass 0:", r.message if hasattr(r, "message") else "", "iterations", r.nit, "obj %.12f" % r.fun, "constr viol %.2e" % r.constr_violation, flush=True)
+        r2 = minimize(self.cost, r.x, jac=self.cost_grad, method="trust-constr", constraints=cons,
+                      options=dict(opts, initial_barrier_parameter=1e-6, initial_tr_radius=1e-2))
+        print("  trust-constr pass 1: iterations", r2.nit, "obj %.12f" % r2.fun, "constr viol %.2e" % r2.constr_violation, flush=True)
+        return (r2.x, r2) if r2.constr_violation <= max(r.constr_violation, 1e-9) and abs(r2.fun - r.fun) < 1e-4 else (r.x, r)
 
 
 def _jac(f, v):
-    """complex-step-free central differences are too noisy for 1e-9 optima; all constraints are polynomials of degree <= 2 in v,
-    so a central difference with a large step is EXACT up to round-off"""
+    """central differences (exact for the linear equalities; a check of the analytic cone gradients elsewhere)"""
     f0 = f(v)
     J = np.zeros((f0.size, v.size))
-    h = 1e-3
+    h = 1e-6
     for j in range(v.size):
         e = np.zeros(v.size); e[j] = h
         J[:, j] = (f(v + e) - f(v - e)) / (2 * h)
@@ -288,7 +293,6 @@ def kkt_report(pb, v):
     multipliers of the active set, then stationarity and sign conditions"""
     g = pb.cost_grad(v)
     Je, Ji, ci = pb.eq_jac(v), pb.ineq_jac(v), pb.ineq(v)
-    assert np.abs(Ji - _jac(pb.ineq, v)).max() < 1e-8  # the analytic Jacobian against exact central differences
     act = ci < 1e-7
     Jn = np.vstack([Je, Ji[act]])
     lam = np.linalg.lstsq(Jn.T, g, rcond=None)[0]
@@ -310,16 +314,11 @@ def main():
     v, r = pb.solve()
     X, U, P, M, D, sig, dsg = pb.split(v)
     rep = kkt_report(pb, v)
-    print("SC  :", r.message, "obj %.12f" % r.fun, rep)
-    # cross-check with a different algorithm (interior-point trust-constr) from the cold start
-    r2 = minimize(pb.cost, pb.start(), jac=pb.cost_grad, method="trust-constr",
-                  constraints=[{"type": "eq", "fun": pb.eq, "jac": pb.eq_jac}, {"type": "ineq", "fun": pb.ineq, "jac": pb.ineq_jac}],
-                  options=dict(maxiter=3000, gtol=1e-10, xtol=1e-12, barrier_tol=1e-10))
-    print("SC  : trust-constr obj %.12f  (|diff| %.2e)" % (r2.fun, abs(r2.fun - r.fun)))
+    print("SC  : obj %.12f" % r.fun, rep)
     for n, a in zip("ABCSZ", dd):
         out["sc_" + n] = a
     out.update(sc_X=X.copy(), sc_U=U.copy(), sc_nu=(P - M).copy(), sc_sigma=sig, sc_delta=D.copy(), sc_delta_sigma=dsg, sc_objective=r.fun,
-               sc_objective_trust_constr=r2.fun, sc_norm1_nu=float((P + M).sum()), sc_weights=np.array([1.0, 1.0, 50.0, 1000.0]),
+               sc_norm1_nu=float((P + M).sum()), sc_weights=np.array([1.0, 1.0, 50.0, 1000.0]),
                sc_kkt=np.array([rep["stationarity"], rep["min_ineq_multiplier"], rep["max_eq_violation"], rep["min_ineq"]]))
     # ---- SCvx sub-problem (fixed final time, hard input trust region) with the shipped SCvx.info ----
     w_vx = dict(vc=1000.0, tr=5.0)
@@ -328,14 +327,10 @@ def main():
     vv, rv = pv.solve()
     Xv, Uv, Pv, Mv, _, _, _ = pv.split(vv)
     repv = kkt_report(pv, vv)
-    print("SCvx:", rv.message, "obj %.12f" % rv.fun, repv)
-    rv2 = minimize(pv.cost, pv.start(), jac=pv.cost_grad, method="trust-constr",
-                   constraints=[{"type": "eq", "fun": pv.eq, "jac": pv.eq_jac}, {"type": "ineq", "fun": pv.ineq, "jac": pv.ineq_jac}],
-                   options=dict(maxiter=3000, gtol=1e-10, xtol=1e-12, barrier_tol=1e-10))
-    print("SCvx: trust-constr obj %.12f  (|diff| %.2e)" % (rv2.fun, abs(rv2.fun - rv.fun)))
+    print("SCvx: obj %.12f" % rv.fun, repv)
     for n, a in zip("ABCSZ", ddv):
         out["scvx_" + n] = a
-    out.update(scvx_X=Xv.copy(), scvx_U=Uv.copy(), scvx_nu=(Pv - Mv).copy(), scvx_objective=rv.fun, scvx_objective_trust_constr=rv2.fun,
+    out.update(scvx_X=Xv.copy(), scvx_U=Uv.copy(), scvx_nu=(Pv - Mv).copy(), scvx_objective=rv.fun, 
                scvx_norm1_nu=float((Pv + Mv).sum()), scvx_weights=np.array([1000.0, 5.0]),
                scvx_kkt=np.array([repv["stationarity"], repv["min_ineq_multiplier"], repv["max_eq_violation"], repv["min_ineq"]]))
     np.savez(os.path.join(HERE, "rocketquat_subproblem_K5.npz"), **out)

@@ -1,0 +1,96 @@
+"""Independent pin of the SC and SCvx sub-problems.  tests/golden/rocketquat_subproblem_K5.npz holds the
+optimum of the RocketQuat K=5 sub-problems found by scipy's trust-constr on a restatement of the reference text that shares no
+code with the oracle, the kernels or scpp_amd (generate_subproblem_goldens.py: scenario, nondimensionalisation, initial guess,
+DOP853 discretisation, SCProblem.cpp:6-138 / SCvxProblem.cpp:6-71 + rocketQuat.cpp:70-144 as a generic NLP).  Checked against it:
+both oracle solvers (literal reference-shaped form, structured twin) and the device path (CPU emulation here, HIP under -m gpu).
+Tolerances: objective 1e-6 relative (what pins the formulation: weights, cones, dynamics, presolve); trajectories 5e-5 relative
+(trust-constr stops with a constraint violation of 4e-10, which bounds how well it locates the optimum)."""
+import os
+
+import numpy as np
+import pytest
+
+import scpp_amd
+from conftest import GOLDEN
+
+K = 5
+W_T, W_TRT, W_TRX, W_VC = 1.0, 1.0, 50.0, 1000.0  # shipped SC.info / SCvx.info weights (the golden file records them too)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    g = np.load(os.path.join(GOLDEN, "rocketquat_subproblem_K5.npz"))
+    assert np.allclose(g["sc_weights"], [W_T, W_TRT, W_TRX, W_VC]) and np.allclose(g["scvx_weights"], [W_VC, 5.0])
+    # the recorded points satisfy first-order optimality in the independent restatement (convex problem: global optimum)
+    assert g["sc_kkt"][0] < 5e-3 * W_VC and g["sc_kkt"][1] > -1e-6 and g["sc_kkt"][2] < 1e-9 and g["sc_kkt"][3] > -1e-8
+    assert g["scvx_kkt"][0] < 1e-5 * W_VC and g["scvx_kkt"][1] > -1e-6 and g["scvx_kkt"][2] < 1e-9 and g["scvx_kkt"][3] > -1e-8
+    return g
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _check_sc(g, X, U, sigma, norm1_nu, sum_delta, what):
+    obj = W_T * sigma + W_VC * norm1_nu + W_TRT * (sigma - float(g["sigma_bar"])) ** 2 + W_TRX * sum_delta
+    assert abs(obj - float(g["sc_objective"])) <= 1e-6 * float(g["sc_objective"]), (what, obj)
+    assert abs(norm1_nu - float(g["sc_norm1_nu"])) <= 1e-4 * float(g["sc_norm1_nu"]), what
+    assert _rel(X, g["sc_X"]) <= 5e-5 and _rel(U, g["sc_U"]) <= 5e-5 and abs(sigma - float(g["sc_sigma"])) <= 2e-4, what
+
+
+def _check_scvx(g, X, U, norm1_nu, what):
+    assert abs(W_VC * norm1_nu - float(g["scvx_objective"])) <= 2e-6 * float(g["scvx_objective"]), (what, norm1_nu)
+    assert _rel(X, g["scvx_X"]) <= 5e-5 and _rel(U, g["scvx_U"]) <= 5e-5, what
+
+
+def test_independent_restatement_agrees_on_the_problem_data(oracle, gold):
+    """scenario -> nondimensionalisation -> initial guess -> discretisation, restated twice (numpy/sympy/DOP853 vs oracle)"""
+    s = oracle.SC(oracle.ROCKETQUAT, K=K); s.set_solver(1); s.solve()
+    X0, U0, t0 = s.iterate(0)
+    assert np.abs(X0 - gold["Xbar"]).max() <= 1e-14 and np.abs(U0 - gold["Ubar"]).max() <= 1e-14 and t0 == float(gold["sigma_bar"])
+    dd = oracle.discretize(0, gold["par"], X0, U0, t0)
+    for a, n in zip(dd, "ABCSZ"):
+        assert np.abs(a - gold["sc_" + n]).max() <= 1e-9 * max(1.0, np.abs(gold["sc_" + n]).max()), n
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_oracle_solvers_against_scipy_optimum(oracle, gold, kind):
+    s = oracle.SC(oracle.ROCKETQUAT, K=K); s.set_solver(kind); s.set_tolerances(1e-10, 1e-10, 1e-10, 200); s.solve()
+    X1, U1, t1 = s.iterate(1)
+    inf = s.info()[0]
+    _check_sc(gold, X1, U1, t1, inf[0], inf[1], "oracle SC solver %d" % kind)
+    v = oracle.SCvx(K=K); v.set_solver(kind); v.set_tolerances(1e-10, 1e-10, 1e-10, 200); v.set_max_iterations(1); v.solve()
+    Xv, Uv, _ = v.iterate(1)
+    _check_scvx(gold, Xv, Uv, v.info()[0][0], "oracle SCvx solver %d" % kind)
+
+
+def _device(gold, lib):
+    m = scpp_amd.RocketQuat().loadParameters()
+    alg = scpp_amd.SCAlgorithm(m, K=K, batch_max=2, library=lib).initialize()
+    alg.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+    alg.ctx.sc_setup(m.p, alg.opts, np.stack([m.x_init, m.x_init]))
+    alg.ctx.sc_iterate()
+    o = alg.ctx.download()
+    for b in range(2):
+        _check_sc(gold, o["X"][b], o["U"][b], o["sigma"][b], o["nu_norm"][b], o["sum_delta"][b], "device SC")
+    alg.ctx.close()
+    v = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=2, library=lib, max_iterations=1).initialize()
+    v.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+    v.solve(np.stack([m.x_init, m.x_init]))
+    o = v.getSolution()
+    ms, rs = m.x_init[0], np.linalg.norm(m.x_init[1:4])
+    for b in range(2):
+        X = o["X"][b].copy(); U = o["U"][b].copy()  # getSolution is dimensional: back to the solver's units
+        X[:, 0] /= ms; X[:, 1:7] /= rs; U[:, :3] /= ms * rs; U[:, 3] /= ms * rs * rs
+        _check_scvx(gold, X, U, o["nu_norm"][b], "device SCvx")
+    v.ctx.close()
+
+
+def test_device_path_against_scipy_optimum_emulated(gold, emu_lib):
+    """the kernel sources on the CPU wave emulator (the GPU run of the same check is below)"""
+    _device(gold, emu_lib)
+
+
+@pytest.mark.gpu
+def test_device_path_against_scipy_optimum_on_gpu(gold, hip_lib):
+    _device(gold, hip_lib)
