@@ -4,12 +4,15 @@
 //   --batch B [--seed S]: B randomised initial states solved at once (the workload of BASELINE configs 1/2);
 //                       instance 0 is written to the same tree under iteration index 0, a summary goes to stdout
 //   --scvx            : run the SCvx variant (SCvxAlgorithm, SCvx.info) instead of SCAlgorithm; output under .../SCvx/
+//   --gpus N          : with --batch, shard the instances over N devices (contiguous static shards, one host thread + one context
+//                       per GPU, nothing shared while solving -- SURVEY 8(e)); results are concatenated in instance order
 //   --config DIR --out DIR --K n --device d
 // The active model is a compile definition like in the reference (CMakeLists.txt:33-55): `sc_oneshot` is built for RocketQuat,
 // `sc_oneshot_rocket2d` (-DSCPP_ACTIVE_MODEL_ROCKET2D) for Rocket2d, the reference's default (activeModel.hpp:10).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "output.hpp"
 #include "sc_algorithm.hpp"
@@ -19,7 +22,7 @@ namespace fs = std::filesystem;
 int main(int argc, char **argv)
 {
     std::string config = "../scpp_amd/config", out = "..";
-    int batch = 0, K = 0, device = 0;
+    int batch = 0, K = 0, device = 0, gpus = 1;
     unsigned long long seed = 20260927ull;
     bool scvx = false;
     for (int i = 1; i < argc; i++)
@@ -46,6 +49,8 @@ int main(int argc, char **argv)
             K = std::atoi(next());
         else if (!std::strcmp(argv[i], "--device"))
             device = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--gpus"))
+            gpus = std::atoi(next());
         else
         {
             std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -95,6 +100,74 @@ int main(int argc, char **argv)
             std::printf("output: %s\n", outputPath.string().c_str());
             return 0;
         }
+        if (batch > 0 && gpus > 1)
+        {
+            // one host thread + one device context per GPU; shard g owns instances [lo_g, hi_g)
+            std::vector<Model::state_vector_t> x_inits;
+            for (int b = 0; b < batch; b++)
+            {
+                Model inst = *model;
+                inst.p.randomizeInitialState(seed, uint64_t(b));
+                x_inits.push_back(inst.p.x_init);
+            }
+            std::vector<scpp::batch_result_t> part(static_cast<size_t>(gpus));
+            std::vector<std::string> err(static_cast<size_t>(gpus));
+            std::vector<std::thread> th;
+            const int base = batch / gpus, rem = batch % gpus;
+            for (int g = 0; g < gpus; g++)
+            {
+                const int lo = g * base + std::min(g, rem), hi = lo + base + (g < rem ? 1 : 0);
+                th.emplace_back([&, g, lo, hi]() {
+                    try
+                    {
+                        if (hi <= lo)
+                            return;
+                        scpp::SCAlgorithm shard(model, hi - lo, device + g, K);
+                        shard.initialize();
+                        const std::vector<Model::state_vector_t> xs(x_inits.begin() + lo, x_inits.begin() + hi);
+                        shard.solveBatch(xs, part[size_t(g)]);
+                    }
+                    catch (const std::exception &e)
+                    {
+                        err[size_t(g)] = e.what();
+                    }
+                });
+            }
+            for (auto &t : th)
+                t.join();
+            long conv = 0, fails = 0, iters = 0, n = 0;
+            for (int g = 0; g < gpus; g++)
+            {
+                if (!err[size_t(g)].empty())
+                    throw std::runtime_error("GPU " + std::to_string(device + g) + ": " + err[size_t(g)]);
+                const scpp::batch_result_t &r = part[size_t(g)];
+                for (size_t b = 0; b < r.td.size(); b++, n++)
+                {
+                    conv += r.converged[b];
+                    fails += r.status[b] != 0;
+                    iters += r.sc_iterations[b];
+                }
+            }
+            std::printf("batch %d on %d GPUs: converged %ld, solver failures %ld, mean SC iterations %.2f\n", batch, gpus, conv, fails,
+                        double(iters) / double(n));
+            // checksum of the concatenated result (tests compare it with the single-device run)
+            double cs = 0.;
+            for (int g = 0; g < gpus; g++)
+                for (const auto &t : part[size_t(g)].td)
+                    for (const auto &x : t.X)
+                        for (double v : x)
+                            cs += v;
+            std::printf("checksum X %.12e\n", cs);
+            all_td.push_back(part[0].td[0]);
+            const fs::path outputPath = fs::path(out) / "output" / Model::getModelName() / "SC" / scpp::getTimeString() / "0";
+            scpp::makeDir(outputPath);
+            scpp::writeRows(outputPath / "X.txt", all_td[0].X);
+            scpp::writeRows(outputPath / "U.txt", all_td[0].U);
+            std::ofstream f(outputPath / "t.txt");
+            f << all_td[0].t;
+            std::printf("output: %s\n", outputPath.string().c_str());
+            return 0;
+        }
         scpp::SCAlgorithm solver(model, batch > 0 ? batch : 1, device, K);
         solver.initialize();
 
@@ -123,6 +196,12 @@ int main(int argc, char **argv)
                 iters += r.sc_iterations[size_t(b)];
             }
             std::printf("batch %d: converged %ld, solver failures %ld, mean SC iterations %.2f\n", batch, conv, fails, double(iters) / batch);
+            double cs = 0.;
+            for (const auto &t : r.td)
+                for (const auto &x : t.X)
+                    for (double v : x)
+                        cs += v;
+            std::printf("checksum X %.12e\n", cs);
             all_td.push_back(r.td[0]);
         }
 

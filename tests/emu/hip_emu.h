@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define __global__
@@ -126,9 +127,17 @@ inline void run_block(unsigned nthreads)
     }
     s.cur = -1;
 }
+inline std::mutex &launch_mutex()
+{
+    static std::mutex m;
+    return m;
+}
 template <class K, class... Args>
 void launch(K kernel, dim3 grid, dim3 block, Args... args)
 {
+    // one emulated kernel at a time: the fiber state and the `static` stand-ins for __shared__ are process-wide (host
+    // front ends that drive one context per thread, sc_oneshot --gpus N, are tested against this build)
+    std::lock_guard<std::mutex> lock(launch_mutex());
     State &s = st();
     s.gdim = grid;
     s.bdim = block;

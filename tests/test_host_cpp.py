@@ -114,6 +114,17 @@ def test_sc_oneshot_rocket2d_default_model(oracle, host_emu, tmp_path):
     _check_rocket2d_oneshot(oracle, os.path.join(host_emu, "sc_oneshot_rocket2d_emu"), tmp_path, K=12)
 
 
+def test_sc_oneshot_gpus_shards_equal_single_device(host_emu, tmp_path):
+    """`sc_oneshot --batch B --gpus N`: one host thread + one device context per GPU, contiguous static shards (uneven here),
+    results concatenated in instance order -- the same trajectories as the single-context run (checksum over every state)."""
+    exe = os.path.join(host_emu, "sc_oneshot_emu")
+    one = subprocess.check_output([exe, "--K", "8", "--batch", "5", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    two = subprocess.check_output([exe, "--K", "8", "--batch", "5", "--gpus", "2", "--config", CONFIG, "--out", str(tmp_path)], text=True)
+    cs = lambda t: [l for l in t.splitlines() if l.startswith("checksum X")][0]
+    assert "batch 5 on 2 GPUs:" in two and "solver failures 0" in two
+    assert cs(one) == cs(two)
+
+
 def test_sc_oneshot_scvx_mode(oracle, host_emu, tmp_path):
     """`sc_oneshot --scvx`: the C++ SCvxAlgorithm front end over scpp_hip_scvx_*, against the oracle's SCvx run."""
     K = 10
