@@ -56,11 +56,7 @@ struct DiscLayout
     // integrated psi_z to round-off (the defect ODE of that combination is exactly the reference's z ODE)
     static constexpr int NCOLS = 1 + NX + NU + (FOH ? NU : 0) + (VT ? 1 : 0);
     static constexpr int NENT = NX * NCOLS;
-#ifndef DISC_VALU_PRODUCT
     static constexpr int NG = WAVE / 16;                                // lane groups: lane = g * 16 + row (MFMA operand rows)
-#else
-    static constexpr int NG = WAVE / NX;                                // lane groups: lane = g * NX + row
-#endif
     static constexpr int EPL = (NCOLS + NG - 1) / NG;                   // columns per lane: col = m * NG + g
     // column order [x | psi_s | Phi | Psi_B | Psi_C]: with NG = 4 groups (RocketQuat) the B and the C columns each
     // fill one column slot m exactly, so their forcing terms need no per-lane selection
@@ -81,25 +77,13 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     using L = DiscLayout<Model, FOH, VT>;
     constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
 
-#ifndef DISC_VALU_PRODUCT
     // (J V)' = V' J' on the matrix core: V' is the A operand of v_mfma_f64_16x16x4_f64, read straight from Ys (two column
     // tiles; the contraction index runs to 16, so Ys is zero-filled once and padded to 32 columns), J' the B operand, taken
     // from the Jacobian row each lane holds in registers.  No staging, no extra synchronisation.
     static_assert(NX <= 16 && NCOLS + NG <= 32 && NG == 4, "one 16-row tile of states, two 16-column tiles of V");
     __shared__ __attribute__((aligned(16))) double Ys[32 * NX + 2];
-#else
-    __shared__ __attribute__((aligned(16))) double Ys[(NCOLS + NG) * NX]; // stage values of V (column-major: col*NX + row)
-#endif
     __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major (-DDISC_AD_JACOBIAN only)
     __shared__ double fv[NX];                                              // f(x,u) (unscaled)            (-DDISC_AD_JACOBIAN only)
-    // -DDISC_KSLOTS_LDS keeps the stage slopes with the longest lifetimes (k1, k4, k5, k6: needed until stage 13) in LDS:
-    // with the forward-mode AD path all 13 x EPL in registers (156 VGPRs) plus the AD temporaries exceeded the 256-VGPR
-    // budget of two waves per SIMD and spilled inside the AD chain.  The default path needs no such slots.
-#ifdef DISC_KSLOTS_LDS
-    __shared__ double Kl[4][EPL][WAVE];
-#else
-    __shared__ double Kl[1][1][1]; // unused: with the analytic rows and the MFMA product all 13 x EPL slopes fit in registers
-#endif
     // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 row evaluations need.
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
     // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the evaluation phase.
@@ -108,23 +92,19 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
     constexpr int UHP = NUAUX + 1 + NU;           // per stage time: input-only sub-expressions, t / dt, u(t)
     __shared__ double uh[5 * RK_S * UHP];
-#if !defined(DISC_VALU_PRODUCT) && !defined(DISC_SWITCH_ROWS)
 #define DISC_TABLE_ROWS 1
     // Jacobian entries as a lane-parallel table (Model::JacobianTable): one output per lane per pass instead of one divergent
     // `case` per row; W holds the operands, the partial sums and the outputs [J | f]
     using TB = typename Model::JacobianTable;
     __shared__ __attribute__((aligned(16))) double Wt[TB::NW];
-#endif
 #else
     constexpr int NAUX = 0;
 #endif
     __shared__ double cst[NP + 2 * NU + NAUX + 1];
 
     const int lane = threadIdx.x;
-#ifndef DISC_VALU_PRODUCT
     for (int i = lane; i < 32 * NX + 2; i += WAVE)
         Ys[i] = 0.;
-#endif
     // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
     // give one XCD all K-1 segments of an instance (they re-read the same X/U/par lines).
     const int nseg = K - 1;
@@ -231,15 +211,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #endif
     // Lane (g, row) owns entries (row, col = m*NG + g), m = 0..EPL-1: it needs ONE row of the Jacobian tile per
     // stage (kept in registers for all its columns) and one column of V per entry.
-#ifndef DISC_VALU_PRODUCT
     // lane = g * 16 + row: the layout in which v_mfma_f64_16x16x4_f64 delivers (J V)' -- lane (g, row), accumulator register
     // r holds the derivative of entry (row, col = g + 4 r), i.e. exactly the entries m = r this lane integrates
     const int row = lane & 15, g = lane >> 4;
     const bool lane_on = row < NX;
-#else
-    const bool lane_on = lane < NG * NX;
-    const int row = lane % NX, g = lane_on ? lane / NX : NG - 1;
-#endif
 #ifndef SCPP_HIP_EMU
     __builtin_assume(g >= 0 && g < NG);
 #endif
@@ -260,11 +235,6 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 
     double kk[RK_S][EPL];
-#ifdef DISC_KSLOTS_LDS
-    constexpr int KSLOT[RK_S] = {0, -1, -1, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1}; // LDS slot of stage j, -1: registers
-#else
-    constexpr int KSLOT[RK_S] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}; // all stage slopes in registers
-#endif
     const double h = dt / 5.;
 #ifdef DISC_PROFILE
     long long tA = 0, tB = 0, tC = 0;
@@ -291,7 +261,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
                 for (int j = 0; j < s; j++)
                     if (RK_A[s][j] != 0.)
-                        acc += RK_A[s][j] * (KSLOT[j] >= 0 ? Kl[KSLOT[j] >= 0 ? KSLOT[j] : 0][m][lane] : kk[j][m]);
+                        acc += RK_A[s][j] * kk[j][m];
                 const double ys = y[m] + h * acc;
                 if (eon[m])
                     Ys[(m * NG + g) * NX + row] = ys;
@@ -387,11 +357,6 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                     us[i] = a0 + frac * (a1 - a0);
                 }
                 fr = Model::JacobianRows::row(row, xs, us, pl, ax, ux, jr);
-#ifdef DISC_VALU_PRODUCT
-#pragma unroll
-                for (int j = 0; j < NJ; j++)
-                    jr[j] *= tscale;
-#endif
             }
 #else
             // ---- Jacobian tile by forward-mode AD, one seed direction per lane ----
@@ -442,7 +407,6 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             // ---- derivative of the owned entries: d(row, c) = J[row,:] V[:,c] + forcing(row, c), branch-free ----
             {
                 const double alphaB = FOH ? (1. - frac) : 1.;
-#ifndef DISC_VALU_PRODUCT
                 d4_t acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
 #pragma unroll
                 for (int t = 0; t < 4; t++)
@@ -463,19 +427,11 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                     if (NCOLS > 16)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ys[(16 + row) * NX + kx], b, acc1, 0, 0, 0);
                 }
-#endif
 #pragma unroll
                 for (int m = 0; m < EPL; m++)
                 {
                     const int c = m * NG + g;
-#ifndef DISC_VALU_PRODUCT
                     const double acc = m < 4 ? acc0[m < 4 ? m : 0] : acc1[m >= 4 ? m - 4 : 0];
-#else
-                    double acc = 0.;
-#pragma unroll
-                    for (int j = 0; j < NX; j++)
-                        acc += jr[j] * Ys[c * NX + j];
-#endif
                     // forcing: B columns J[row, NX+j] * alpha ; C columns J[row, NX+j] * frac ; s column f ; x column: sigma f only.
                     // Which kinds can occur in slot m is a compile-time fact (m is a constant after unrolling).
                     double d = acc;
@@ -495,7 +451,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                         for (int q = 1; q < NU; q++)
                             jb = (jj == q) ? jr[NX + q] : jb;
 #endif
-#if !defined(DISC_VALU_PRODUCT) && !defined(DISC_AD_JACOBIAN)
+#ifndef DISC_AD_JACOBIAN
                         d += (w * tscale) * jb; // sigma scaling of B
 #else
                         d += w * jb;
@@ -505,10 +461,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                         d = (c == L::COL_S) ? d + fr : d;
                     if (m == 0)
                         d = (c == 0) ? tscale * fr : d;
-                    if (KSLOT[s] >= 0)
-                        Kl[KSLOT[s] >= 0 ? KSLOT[s] : 0][m][lane] = d;
-                    else
-                        kk[s][m] = d;
+                    kk[s][m] = d;
                 }
             }
             WAVE_SYNC();
@@ -524,7 +477,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #pragma unroll
             for (int s = 0; s < RK_S; s++)
                 if (RK_B[s] != 0.)
-                    acc += RK_B[s] * (KSLOT[s] >= 0 ? Kl[KSLOT[s] >= 0 ? KSLOT[s] : 0][m][lane] : kk[s][m]);
+                    acc += RK_B[s] * kk[s][m];
             y[m] += h * acc;
         }
     }
