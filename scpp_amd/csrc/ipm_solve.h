@@ -570,7 +570,7 @@ __device__ inline void zeroT(const SV &st)
 #ifdef SCPP_HIP_EMU
 #define PHASE_FN inline
 #else
-#define PHASE_FN __device__ __attribute__((noinline))
+#define PHASE_FN static __device__ __attribute__((noinline))
 #endif
 
 // wave-uniform state of one solve

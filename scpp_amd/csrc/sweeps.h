@@ -16,7 +16,7 @@ namespace ipm
 {
 
 #ifndef SWEEPS_INLINE
-#define SWEEP_FN __device__ __attribute__((noinline))
+#define SWEEP_FN static __device__ __attribute__((noinline))
 #else
 #define SWEEP_FN __device__ inline __attribute__((always_inline))
 #endif
