@@ -22,6 +22,7 @@ Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.d
 """
 import argparse
 import glob
+import re
 import json
 import os
 import sys
@@ -111,7 +112,12 @@ def measured_traffic():
     """HBM bytes per instance-IPM-iteration of ipm_kernel from the newest committed PMC summary (tools/pmc_hbm.sh ->
     profiles/r*_pmc_hbm_*.json); None if there is none."""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_*.json"))):
+
+    def version(f):
+        m = re.search(r"r(\d+)_pmc_hbm_v(\d+)([a-z]?)", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2)), m.group(3)) if m else (-1, -1, "")
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_v*.json")), key=version):
         try:
             d = json.load(open(f))
             if "ipm_bytes_per_instance_iteration" in d:
