@@ -595,6 +595,16 @@ __device__ inline T loadPriv(const PRIV T *p)
     __builtin_memcpy(&t, p, sizeof(T));
     return t;
 }
+// a second, late copy-in: the barrier keeps the compiler from merging it with loads at the top of the phase, so wave-uniform
+// values that are only needed in a phase's tail do not occupy VGPRs across its load / compute / store groups
+template <class T>
+__device__ inline T reloadPriv(const PRIV T *p)
+{
+#ifndef SCPP_HIP_EMU
+    asm volatile("" ::: "memory");
+#endif
+    return loadPriv(p);
+}
 template <class T>
 __device__ inline void storePriv(PRIV T *p, const T &t)
 {
@@ -602,6 +612,30 @@ __device__ inline void storePriv(PRIV T *p, const T &t)
     if (threadIdx.x == 0)
         __builtin_memcpy(p, &t, sizeof(T));
 }
+
+// Field-wise write-back: a phase that copies the whole struct out again keeps every field alive in VGPRs from its first
+// instruction to its last (~80 wave-uniform doubles = 160 VGPRs in the per-iteration phases, measured in the ISA: all ds_read
+// at the top, all ds_write at the bottom), which is what pushed those phases into the callee-saved registers and into scratch.
+// The per-iteration phases therefore store only what they change: PUT(ptr, obj, field) inside PUT_BEGIN / PUT_END.
+template <class T>
+__device__ inline void putv(PRIV T &dst, const T &src)
+{
+    dst = src;
+}
+template <class T, int N>
+__device__ inline void putv(PRIV T (&dst)[N], const T (&src)[N])
+{
+    for (int i = 0; i < N; i++)
+        dst[i] = src[i];
+}
+#define PUT(ptr, obj, f) putv((ptr)->f, (obj).f)
+#define PUT_BEGIN()                                                                                                    \
+    WAVE_SYNC(); /* every lane has read the old values */                                                              \
+    if (threadIdx.x == 0)                                                                                              \
+    {
+#define PUT_END()                                                                                                      \
+    }                                                                                                                  \
+    WAVE_SYNC()
 
 // lane-local views used by every phase
 struct Views
@@ -1008,16 +1042,15 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &sgP = v.sgP, &dy = v.dy, &dyP = v.dyP;
     const double *ip = c.ip;
     const unsigned fm = v.fm;
-    const Glob g = loadPriv(gp);
-    Iter it = loadPriv(ip_);
+    const double g_z3 = gp->z3, g_sig = gp->sig, it_wtrx = ip_->wtrx;
     ResAcc p;
     p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
     double p_dl = 0.;
     if (v.vsg)
     {
-        resSegChunk<P, 0, L::SC1>(sg, dy, g.z3, p);
-        resSegChunk<P, L::SC1, L::SC2>(sg, dy, g.z3, p);
-        resSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, dy, g.z3, p);
+        resSegChunk<P, 0, L::SC1>(sg, dy, g_z3, p);
+        resSegChunk<P, L::SC1, L::SC2>(sg, dy, g_z3, p);
+        resSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, dy, g_z3, p);
     }
     if (v.vst)
     {
@@ -1049,7 +1082,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             }
             LTmul<P>(ip, fm, zv, uh, gw, &gdl);
         }
-        const double rxd = (ip[IP_SCVX] != 0.) ? 0. : it.wtrx - gdl; // SCvx: delta_k is not a variable
+        const double rxd = (ip[IP_SCVX] != 0.) ? 0. : it_wtrx - gdl; // SCvx: delta_k is not a variable
         // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
         // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
         constexpr int NXV = P::NXV, NUV = P::NUV;
@@ -1069,7 +1102,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = dyP[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
             const double l = mk * double(sg[G_LAM * L::NL + i]), lp = mp * double(sgP[G_LAM * L::NL + i]);
             const int xi = L::XINV.v[i]; // stage variable of state i, -1: pinned
-            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dy[L::DY_S + i] * g.sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
+            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dy[L::DY_S + i] * g_sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
 #pragma unroll
             for (int j = 0; j < NXV; j++)
             {
@@ -1116,6 +1149,8 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     p.rxs = wave_sum(p.rxs);
     p.sumnb = wave_sum(p.sumnb);
     p_dl = wave_sum(p_dl);
+    const Glob g = reloadPriv(gp);
+    Iter it = reloadPriv(ip_);
     const double sas = g.sig - 0.001, sa3 = g.n1 - p.sumnb;
     const double sac[3] = {0.5 + 0.5 * g.dsg, 0.5 - 0.5 * g.dsg, g.sig - g.sigbar};
     it.rzs = g.ss - sas;
@@ -1167,9 +1202,27 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             it.bk_n1 = g.n1;
             it.bk_valid = 1;
         }
+        PUT_BEGIN();
+        PUT(ip_, it, rzs);
+        PUT(ip_, it, rz3);
+        PUT(ip_, it, rzc);
+        PUT(ip_, it, rxs);
+        PUT(ip_, it, rxds);
+        PUT(ip_, it, rxn1);
+        PUT(ip_, it, gap);
+        PUT(ip_, it, mu);
+        PUT(ip_, it, pcost);
+        PUT(ip_, it, pres);
+        PUT(ip_, it, dres);
+        if (inacc)
+        {
+            PUT(ip_, it, bk_sig);
+            PUT(ip_, it, bk_dsg);
+            PUT(ip_, it, bk_n1);
+            PUT(ip_, it, bk_valid);
+        }
+        PUT_END();
     }
-    storePriv(ip_, it);
-    WAVE_SYNC();
 }
 
 // ---- Nesterov-Todd scalings and the per-stage factorisation inputs ----
@@ -1210,9 +1263,15 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         WAVE_SYNC();
         prepareFactor<P>(c, false, g);
     }
+    PUT_BEGIN();
     ip_->bad = bad;
-    storePriv(gp, g);
-    WAVE_SYNC();
+    PUT(gp, g, seta);
+    PUT(gp, g, sw);
+    PUT(gp, g, lamC);
+    PUT(gp, g, Hsd);
+    PUT(gp, g, Hdd);
+    PUT(gp, g, hsig);
+    PUT_END();
 }
 
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
@@ -1324,6 +1383,17 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
     g.dz3 = -b.n1;
     it.bts = b.s - g.Hsd * b.ds / g.Hdd;
     it.b = b;
+    const double g_dz3 = g.dz3;
+    PUT_BEGIN();
+    PUT(gp, g, dz3);
+    PUT(ip_, it, tzs);
+    PUT(ip_, it, tzc);
+    PUT(ip_, it, b.s);
+    PUT(ip_, it, b.ds);
+    PUT(ip_, it, b.n1);
+    PUT(ip_, it, b.rhs3);
+    PUT(ip_, it, bts);
+    PUT_END();
     // ---- stages ----
     if (v.vst)
     {
@@ -1373,12 +1443,10 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
     }
     if (v.vsg)
     {
-        rhsSegChunk<P, 0, L::SC1>(sg, pass, om, sigmu, g.dz3);
-        rhsSegChunk<P, L::SC1, L::SC2>(sg, pass, om, sigmu, g.dz3);
-        rhsSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, pass, om, sigmu, g.dz3);
+        rhsSegChunk<P, 0, L::SC1>(sg, pass, om, sigmu, g_dz3);
+        rhsSegChunk<P, L::SC1, L::SC2>(sg, pass, om, sigmu, g_dz3);
+        rhsSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, pass, om, sigmu, g_dz3);
     }
-    storePriv(gp, g);
-    storePriv(ip_, it);
     WAVE_SYNC();
 }
 
@@ -1444,9 +1512,11 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
     const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     const unsigned act = v.act;
-    Glob g = loadPriv(gp);
-    Iter it = loadPriv(ip_);
-    const double sigma_c = pass ? it.sigma_c : 0.;
+    Glob g;   // the fields this phase produces (the rest is read where it is needed)
+    Iter it;
+    it.bad = ip_->bad;
+    g.schur = gp->schur;
+    const double sigma_c = pass ? double(ip_->sigma_c) : 0.;
     const double om = 1. - sigma_c;
     // ---- sigma row: border correction (and the border's Schur complement, once per factorisation) ----
     {
@@ -1468,18 +1538,18 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
         if (pass == 0)
         {
             bs = wave_sum(bs);
-            g.schur = g.hsig - bs;
+            g.schur = gp->hsig - bs;
         }
         if (!(g.schur > 0.))
         {
             it.bad = 1;
 #ifdef SCPP_HIP_EMU
             if (c.lane == 0 && getenv("SCPP_EMU_DEBUG"))
-                printf("[emu] schur %g hsig %g\n", g.schur, g.hsig);
+                printf("[emu] schur %g hsig %g\n", g.schur, double(gp->hsig));
 #endif
         }
-        g.dsig = (it.bts - cv) / g.schur;
-        g.ddsg = (it.b.ds - g.Hsd * g.dsig) / g.Hdd;
+        g.dsig = (ip_->bts - cv) / g.schur;
+        g.ddsg = (ip_->b.ds - gp->Hsd * g.dsig) / gp->Hdd;
     }
     double ainv = 0., finite_chk = g.dsig * 0. + g.ddsg * 0.;
     if (v.vst)
@@ -1545,37 +1615,39 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
         dirSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
     }
     sumdnb = wave_sum(sumdnb);
+    const Glob gt = reloadPriv(gp);
+    const Iter itt = reloadPriv(ip_);
     // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
     // (sumdnb carries dlam through dnu / dnub)
     finite_chk = wave_sum(finite_chk + sumdnb * 0.);
     if (!(finite_chk == 0.))
         it.bad = 1;
-    g.dn1 = sumdnb - (g.s3 / g.z3) * g.dz3 - it.b.rhs3;
-    g.dzs = -(g.zs / g.ss) * g.dsig + it.tzs;
-    g.dss = -om * it.rzs + g.dsig;
+    g.dn1 = sumdnb - (gt.s3 / gt.z3) * gt.dz3 - itt.b.rhs3;
+    g.dzs = -(gt.zs / gt.ss) * g.dsig + itt.tzs;
+    g.dss = -om * itt.rzs + g.dsig;
     {
-        const double m1 = -g.dss / g.ss, m2 = -g.dzs / g.zs;
+        const double m1 = -g.dss / gt.ss, m2 = -g.dzs / gt.zs;
         ainv = m1 > ainv ? m1 : ainv;
         ainv = m2 > ainv ? m2 : ainv;
     }
-    g.ds3 = -om * it.rz3 + (g.dn1 - sumdnb);
+    g.ds3 = -om * itt.rz3 + (g.dn1 - sumdnb);
     {
-        const double m1 = -g.ds3 / g.s3, m2 = -g.dz3 / g.z3;
+        const double m1 = -g.ds3 / gt.s3, m2 = -gt.dz3 / gt.z3;
         ainv = m1 > ainv ? m1 : ainv;
         ainv = m2 > ainv ? m2 : ainv;
     }
     {
         const double Ld[3] = {0.5 * g.ddsg, -0.5 * g.ddsg, g.dsig};
         double aa[3];
-        cone::applyWinv2(g.seta, g.sw, 3, Ld, aa);
+        cone::applyWinv2(gt.seta, gt.sw, 3, Ld, aa);
         for (int i = 0; i < 3; i++)
         {
-            g.dzc3[i] = -aa[i] + it.tzc[i];
-            g.dsc3[i] = -om * it.rzc[i] + Ld[i];
+            g.dzc3[i] = -aa[i] + itt.tzc[i];
+            g.dsc3[i] = -om * itt.rzc[i] + Ld[i];
         }
-        cone::applyWinv(g.seta, g.sw, 3, g.dsc3, g.dsC);
-        cone::applyW(g.seta, g.sw, 3, g.dzc3, g.dzC);
-        const double a1 = cone::stepInv(3, g.lamC, g.dsC), a2 = cone::stepInv(3, g.lamC, g.dzC);
+        cone::applyWinv(gt.seta, gt.sw, 3, g.dsc3, g.dsC);
+        cone::applyW(gt.seta, gt.sw, 3, g.dzc3, g.dzC);
+        const double a1 = cone::stepInv(3, gt.lamC, g.dsC), a2 = cone::stepInv(3, gt.lamC, g.dzC);
         ainv = a1 > ainv ? a1 : ainv;
         ainv = a2 > ainv ? a2 : ainv;
     }
@@ -1591,15 +1663,32 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
     }
     else
     {
-        double alpha = ainv > 0. ? it.gamma / ainv : 1.;
+        double alpha = ainv > 0. ? itt.gamma / ainv : 1.;
         alpha = alpha < 1. ? alpha : 1.;
         alpha = alpha < 0.999 ? alpha : 0.999;
         alpha = alpha > 1e-8 ? alpha : 1e-8;
         it.alpha = alpha;
     }
-    storePriv(gp, g);
-    storePriv(ip_, it);
-    WAVE_SYNC();
+    PUT_BEGIN();
+    if (pass == 0)
+    {
+        PUT(gp, g, schur);
+        PUT(ip_, it, sigma_c);
+    }
+    else
+        PUT(ip_, it, alpha);
+    PUT(ip_, it, bad);
+    PUT(gp, g, dsig);
+    PUT(gp, g, ddsg);
+    PUT(gp, g, dn1);
+    PUT(gp, g, dzs);
+    PUT(gp, g, dss);
+    PUT(gp, g, ds3);
+    PUT(gp, g, dzc3);
+    PUT(gp, g, dsc3);
+    PUT(gp, g, dsC);
+    PUT(gp, g, dzC);
+    PUT_END();
 }
 
 // ---- x += alpha dx ; s += alpha ds ; z += alpha dz ----
@@ -1667,8 +1756,17 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         g.sc3[i] += alpha * g.dsc3[i];
         g.zc3[i] += alpha * g.dzc3[i];
     }
-    storePriv(gp, g);
-    WAVE_SYNC();
+    PUT_BEGIN();
+    PUT(gp, g, sig);
+    PUT(gp, g, dsg);
+    PUT(gp, g, n1);
+    PUT(gp, g, ss);
+    PUT(gp, g, zs);
+    PUT(gp, g, s3);
+    PUT(gp, g, z3);
+    PUT(gp, g, sc3);
+    PUT(gp, g, zc3);
+    PUT_END();
 }
 
 #ifndef IPM_WAVES_PER_SIMD
