@@ -49,10 +49,7 @@ struct Lay : Derived<P>
     static constexpr int F_HDW = F_HDD + 1;       // [16]
     static constexpr int F_RXW = F_HDW + NV;      // [16]
     static constexpr int F_RXD = F_RXW + NV;
-    static constexpr int F_BETA = F_RXD + 1;      // [16]
-    static constexpr int F_BCW = F_BETA + NV;     // [16] border column (w part)
-    static constexpr int F_VW = F_BCW + NV;       // [16] block-solve output
-    static constexpr int F_S = F_VW + NV;         // [NS]
+    static constexpr int F_S = F_RXD + 1;         // [NS]
     static constexpr int F_Z = F_S + NS;
     static constexpr int F_DS = F_Z + NS;
     static constexpr int F_DZ = F_DS + NS;
@@ -65,10 +62,24 @@ struct Lay : Derived<P>
     static constexpr int F_WB = F_ETA + D::NCONES; // [LP0] wbar of the cones, same offsets as the slack layout
     static constexpr int F_BXW = F_WB + D::LP0;   // [16] right-hand side (w part)
     static constexpr int F_BXD = F_BXW + NV;
-    static constexpr int F_HS = F_BXD + 1;        // [HS_N] small Hessian blocks of the application cones / LP rows
-    static constexpr int F_HC = F_HS + HS_N;      // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
-    static constexpr int F_WBK = F_HC + 2;        // [17] W and delta of the last iterate that met the reduced tolerances
+    static constexpr int F_WBK = F_BXD + 1;       // [17] W and delta of the last iterate that met the reduced tolerances
     static constexpr int STREC = F_WBK + NV + 1;
+    // ---- exchange record, STAGE-major: sx[k][XREC].  Everything the tile sweeps read or write per stage as single entries
+    //      (right-hand sides in, solutions out, the Hessian inputs of the factorisation).  In the field-major records each of
+    //      these ~210 accesses per stage and iteration touched its own 128-byte line for 8 useful bytes; here a stage's
+    //      entries are 10 consecutive lines, and the lane = stage phases reach them with one stride-XREC access per field.
+    static constexpr int X_BETA = 0;              // [16] condensed right-hand side (w part)         phases -> sweeps
+    static constexpr int X_BCW = X_BETA + NV;     // [16] border column of the block solve (w part)  sweeps -> phases
+    static constexpr int X_VW = X_BCW + NV;       // [16] block-solve output (w part)                sweeps -> phases
+    static constexpr int X_HS = X_VW + NV;        // [HS_N] small Hessian blocks of the application cones / LP rows
+    static constexpr int X_HC = X_HS + HS_N;      // [2]  {1/eta1^2, 2/(2 w0^2 - 1)} of the trust-region cone
+    static constexpr int X_WBT = X_VW + NV + 32;  // [16] wbar_1..16 of the trust-region cone (copy of F_WB + 1 ..)
+    static constexpr int X_RHO = X_WBT + NV;      // [NL] condensed right-hand side (multiplier part)
+    static constexpr int X_BCL = X_RHO + 16;      // [NL] border column (multiplier part)
+    static constexpr int X_VL = X_BCL + 16;       // [NL] block-solve output (multiplier part)
+    static constexpr int X_EINV = X_VL + 16;      // [NL] E^-1 of the segment
+    static constexpr int XREC = X_EINV + 16;      // 160 doubles = ten 128-byte lines
+    static_assert(HS_N + 2 <= 32 && NL <= 16 && XREC % 16 == 0, "exchange record layout");
     // ---- segment record: G_NFIELDS fields of NL doubles (enum SegField) ----
     // ---- per-stage factor record, PACKED (the kernel is HBM-throughput bound): Li lower triangle (136), Yt 16 x NL,
     //      Ti lower triangle of the NL x NL block.  Z = Ti N is not stored: N = [I | -C] makes it 4 extra matrix-core
@@ -104,14 +115,10 @@ enum SegField
     G_RZ2,
     G_TZ1,
     G_TZ2,
-    G_EINV,
     G_QV,
-    G_RHO,
     G_BTN,
     G_BNB,
     G_DINV,
-    G_BCL,
-    G_VL,
     G_CV,
     G_BXNU,
     G_BXNUB,
@@ -132,7 +139,9 @@ template <class P>
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
     using L = Lay<P>;
-    return size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE;
+    // the exchange records come first so that they start on a 128-byte line; the total is a multiple of a line
+    const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE;
+    return (n + 15) & ~size_t(15);
 }
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is
@@ -175,6 +184,11 @@ __device__ inline SV makeSV(double *block, int nfields, unsigned lane_index, int
 {
     return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, nfields * pitch * 8, 0x00020000), int(lane_index * 8u), 0, pitch * 8};
 }
+// the same view type over the stage-major exchange records: lane offset = stage * XREC, field pitch 8 bytes
+__device__ inline SV makeSX(double *block, int xrec, int K, unsigned stage)
+{
+    return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, K * xrec * 8, 0x00020000), int(stage * unsigned(xrec) * 8u), 0, 8};
+}
 
 struct Settings
 {
@@ -193,6 +207,7 @@ struct Ctx
     double *dy;  // [DYNREC][pitch]  field-major copy of A,B,C,s,z
     double *fac; // [K][FACREC]
     double *sv;  // [K][SVREC]
+    double *sx;  // [K][XREC]        stage-major exchange records (sweeps <-> phases)
     double *gsave; // [GSAVE]
     const double *A, *B, *C, *S, *Z; // dd of this instance
     const double *ip;                // instance parameters
@@ -424,7 +439,7 @@ __device__ inline void dynResF(const SV &dy, A0 w0, A1 w1, AN nuv, double sig, d
 }
 
 // Per-stage Hessian data (delta_k eliminated) for the in-sweep tile build: F_HDD, F_HDW (delta elimination),
-// F_HC = {1/eta1^2, 2/den} of the trust-region cone and F_HS = the small dense blocks contributed by the application
+// X_HC = {1/eta1^2, 2/den} of the trust-region cone and X_HS = the small dense blocks contributed by the application
 // cones / LP rows (layout: Derived<P>::PAT).
 template <class P>
 __device__ inline int hsIndex(int a, int b)
@@ -469,6 +484,7 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
     const unsigned fm = L::fixedMask(k, c.K), act = L::activeMask(k, c.K);
     const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
     const SV eta = st + L::F_ETA, wb = st + L::F_WB, uh = st + L::F_UHAT;
+    const SV xs = makeSX(c.sx, L::XREC, c.K, unsigned(k));
     double Hs[L::HS_N > 0 ? L::HS_N : 1];
     for (int i = 0; i < L::HS_N; i++)
         Hs[i] = 0.;
@@ -480,9 +496,13 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         // on the rows that exist (the mask is applied where the tile is built, sweeps.h buildHTile)
         st[L::F_HDD] = scvx ? 1. : den * e2;
         for (int j = 0; j < NV; j++)
-            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wb[1 + j] * e2;
-        st[L::F_HC] = e2;
-        st[L::F_HC + 1] = scvx ? -2. : 2. / den;
+        {
+            const double wj = wb[1 + j];
+            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wj * e2;
+            xs[L::X_WBT + j] = wj;
+        }
+        xs[L::X_HC] = e2;
+        xs[L::X_HC + 1] = scvx ? -2. : 2. / den;
     }
     sfor<P::NCONE>([&](auto ct) {
         SFOR_IDX(C, ct);
@@ -517,7 +537,7 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         }
     });
     for (int i = 0; i < L::HS_N; i++)
-        st[L::F_HS + i] = Hs[i];
+        xs[L::X_HS + i] = Hs[i];
 }
 
 } // namespace ipm

@@ -61,17 +61,18 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     if (k < K - 1)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
         for (int i = 0; i < L::NL; i++)
         {
             if (identity)
             {
-                sg[G_EINV * L::NL + i] = 0.5;
+                xs[L::X_EINV + i] = 0.5;
                 sg[G_QV * L::NL + i] = 0.;
             }
             else
             {
                 const double r1 = sg[G_S1 * L::NL + i] / sg[G_Z1 * L::NL + i], r2 = sg[G_S2 * L::NL + i] / sg[G_Z2 * L::NL + i];
-                sg[G_EINV * L::NL + i] = 0.25 * (r1 + r2);
+                xs[L::X_EINV + i] = 0.25 * (r1 + r2);
                 sg[G_QV * L::NL + i] = (r1 - r2) / (r1 + r2);
             }
         }
@@ -99,9 +100,9 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
 }
 
 // Reduced KKT solve, part 1: condensed right-hand side.  Input: L::F_BXW/L::F_BXD, G_BXNU/G_BXNUB/G_BY and b.
-// Output: stage field fBeta (16) and segment field gRho (14) for the sweeps; returns the sigma-row rhs.
+// Output: X_BETA (16) and X_RHO (NL) of the exchange records for the sweeps; returns the sigma-row rhs.
 template <class P>
-__device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs &b, int fBeta, int gRho)
+__device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs &b)
 {
     using L = Lay<P>;
     const int k = c.lane, K = c.K;
@@ -109,6 +110,7 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
     if (k < K - 1)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
         for (int i = 0; i < L::NL; i++)
         {
             const double d1 = dLP(identity, sg[G_S1 * L::NL + i], sg[G_Z1 * L::NL + i]);
@@ -118,15 +120,16 @@ __device__ inline double kktPrep(const Ctx &c, bool identity, Glob &g, const Rhs
             const double btn = sg[G_BXNU * L::NL + i] - sg[G_QV * L::NL + i] * bnb;
             sg[G_BNB * L::NL + i] = bnb;
             sg[G_BTN * L::NL + i] = btn;
-            sg[gRho * L::NL + i] = sg[G_BY * L::NL + i] + sg[G_EINV * L::NL + i] * btn;
+            xs[L::X_RHO + i] = sg[G_BY * L::NL + i] + xs[L::X_EINV + i] * btn;
         }
     }
     if (k < K)
     {
         const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
         const unsigned fm = L::fixedMask(k, K);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
         for (int j = 0; j < NV; j++)
-            st[fBeta + j] = (fm & (1u << j)) ? 0. : st[L::F_BXW + j] - st[L::F_HDW + j] * st[L::F_BXD] / st[L::F_HDD];
+            xs[L::X_BETA + j] = (fm & (1u << j)) ? 0. : st[L::F_BXW + j] - st[L::F_HDW + j] * st[L::F_BXD] / st[L::F_HDD];
     }
     return b.s - g.Hsd * b.ds / g.Hdd;
 }
@@ -140,22 +143,22 @@ __device__ inline void borderSchur(const Ctx &c, Glob &g)
     double acc = 0.;
     if (k < K - 1)
         for (int i = 0; i < L::NL; i++)
-            acc += -c.S[k * P::NX + i] * c.sg[size_t(G_BCL * L::NL + i) * c.pitch + k];
+            acc += -c.S[k * P::NX + i] * c.sx[size_t(k) * L::XREC + L::X_BCL + i];
     acc = wave_sum(acc);
     g.schur = g.hsig - acc;
 }
 
-// part 2: after the sweeps left T_mat^-1 [beta;rho] in fVW / gVL: border correction and recovery of the
+// part 2: after the sweeps left T_mat^-1 [beta;rho] in X_VW / X_VL: border correction and recovery of the
 // eliminated variables.
 template <class P>
-__device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs &b, double bts, int fVW, int gVL)
+__device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs &b, double bts)
 {
     using L = Lay<P>;
     const int k = c.lane, K = c.K;
     double cv = 0.;
     if (k < K - 1)
         for (int i = 0; i < L::NL; i++)
-            cv += -c.S[k * P::NX + i] * c.sg[size_t(gVL * L::NL + i) * c.pitch + k];
+            cv += -c.S[k * P::NX + i] * c.sx[size_t(k) * L::XREC + L::X_VL + i];
     cv = wave_sum(cv);
     g.dsig = (bts - cv) / g.schur;
     g.ddsg = (b.ds - g.Hsd * g.dsig) / g.Hdd;
@@ -163,10 +166,11 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     if (k < K)
     {
         const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
         double acc = 0.;
         for (int j = 0; j < NV; j++)
         {
-            const double d = st[fVW + j] - st[L::F_BCW + j] * g.dsig;
+            const double d = xs[L::X_VW + j] - xs[L::X_BCW + j] * g.dsig;
             st[L::F_DW + j] = d;
             acc += st[L::F_HDW + j] * d;
         }
@@ -175,11 +179,12 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     if (k < K - 1)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
         for (int i = 0; i < L::NL; i++)
         {
-            const double dl = sg[gVL * L::NL + i] - sg[G_BCL * L::NL + i] * g.dsig;
+            const double dl = xs[L::X_VL + i] - xs[L::X_BCL + i] * g.dsig;
             sg[G_DLAM * L::NL + i] = dl;
-            const double dnu = sg[G_EINV * L::NL + i] * (dl + sg[G_BTN * L::NL + i]);
+            const double dnu = xs[L::X_EINV + i] * (dl + sg[G_BTN * L::NL + i]);
             const double dnub = sg[G_BNB * L::NL + i] * sg[G_DINV * L::NL + i] - sg[G_QV * L::NL + i] * dnu;
             sg[G_DNU * L::NL + i] = dnu;
             sg[G_DNUB * L::NL + i] = dnub;
@@ -191,24 +196,16 @@ __device__ inline void kktFinish(const Ctx &c, bool identity, Glob &g, const Rhs
     g.dn1 = sumnb - w3sq * g.dz3 - b.rhs3;
 }
 
-__device__ inline RhsSpec specBorderPlus(int fBeta, int gRho, int fOut, int gOut)
+__device__ inline RhsSpec specBorderPlus()
 {
     RhsSpec sp;
     sp.n = 2;
-    sp.fBeta = fBeta;
-    sp.gRho = gRho;
-    sp.fOut = fOut;
-    sp.gOut = gOut;
     return sp;
 }
-__device__ inline RhsSpec specSingle(int fBeta, int gRho, int fOut, int gOut)
+__device__ inline RhsSpec specSingle()
 {
     RhsSpec sp;
     sp.n = 1;
-    sp.fBeta = fBeta;
-    sp.gRho = gRho;
-    sp.fOut = fOut;
-    sp.gOut = gOut;
     return sp;
 }
 
@@ -441,6 +438,28 @@ __device__ inline void forEachCone(F &&f)
 }
 
 // ---- per-cone work on register arrays (compile-time offset / dimension) ----
+// segment rows [0, NL) in balanced chunks of at most CH rows: f(integral_constant<I0>, integral_constant<N>) per chunk
+template <class P, int CH, int J = 0, class F>
+__device__ inline void forSegChunks(F &&f)
+{
+    constexpr int NL = Lay<P>::NL, NCH = (NL + CH - 1) / CH;
+    if constexpr (J < NCH)
+    {
+        constexpr int base = NL / NCH, rem = NL % NCH;
+        constexpr int I0 = J * base + (J < rem ? J : rem), N = base + (J < rem ? 1 : 0);
+        f(std::integral_constant<int, I0>{}, std::integral_constant<int, N>{});
+        forSegChunks<P, CH, J + 1>(f);
+    }
+}
+#ifndef IPM_DIR_CHUNK
+#define IPM_DIR_CHUNK 5
+#endif
+#ifndef IPM_RHS_CHUNK
+#define IPM_RHS_CHUNK 5
+#endif
+#ifndef IPM_RES_CHUNK
+#define IPM_RES_CHUNK 5
+#endif
 template <int OFF, int D>
 __device__ inline void ldv(const SV &st, int f, double (&v)[D])
 {
@@ -644,6 +663,7 @@ struct Views
     bool vst, vsg;
     unsigned fm, act;
     SV st, stN, sg, sgP, dy, dyP;
+    SV xs; // this lane's exchange record (stage-major)
 };
 template <class P>
 __device__ inline Views makeViews(const Ctx &c)
@@ -661,7 +681,8 @@ __device__ inline Views makeViews(const Ctx &c)
             makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k < K - 1 ? k : 0), c.pitch),
             makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch),
             makeSV(c.dy, L::DYNREC, unsigned(k < K - 1 ? k : 0), c.pitch),
-            makeSV(c.dy, L::DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch)};
+            makeSV(c.dy, L::DYNREC, unsigned(k > 0 && k < K ? k - 1 : 0), c.pitch),
+            makeSX(c.sx, L::XREC, K, unsigned(k < K ? k : 0))};
     return v;
 }
 
@@ -712,8 +733,12 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
     // device memory is not zero-initialised: clear this lane's records (entries of inactive cones are
     // never written afterwards but are swept by the vector updates)
     if (v.vst && !warm)
+    {
         for (int i = 0; i < L::STREC; i++)
             st[i] = 0.;
+        for (int i = 0; i < L::XREC; i++)
+            v.xs[i] = 0.;
+    }
     if (v.vsg)
     {
         if (!warm)
@@ -814,7 +839,7 @@ PHASE_FN void phInitPrimalRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_
     b.ds = -(0.5 * (0.5 + 0.5 * g.dsg) - 0.5 * (0.5 - 0.5 * g.dsg));
     b.n1 = 0.;
     b.rhs3 = g.n1;
-    it.bts = kktPrep<P>(c, true, g, b, L::F_BETA, G_RHO);
+    it.bts = kktPrep<P>(c, true, g, b);
     it.b = b;
     storePriv(gp, g);
     storePriv(ip_, it);
@@ -828,7 +853,7 @@ PHASE_FN void phInitPrimalFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *
     Glob g = loadPriv(gp);
     const Iter it = loadPriv(ip_);
     borderSchur<P>(c, g);
-    kktFinish<P>(c, true, g, it.b, it.bts, L::F_VW, G_VL);
+    kktFinish<P>(c, true, g, it.b, it.bts);
     applyPrimalStep<P>(c, g, 1.);
     WAVE_SYNC();
     evalAllSaff<P>(c, g, L::F_S, G_S1, G_S2, g.ss, g.s3, g.sc3);
@@ -864,7 +889,7 @@ PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     b.ds = -it.w_trt;
     b.n1 = -it.w_vc;
     b.rhs3 = 0.;
-    it.bts = kktPrep<P>(c, true, g, b, L::F_BETA, G_RHO);
+    it.bts = kktPrep<P>(c, true, g, b);
     it.b = b;
     storePriv(gp, g);
     storePriv(ip_, it);
@@ -881,7 +906,7 @@ PHASE_FN void phInitDualFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip
     const double *ip = c.ip;
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
-    kktFinish<P>(c, true, g, it.b, it.bts, L::F_VW, G_VL);
+    kktFinish<P>(c, true, g, it.b, it.bts);
     if (v.vst)
     {
         double t[L::NS];
@@ -1048,9 +1073,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     double p_dl = 0.;
     if (v.vsg)
     {
-        resSegChunk<P, 0, L::SC1>(sg, dy, g_z3, p);
-        resSegChunk<P, L::SC1, L::SC2>(sg, dy, g_z3, p);
-        resSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, dy, g_z3, p);
+        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, dy, g_z3, p); });
     }
     if (v.vst)
     {
@@ -1277,7 +1300,7 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
 // segment rows [I0, I0+N): LP blocks of nu / nu_b, fused with the condensation (kktPrep) of those rows
 template <class P, int I0, int N>
-__device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sigmu, double dz3)
+__device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double om, double sigmu, double dz3)
 {
     using L = Lay<P>;
     double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N], qv[N], einv[N];
@@ -1291,7 +1314,7 @@ __device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sig
     ldf<N>(sg, G_RXNUB * L::NL + I0, rxnub);
     ldf<N>(sg, G_RY * L::NL + I0, ry);
     ldf<N>(sg, G_QV * L::NL + I0, qv);
-    ldf<N>(sg, G_EINV * L::NL + I0, einv);
+    ldf<N>(xs, L::X_EINV + I0, einv);
     double c1[N], c2[N];
     if (pass)
     {
@@ -1333,7 +1356,7 @@ __device__ inline void rhsSegChunk(const SV &sg, int pass, double om, double sig
     stf<N>(sg, G_DINV * L::NL + I0, dinv);
     stf<N>(sg, G_BNB * L::NL + I0, bnb);
     stf<N>(sg, G_BTN * L::NL + I0, btn);
-    stf<N>(sg, G_RHO * L::NL + I0, rho);
+    stf<N>(xs, L::X_RHO + I0, rho);
 }
 template <class P>
 PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
@@ -1439,27 +1462,25 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
         }
         stf<NV>(st, L::F_BXW, rxw);
         st[L::F_BXD] = bxd;
-        stf<NV>(st, L::F_BETA, beta);
+        stf<NV>(v.xs, L::X_BETA, beta);
     }
     if (v.vsg)
     {
-        rhsSegChunk<P, 0, L::SC1>(sg, pass, om, sigmu, g_dz3);
-        rhsSegChunk<P, L::SC1, L::SC2>(sg, pass, om, sigmu, g_dz3);
-        rhsSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, pass, om, sigmu, g_dz3);
+        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, pass, om, sigmu, g_dz3); });
     }
     WAVE_SYNC();
 }
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
 template <class P, int I0, int N>
-__device__ inline void dirSegChunk(const SV &sg, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
+__device__ inline void dirSegChunk(const SV &sg, const SV &xs, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
 {
     using L = Lay<P>;
     double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
     double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
-    ldf<N>(sg, G_VL * L::NL + I0, vl);
-    ldf<N>(sg, G_BCL * L::NL + I0, bcl);
-    ldf<N>(sg, G_EINV * L::NL + I0, einv);
+    ldf<N>(xs, L::X_VL + I0, vl);
+    ldf<N>(xs, L::X_BCL + I0, bcl);
+    ldf<N>(xs, L::X_EINV + I0, einv);
     ldf<N>(sg, G_BTN * L::NL + I0, btn);
     ldf<N>(sg, G_BNB * L::NL + I0, bnb);
     ldf<N>(sg, G_DINV * L::NL + I0, dinv);
@@ -1525,8 +1546,8 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
         {
             double S[L::NL], vl[L::NL], bcl[L::NL];
             ldf<L::NL>(dy, L::DY_S, S);
-            ldf<L::NL>(sg, G_VL * L::NL, vl);
-            ldf<L::NL>(sg, G_BCL * L::NL, bcl);
+            ldf<L::NL>(v.xs, L::X_VL, vl);
+            ldf<L::NL>(v.xs, L::X_BCL, bcl);
 #pragma unroll
             for (int i = 0; i < L::NL; i++)
             {
@@ -1557,8 +1578,8 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
         double Ld[L::NS];
         {
             double dw[NV], bcw[NV], hdw[NV], uh[3];
-            ldf<NV>(st, L::F_VW, dw);
-            ldf<NV>(st, L::F_BCW, bcw);
+            ldf<NV>(v.xs, L::X_VW, dw);
+            ldf<NV>(v.xs, L::X_BCW, bcw);
             ldf<NV>(st, L::F_HDW, hdw);
             ldf<3>(st, L::F_UHAT, uh);
             const double bxd = st[L::F_BXD], hdd = st[L::F_HDD];
@@ -1610,9 +1631,8 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
     double sumdnb = 0.;
     if (v.vsg)
     {
-        dirSegChunk<P, 0, L::SC1>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
-        dirSegChunk<P, L::SC1, L::SC2>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
-        dirSegChunk<P, L::SC1 + L::SC2, L::SC3>(sg, om, g.dsig, ainv, sumdnb, pass != 0);
+        forSegChunks<P, IPM_DIR_CHUNK>(
+            [&](auto i0, auto n) { dirSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, om, g.dsig, ainv, sumdnb, pass != 0); });
     }
     sumdnb = wave_sum(sumdnb);
     const Glob gt = reloadPriv(gp);
@@ -1769,6 +1789,18 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     PUT_END();
 }
 
+#ifdef SCPP_HIP_EMU
+#define KERNEL_TAIL_ARGS(t, a) const KernelArgs &t = a
+#else
+typedef const __attribute__((address_space(4))) KernelArgs ConstKernelArgs;
+__device__ inline ConstKernelArgs *kernelArgsLate()
+{
+    ConstKernelArgs *p = (ConstKernelArgs *)__builtin_amdgcn_kernarg_segment_ptr(); // explicit arguments start at offset 0
+    asm volatile("" : "+s"(p));                                                      // opaque: the loads stay where they are used
+    return p;
+}
+#define KERNEL_TAIL_ARGS(t, a) ConstKernelArgs &t = *kernelArgsLate()
+#endif
 #ifndef IPM_WAVES_PER_SIMD
 #define IPM_WAVES_PER_SIMD 2
 #endif
@@ -1799,9 +1831,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     c.K = K;
     c.lane = lane;
     double *ws = a.ws + size_t(inst) * workspaceDoubles<P>(K);
-    c.st = ws;
+    c.sx = ws;
+    c.st = ws + size_t(K) * L::XREC;
     c.pitch = recPitch(K);
-    c.sg = ws + size_t(c.pitch) * L::STREC;
+    c.sg = c.st + size_t(c.pitch) * L::STREC;
     c.dy = c.sg + size_t(c.pitch) * (G_NFIELDS * L::NL);
     c.fac = c.dy + size_t(c.pitch) * L::DYNREC;
     c.sv = c.fac + size_t(K) * L::FACREC;
@@ -1862,14 +1895,14 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
         // =============== initialisation (ECOS init, W = I) ===============
         phInitPrimalRhs<P>(cs, gp, itp);
         {
-            const RhsSpec sp = specBorderPlus(L::F_BETA, G_RHO, L::F_VW, G_VL);
+            const RhsSpec sp = specBorderPlus();
             factorSweepFused<P>(cs, sh, sp);
             bwdSweep<P>(cs, sp);
         }
         phInitPrimalFinish<P>(cs, gp, itp);
         phInitDualRhs<P>(cs, gp, itp);
         {
-            const RhsSpec sp = specSingle(L::F_BETA, G_RHO, L::F_VW, G_VL);
+            const RhsSpec sp = specSingle();
             fwdSweep<P>(cs, sp);
             bwdSweep<P>(cs, sp);
         }
@@ -1938,7 +1971,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             {
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
                 // column and of the affine right-hand side
-                const RhsSpec sp = specBorderPlus(L::F_BETA, G_RHO, L::F_VW, G_VL);
+                const RhsSpec sp = specBorderPlus();
                 factorSweepFused<P>(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
@@ -1948,7 +1981,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             }
             else
             {
-                const RhsSpec sp = specSingle(L::F_BETA, G_RHO, L::F_VW, G_VL);
+                const RhsSpec sp = specSingle();
                 fwdSweep<P>(cs, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
@@ -1982,6 +2015,9 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     }
     iter = iter_total;
     // =============== outputs: readSolution + SC bookkeeping ===============
+    // The output pointers are re-read from the kernel-argument segment here instead of being carried (as spilled SGPRs) across
+    // the whole solve: nothing below the main loop keeps a kernel argument alive above it.
+    KERNEL_TAIL_ARGS(t, a);
     const bool vst = k < K;
     const SV st = makeSV(c.st, L::STREC, unsigned(vst ? k : 0), c.pitch);
     // W / delta to report: the current iterate, or the restored best one (use_backup)
@@ -1992,17 +2028,17 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     sum_delta = wave_sum(sum_delta);
     const double n1 = use_backup ? it.bk_n1 : g.n1, sig = use_backup ? it.bk_sig : g.sig, dsg = use_backup ? it.bk_dsg : g.dsg;
 #ifdef IPM_PROFILE
-    if (a.dbg && lane == 0)
+    if (t.dbg && lane == 0)
     {
-        double *d = a.dbg + size_t(inst) * 32;
+        double *d = t.dbg + size_t(inst) * 32;
         prof[11] = double(clock64() - t_kernel0);
         for (int i = 0; i < 12; i++)
             d[8 + i] = prof[i];
     }
 #endif
-    if (a.dbg && lane == 0)
+    if (t.dbg && lane == 0)
     {
-        double *d = a.dbg + size_t(inst) * 32;
+        double *d = t.dbg + size_t(inst) * 32;
         d[0] = it.pcost;
         d[1] = it.gap;
         d[2] = it.pres;
@@ -2016,7 +2052,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
     {
         if (vst)
         {
-            double *Xo = a.X + (size_t(inst) * K + k) * NX, *Uo = a.U + (size_t(inst) * K + k) * NU;
+            double *Xo = t.X + (size_t(inst) * K + k) * NX, *Uo = t.U + (size_t(inst) * K + k) * NU;
             // states / inputs the table pins for the whole horizon are written as their constant (0)
 #pragma unroll
             for (int i = 0; i < NX; i++)
@@ -2026,7 +2062,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
                 Uo[i] = L::UINV.v[i] >= 0 ? double(st[fW + (L::UINV.v[i] >= 0 ? L::UINV.v[i] : 0)]) : 0.;
         }
         if (lane == 0 && c.ip[IP_SCVX] == 0.)
-            a.sigma[inst] = sig; // SCvx: fixed final time (the sigma block is a decoupled dummy)
+            t.sigma[inst] = sig; // SCvx: fixed final time (the sigma block is a decoupled dummy)
     }
     if (lane == 0)
     {
@@ -2044,36 +2080,36 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArg
             gs[7 + i] = g.sc3[i];
             gs[10 + i] = g.zc3[i];
         }
-        if (a.warm)
-            a.warm[inst] = (status == 0 && !use_backup) ? 1 : 0;
-        a.ipm_iters[inst] += iter;
-        a.norm1_nu[inst] = n1;
-        a.sum_delta[inst] = sum_delta;
-        a.delta_sigma[inst] = dsg;
-        if (a.do_sc_update)
+        if (t.warm)
+            t.warm[inst] = (status == 0 && !use_backup) ? 1 : 0;
+        t.ipm_iters[inst] += iter;
+        t.norm1_nu[inst] = n1;
+        t.sum_delta[inst] = sum_delta;
+        t.delta_sigma[inst] = dsg;
+        if (t.do_sc_update)
         {
-            a.sc_iters[inst] += 1;
+            t.sc_iters[inst] += 1;
             if (status != 0)
             {
-                a.status[inst] = status; // solver failure: reference would std::terminate (SCAlgorithm.cpp:94-98)
-                a.active[inst] = 0;
+                t.status[inst] = status; // solver failure: reference would std::terminate (SCAlgorithm.cpp:94-98)
+                t.active[inst] = 0;
             }
             else
             {
-                if (n1 < a.nu_tol)
-                    a.wtrx[inst] = wtrx * 2.;
-                const int conv = (sum_delta < a.delta_tol && n1 < a.nu_tol) ? 1 : 0;
+                if (n1 < t.nu_tol)
+                    t.wtrx[inst] = wtrx * 2.;
+                const int conv = (sum_delta < t.delta_tol && n1 < t.nu_tol) ? 1 : 0;
                 if (conv)
                 {
-                    a.converged[inst] = 1;
-                    a.active[inst] = 0;
+                    t.converged[inst] = 1;
+                    t.active[inst] = 0;
                 }
-                else if (a.sc_iters[inst] >= a.max_sc_iterations)
-                    a.active[inst] = 0;
+                else if (t.sc_iters[inst] >= t.max_sc_iterations)
+                    t.active[inst] = 0;
             }
         }
         else
-            a.status[inst] = status;
+            t.status[inst] = status;
     }
 }
 

@@ -1,10 +1,10 @@
 // Stage sweeps of the block-tridiagonal KKT system on the tile engine (see tile_engine.h for the algebra).
 //   factorSweepFused : factorisation + forward substitution of up to 2 right-hand-side columns
 //   fwdSweep         : forward substitution only (re-uses the stored tiles)
-//   bwdSweep         : backward substitution, writes dw / dlam columns to the field-major records
-// Right-hand sides and solutions live in the field-major stage / segment records.  Column 0 of a 2-column
-// sweep is the sigma BORDER column (beta = 0, rho = -S_k, result to F_BCW / G_BCL); the other column reads
-// beta from stage field fBeta (16 entries) and rho from segment field gRho (14 entries).
+//   bwdSweep         : backward substitution, writes dw / dlam columns to the exchange records
+// Right-hand sides and solutions live in the stage-major exchange records (Lay<P>::X_*).  Column 0 of a 2-column
+// sweep is the sigma BORDER column (beta = 0, rho = -S_k, result to X_BCW / X_BCL); the other column reads
+// beta from X_BETA (16 entries) and rho from X_RHO (NL entries) and leaves its solution in X_VW / X_VL.
 // All sweeps are software-pipelined: the global loads of stage k+1 (k-1) are issued before the dependent
 // MFMA / elimination chain of stage k so that HBM/L2 latency overlaps the chain.
 #pragma once
@@ -38,6 +38,7 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
     c.dy = uniformPtr(cin->dy);
     c.fac = uniformPtr(cin->fac);
     c.sv = uniformPtr(cin->sv);
+    c.sx = uniformPtr(cin->sx);
     c.gsave = uniformPtr(cin->gsave);
     c.A = uniformPtr(cin->A);
     c.B = uniformPtr(cin->B);
@@ -49,21 +50,13 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
 }
 struct RhsSpec
 {
-    int n;      // 1: single column ; 2: [border | column]
-    int fBeta;  // stage field of beta
-    int gRho;   // segment field of rho
-    int fOut;   // stage field receiving dw
-    int gOut;   // segment field receiving dlam
+    int n; // 1: single column (X_BETA / X_RHO -> X_VW / X_VL) ; 2: [border | column] (border: -S_k -> X_BCW / X_BCL)
 };
 
 __device__ inline RhsSpec uniformSpec(const RhsSpec &s)
 {
     RhsSpec o;
     o.n = uniformInt(s.n);
-    o.fBeta = uniformInt(s.fBeta);
-    o.gRho = uniformInt(s.gRho);
-    o.fOut = uniformInt(s.fOut);
-    o.gOut = uniformInt(s.gOut);
     return o;
 }
 
@@ -84,7 +77,7 @@ __device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane
     {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            t.v[r] = c.st[size_t(sp.fBeta + g + 4 * r) * c.pitch + k];
+            t.v[r] = c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_BETA + g + 4 * r];
     }
     return t;
 }
@@ -102,7 +95,7 @@ __device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane
         {
             const int row = g + 4 * r;
             if (row < NL)
-                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sg[size_t(sp.gRho * NL + row) * c.pitch + k];
+                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_RHO + row];
         }
     }
     return t;
@@ -187,17 +180,17 @@ __device__ inline HRaw loadHRaw(const Ctx &c, const HsLane &hl, int k, int lane)
 {
     using L = Lay<P>;
     const int g = lane >> 4, i = lane & 15;
-    const SV st = makeSV(c.st, L::STREC, unsigned(k), c.pitch);
+    const double *xk = c.sx + size_t(k) * L::XREC;
     HRaw h;
-    h.e2 = st[L::F_HC];
-    h.cc = st[L::F_HC + 1];
-    h.wcol = st.dyn(L::F_WB + 1 + i);
+    h.e2 = xk[L::X_HC];
+    h.cc = xk[L::X_HC + 1];
+    h.wcol = xk[L::X_WBT + i];
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
         const int row = g + 4 * r;
-        h.wrow[r] = st.dyn(L::F_WB + 1 + row);
-        h.hs[r] = st.dyn(L::F_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0));
+        h.wrow[r] = xk[L::X_WBT + row];
+        h.hs[r] = xk[L::X_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0)];
     }
     return h;
 }
@@ -358,7 +351,7 @@ __device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int
         f.n = loadNRaw<P>(c, k, lane);
         f.rl = loadRhsL<P>(c, sp, k, lane);
         f.rwn = loadRhsW<P>(c, sp, k + 1, lane);
-        f.einv = c.sg[size_t(G_EINV * NL + (i < NL ? i : 0)) * c.pitch + k];
+        f.einv = c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_EINV + (i < NL ? i : 0)];
     }
     else
     {
@@ -490,10 +483,10 @@ __device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lan
     const int kind = colKind(sp, i);
     if (kind)
     {
-        const int f = kind == 1 ? int(Lay<P>::F_BCW) : sp.fOut;
+        const int f = kind == 1 ? int(Lay<P>::X_BCW) : int(Lay<P>::X_VW);
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            c.st[size_t(f + g + 4 * r) * c.pitch + k] = x.v[r];
+            c.sx[size_t(k) * Lay<P>::XREC + f + g + 4 * r] = x.v[r];
     }
 }
 template <class P>
@@ -504,13 +497,13 @@ __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lan
     const int kind = colKind(sp, i);
     if (kind)
     {
-        const int f = kind == 1 ? int(G_BCL) : sp.gOut;
+        const int f = kind == 1 ? int(Lay<P>::X_BCL) : int(Lay<P>::X_VL);
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
             const int row = g + 4 * r;
             if (row < NL)
-                c.sg[size_t(f * NL + row) * c.pitch + k] = l.v[r];
+                c.sx[size_t(k) * Lay<P>::XREC + f + row] = l.v[r];
         }
     }
 }
