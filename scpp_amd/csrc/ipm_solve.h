@@ -589,7 +589,7 @@ __device__ inline void zeroT(const SV &st)
 #ifdef SCPP_HIP_EMU
 #define PHASE_FN inline
 #else
-#define PHASE_FN static __device__ __attribute__((noinline))
+#define PHASE_FN static __device__ __attribute__((noinline, disable_tail_calls))
 #endif
 
 // wave-uniform state of one solve
@@ -1812,7 +1812,7 @@ __device__ inline ConstKernelArgs *kernelArgsLate()
 #define PROF_ADD(slot, t0, t1)
 #endif
 template <class P>
-__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) ipm_kernel(KernelArgs a)
+__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disable_tail_calls)) ipm_kernel(KernelArgs a)
 {
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;

@@ -16,7 +16,7 @@ namespace ipm
 {
 
 #ifndef SWEEPS_INLINE
-#define SWEEP_FN static __device__ __attribute__((noinline))
+#define SWEEP_FN static __device__ __attribute__((noinline, disable_tail_calls))
 #else
 #define SWEEP_FN __device__ inline __attribute__((always_inline))
 #endif
@@ -48,6 +48,30 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
     c.ip = uniformPtr(cin->ip);
     return c;
 }
+// the exchange records through a buffer resource: stage offset in an SGPR, the lane's entry in the VGPR / immediate offset,
+// so that a sweep carries no 64-bit per-lane addresses for them
+struct XS
+{
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ double ld(int stage_bytes, int entry) const
+    {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, entry * 8, stage_bytes, 0));
+    }
+    __device__ void st(int stage_bytes, int entry, double x) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), rsrc, entry * 8, stage_bytes, 0);
+    }
+};
+template <class P>
+__device__ inline XS makeXS(const Ctx &c)
+{
+    return XS{__builtin_amdgcn_make_buffer_rsrc(c.sx, 0, c.K * Lay<P>::XREC * 8, 0x00020000)};
+}
+template <class P>
+__device__ inline int xsStage(int k)
+{
+    return k * (Lay<P>::XREC * 8);
+}
 struct RhsSpec
 {
     int n; // 1: single column (X_BETA / X_RHO -> X_VW / X_VL) ; 2: [border | column] (border: -S_k -> X_BCW / X_BCL)
@@ -69,7 +93,7 @@ __device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 r
 }
 
 template <class P>
-__device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane)
+__device__ inline Tile loadRhsW(const XS &xs, const RhsSpec &sp, int k, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
     Tile t = tileZero();
@@ -77,12 +101,12 @@ __device__ inline Tile loadRhsW(const Ctx &c, const RhsSpec &sp, int k, int lane
     {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            t.v[r] = c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_BETA + g + 4 * r];
+            t.v[r] = xs.ld(xsStage<P>(k), Lay<P>::X_BETA + g + 4 * r);
     }
     return t;
 }
 template <class P>
-__device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane)
+__device__ inline Tile loadRhsL(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
 {
     constexpr int NL = Lay<P>::NL, NX = P::NX;
     const int g = lane >> 4, i = lane & 15;
@@ -95,7 +119,7 @@ __device__ inline Tile loadRhsL(const Ctx &c, const RhsSpec &sp, int k, int lane
         {
             const int row = g + 4 * r;
             if (row < NL)
-                t.v[r] = kind == 1 ? c.S[k * NX + row] : c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_RHO + row];
+                t.v[r] = kind == 1 ? c.S[k * NX + row] : xs.ld(xsStage<P>(k), Lay<P>::X_RHO + row);
         }
     }
     return t;
@@ -176,21 +200,21 @@ __device__ inline HsLane hsLane(int lane)
     return h;
 }
 template <class P>
-__device__ inline HRaw loadHRaw(const Ctx &c, const HsLane &hl, int k, int lane)
+__device__ inline HRaw loadHRaw(const XS &xs, const HsLane &hl, int k, int lane)
 {
     using L = Lay<P>;
     const int g = lane >> 4, i = lane & 15;
-    const double *xk = c.sx + size_t(k) * L::XREC;
+    const int sk = xsStage<P>(k);
     HRaw h;
-    h.e2 = xk[L::X_HC];
-    h.cc = xk[L::X_HC + 1];
-    h.wcol = xk[L::X_WBT + i];
+    h.e2 = xs.ld(sk, L::X_HC);
+    h.cc = xs.ld(sk, L::X_HC + 1);
+    h.wcol = xs.ld(sk, L::X_WBT + i);
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
         const int row = g + 4 * r;
-        h.wrow[r] = xk[L::X_WBT + row];
-        h.hs[r] = xk[L::X_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0)];
+        h.wrow[r] = xs.ld(sk, L::X_WBT + row);
+        h.hs[r] = xs.ld(sk, L::X_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0));
     }
     return h;
 }
@@ -340,7 +364,7 @@ struct FactorRest
     double einv;
 };
 template <class P>
-__device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int k, int lane)
+__device__ inline FactorRest loadFactorRest(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
 {
     constexpr int NL = Lay<P>::NL;
     const int i = lane & 15;
@@ -349,9 +373,9 @@ __device__ inline FactorRest loadFactorRest(const Ctx &c, const RhsSpec &sp, int
     {
         f.mt = loadMtRaw<P>(c, k, lane);
         f.n = loadNRaw<P>(c, k, lane);
-        f.rl = loadRhsL<P>(c, sp, k, lane);
-        f.rwn = loadRhsW<P>(c, sp, k + 1, lane);
-        f.einv = c.sx[size_t(k) * Lay<P>::XREC + Lay<P>::X_EINV + (i < NL ? i : 0)];
+        f.rl = loadRhsL<P>(c, xs, sp, k, lane);
+        f.rwn = loadRhsW<P>(xs, sp, k + 1, lane);
+        f.einv = xs.ld(xsStage<P>(k), Lay<P>::X_EINV + (i < NL ? i : 0));
     }
     else
     {
@@ -374,15 +398,16 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
     const double dual_reg = scvx ? 1e-9 : 0.;
-    Tile Z = tileZero(), G = loadRhsW<P>(c, sp, 0, lane);
+    const XS xs = makeXS<P>(c);
+    Tile Z = tileZero(), G = loadRhsW<P>(xs, sp, 0, lane);
     const HsLane hl = hsLane<P>(lane);
-    HRaw hcur = loadHRaw<P>(c, hl, 0, lane);
+    HRaw hcur = loadHRaw<P>(xs, hl, 0, lane);
     for (int k = 0; k < K; k++)
     {
-        const FactorRest cur = loadFactorRest<P>(c, sp, k, lane); // arrives during the first elimination below
+        const FactorRest cur = loadFactorRest<P>(c, xs, sp, k, lane); // arrives during the first elimination below
         HRaw hnxt = hcur;
         if (k + 1 < K)
-            hnxt = loadHRaw<P>(c, hl, k + 1, lane); // prefetch
+            hnxt = loadHRaw<P>(xs, hl, k + 1, lane); // prefetch
         double *fk = c.fac + size_t(k) * FACREC;
         double *svk = c.sv + size_t(k) * SVREC;
         Tile Phi = buildHTile<P>(hcur, hl, k, K, lane, scvx);
@@ -424,7 +449,7 @@ struct FwdIn
     Tile lit, yt, tit, ti, n, rl, rwn;
 };
 template <class P>
-__device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+__device__ inline FwdIn loadFwdIn(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
 {
     using L = Lay<P>;
     constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
@@ -437,8 +462,8 @@ __device__ inline FwdIn loadFwdIn(const Ctx &c, const RhsSpec &sp, int k, int la
         f.tit = loadTriT<NL>(fk + FAC_TI, lane);
         f.ti = loadTri<NL>(fk + FAC_TI, lane);
         f.n = loadNRaw<P>(c, k, lane);
-        f.rl = loadRhsL<P>(c, sp, k, lane);
-        f.rwn = loadRhsW<P>(c, sp, k + 1, lane);
+        f.rl = loadRhsL<P>(c, xs, sp, k, lane);
+        f.rwn = loadRhsW<P>(xs, sp, k + 1, lane);
     }
     else
         f.yt = f.tit = f.ti = f.n = f.rl = f.rwn = tileZero();
@@ -451,16 +476,17 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
-    Tile G = loadRhsW<P>(c, sp, 0, lane);
+    const XS xs = makeXS<P>(c);
+    Tile G = loadRhsW<P>(xs, sp, 0, lane);
     // two stages of loads in flight: the per-stage MFMA chain (~1k cycles) is much shorter than the loaded-HBM
     // latency, so a distance-1 prefetch still stalls every stage
-    FwdIn cur = loadFwdIn<P>(c, sp, 0, lane);
-    FwdIn nx1 = K > 1 ? loadFwdIn<P>(c, sp, 1, lane) : cur;
+    FwdIn cur = loadFwdIn<P>(c, xs, sp, 0, lane);
+    FwdIn nx1 = K > 1 ? loadFwdIn<P>(c, xs, sp, 1, lane) : cur;
     for (int k = 0; k < K; k++)
     {
         FwdIn nxt = nx1;
         if (k + 2 < K)
-            nx1 = loadFwdIn<P>(c, sp, k + 2, lane);
+            nx1 = loadFwdIn<P>(c, xs, sp, k + 2, lane);
         double *svk = c.sv + size_t(k) * SVREC;
         const Tile a = mm(cur.lit, G);
         saveCols(svk, sp.n, lane, a);
@@ -477,7 +503,7 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 }
 
 template <class P>
-__device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &x)
+__device__ inline void storeSolW(const XS &xs, const RhsSpec &sp, int k, int lane, const Tile &x)
 {
     const int g = lane >> 4, i = lane & 15;
     const int kind = colKind(sp, i);
@@ -486,11 +512,11 @@ __device__ inline void storeSolW(const Ctx &c, const RhsSpec &sp, int k, int lan
         const int f = kind == 1 ? int(Lay<P>::X_BCW) : int(Lay<P>::X_VW);
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            c.sx[size_t(k) * Lay<P>::XREC + f + g + 4 * r] = x.v[r];
+            xs.st(xsStage<P>(k), f + g + 4 * r, x.v[r]);
     }
 }
 template <class P>
-__device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lane, const Tile &l)
+__device__ inline void storeSolL(const XS &xs, const RhsSpec &sp, int k, int lane, const Tile &l)
 {
     constexpr int NL = Lay<P>::NL;
     const int g = lane >> 4, i = lane & 15;
@@ -503,7 +529,7 @@ __device__ inline void storeSolL(const Ctx &c, const RhsSpec &sp, int k, int lan
         {
             const int row = g + 4 * r;
             if (row < NL)
-                c.sx[size_t(k) * Lay<P>::XREC + f + row] = l.v[r];
+                xs.st(xsStage<P>(k), f + row, l.v[r]);
         }
     }
 }
@@ -541,6 +567,7 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
+    const XS xs = makeXS<P>(c);
     BwdIn cur = loadBwdIn<P>(c, sp, K - 1, lane);
     BwdIn nx1 = K > 1 ? loadBwdIn<P>(c, sp, K - 2, lane) : cur;
     Tile x = tileZero();
@@ -560,9 +587,9 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
             const Tile lam = mm(cur.ti, t);                 // Ti' t = T^-T t
             const Tile s = tileSub(cur.as, mm(cur.y, lam)); // a - Y' lam
             x = mm(cur.li, s);
-            storeSolL<P>(c, sp, k, lane, lam);
+            storeSolL<P>(xs, sp, k, lane, lam);
         }
-        storeSolW<P>(c, sp, k, lane, x);
+        storeSolW<P>(xs, sp, k, lane, x);
         cur = nxt;
     }
     WAVE_SYNC();
