@@ -78,7 +78,8 @@ struct Lay : Derived<P>
     static constexpr int X_BCL = X_RHO + 16;      // [NL] border column (multiplier part)
     static constexpr int X_VL = X_BCL + 16;       // [NL] block-solve output (multiplier part)
     static constexpr int X_EINV = X_VL + 16;      // [NL] E^-1 of the segment
-    static constexpr int XREC = X_EINV + 16;      // 160 doubles = ten 128-byte lines
+    static constexpr int X_S = X_EINV + 16;       // [NL] S_k of the segment (copy of dd: right-hand side of the border column)
+    static constexpr int XREC = X_S + 16;         // 176 doubles = eleven 128-byte lines
     static_assert(HS_N + 2 <= 32 && NL <= 16 && XREC % 16 == 0, "exchange record layout");
     // ---- segment record: G_NFIELDS fields of NL doubles (enum SegField) ----
     // ---- per-stage factor record, PACKED (the kernel is HBM-throughput bound): Li lower triangle (136), Yt 16 x NL,

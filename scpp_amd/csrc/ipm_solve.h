@@ -744,6 +744,8 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
         if (!warm)
             for (int i = 0; i < (G_NFIELDS * L::NL); i++)
                 sg[i] = 0.;
+        for (int i = 0; i < L::NL; i++)
+            v.xs[L::X_S + i] = c.S[size_t(k) * NX + i];
         // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
         const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
         for (int e = 0; e < NX * NX; e++)
@@ -1826,6 +1828,11 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
     if (a.active && a.active[inst] == 0)
         return;
     __shared__ TileShared sh;
+#ifdef IPM_PROFILE
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 4; i++)
+            sh.prof[i] = 0.;
+#endif
     const int K = a.K, lane = threadIdx.x, k = lane;
     Ctx c;
     c.K = K;
@@ -2034,6 +2041,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         prof[11] = double(clock64() - t_kernel0);
         for (int i = 0; i < 12; i++)
             d[8 + i] = prof[i];
+        for (int i = 0; i < 4; i++)
+            d[20 + i] = sh.prof[i];
     }
 #endif
     if (t.dbg && lane == 0)

@@ -7,6 +7,11 @@
 // beta from X_BETA (16 entries) and rho from X_RHO (NL entries) and leaves its solution in X_VW / X_VL.
 // All sweeps are software-pipelined: the global loads of stage k+1 (k-1) are issued before the dependent
 // MFMA / elimination chain of stage k so that HBM/L2 latency overlaps the chain.
+// Every global access of a sweep is an UNCONDITIONAL buffer instruction: a lane whose tile entry lies outside the stored
+// pattern uses a byte offset beyond the record block, for which the hardware returns 0 (loads) or drops the access (stores).
+// With predicated accesses (divergent `if` around a load or store) the compiler cannot count the memory operations between a
+// load and its use, and every first use became s_waitcnt vmcnt(0): the prefetch distance of the sweeps existed in the source
+// only, and each stage waited for the loads it had just issued (measured in the ISA).
 #pragma once
 #include "tile_engine.h"
 
@@ -15,6 +20,13 @@ namespace scpp
 namespace ipm
 {
 
+// stages of loads in flight ahead of the dependent chain in the forward / backward sweeps (2 at two waves per SIMD)
+#ifndef SWEEP_PREFETCH
+#define SWEEP_PREFETCH 2
+#endif
+#ifndef FACTOR_PREFETCH_REST
+#define FACTOR_PREFETCH_REST 0
+#endif
 #ifndef SWEEPS_INLINE
 #define SWEEP_FN static __device__ __attribute__((noinline, disable_tail_calls))
 #else
@@ -48,30 +60,128 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
     c.ip = uniformPtr(cin->ip);
     return c;
 }
-// the exchange records through a buffer resource: stage offset in an SGPR, the lane's entry in the VGPR / immediate offset,
-// so that a sweep carries no 64-bit per-lane addresses for them
-struct XS
+// ---- branch-free buffer access ----
+constexpr int VO_OOB = 0x40000000; // byte offset beyond every record block of an instance
+struct Buf
 {
-    __amdgpu_buffer_rsrc_t rsrc;
-    __device__ double ld(int stage_bytes, int entry) const
-    {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, entry * 8, stage_bytes, 0));
-    }
-    __device__ void st(int stage_bytes, int entry, double x) const
-    {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), rsrc, entry * 8, stage_bytes, 0);
-    }
+    __amdgpu_buffer_rsrc_t r;
+    __device__ double ld(int vo, int so) const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
+    __device__ void st(int vo, int so, double x) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, vo, so, 0); }
 };
-template <class P>
-__device__ inline XS makeXS(const Ctx &c)
+__device__ inline Buf makeBuf(const double *p, int ndoubles)
 {
-    return XS{__builtin_amdgcn_make_buffer_rsrc(c.sx, 0, c.K * Lay<P>::XREC * 8, 0x00020000)};
+    return Buf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, ndoubles * 8, 0x00020000)};
 }
-template <class P>
-__device__ inline int xsStage(int k)
+// byte offsets of a lane's four tile entries (register r holds row / contraction index g + 4r), VO_OOB where the entry is
+// outside the stored pattern; they depend on the lane only and are computed once per sweep
+struct Off4
 {
-    return k * (Lay<P>::XREC * 8);
+    int v[4];
+};
+__device__ inline Tile ldTile(const Buf &b, const Off4 &o, int so)
+{
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        t.v[r] = b.ld(o.v[r], so);
+    return t;
 }
+__device__ inline void stTile(const Buf &b, const Off4 &o, int so, const Tile &t)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        b.st(o.v[r], so, t.v[r]);
+}
+template <int n>
+__device__ inline Off4 offTri(int lane, int base) // tile[row][col] = L[row][col]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        o.v[r] = (row < n && i <= row) ? (base + triIdx(row, i)) * 8 : VO_OOB;
+    }
+    return o;
+}
+template <int n>
+__device__ inline Off4 offTriT(int lane, int base) // tile[a][b] = L[b][a]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        o.v[r] = (i < n && a <= i) ? (base + triIdx(i, a)) * 8 : VO_OOB;
+    }
+    return o;
+}
+// the identity outside the leading n x n block (loads returned 0 there)
+template <int n>
+__device__ inline Tile finishTri(const Tile &raw, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile t = raw;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (4 * r + 3 >= n) // this register holds a row >= n
+            t.v[r] = (g + 4 * r >= n && g + 4 * r == i) ? 1. : raw.v[r];
+    return t;
+}
+template <int NL>
+__device__ inline Off4 offYt(int lane, int base) // tile[a][b] = Yt[a][b], row-major with pitch NL
+{
+    const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.v[r] = i < NL ? (base + (g + 4 * r) * NL + i) * 8 : VO_OOB;
+    return o;
+}
+template <int NL>
+__device__ inline Off4 offYtT(int lane, int base) // tile[a][b] = Yt[b][a]
+{
+    const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        o.v[r] = a < NL ? (base + i * NL + a) * 8 : VO_OOB;
+    }
+    return o;
+}
+// saved right-hand-side columns (a, c of the forward pass): column i < n at p[i * 16 + row]
+__device__ inline Off4 offCols(int lane, int n, int base)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.v[r] = i < n ? (base + i * 16 + g + 4 * r) * 8 : VO_OOB;
+    return o;
+}
+
+// what a sweep reads and writes: the instance's record blocks as buffer resources + the byte offset of a stage in each
+template <class P>
+struct SweepIO
+{
+    using L = Lay<P>;
+    Buf fac, sv, sx, A, B, C;
+    __device__ explicit SweepIO(const Ctx &c)
+        : fac(makeBuf(c.fac, c.K * L::FACREC)), sv(makeBuf(c.sv, c.K * SVREC)), sx(makeBuf(c.sx, c.K * L::XREC)),
+          A(makeBuf(c.A, (c.K - 1) * P::NX * P::NX)), B(makeBuf(c.B, (c.K - 1) * P::NX * P::NU)), C(makeBuf(c.C, (c.K - 1) * P::NX * P::NU))
+    {
+    }
+    static __device__ int sFac(int k) { return k * (L::FACREC * 8); }
+    static __device__ int sSv(int k) { return k * (SVREC * 8); }
+    static __device__ int sX(int k) { return k * (L::XREC * 8); }
+    static __device__ int sA(int k) { return k * (P::NX * P::NX * 8); }
+    static __device__ int sBC(int k) { return k * (P::NX * P::NU * 8); }
+};
+
 struct RhsSpec
 {
     int n; // 1: single column (X_BETA / X_RHO -> X_VW / X_VL) ; 2: [border | column] (border: -S_k -> X_BCW / X_BCL)
@@ -84,7 +194,6 @@ __device__ inline RhsSpec uniformSpec(const RhsSpec &s)
     return o;
 }
 
-// column index of the regular (non-border) column, -1 if this lane's column is unused
 __device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 regular
 {
     if (sp.n == 2)
@@ -92,39 +201,57 @@ __device__ inline int colKind(const RhsSpec &sp, int i) // 0 none, 1 border, 2 r
     return i == 0 ? 2 : 0;
 }
 
+// right-hand sides / solutions in the exchange record: the border column reads -S_k (X_S) and writes X_BCW / X_BCL
 template <class P>
-__device__ inline Tile loadRhsW(const XS &xs, const RhsSpec &sp, int k, int lane)
+__device__ inline Off4 offRhsW(const RhsSpec &sp, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
-    Tile t = tileZero();
-    if (colKind(sp, i) == 2)
-    {
+    Off4 o;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            t.v[r] = xs.ld(xsStage<P>(k), Lay<P>::X_BETA + g + 4 * r);
-    }
-    return t;
+    for (int r = 0; r < 4; r++)
+        o.v[r] = colKind(sp, i) == 2 ? (Lay<P>::X_BETA + g + 4 * r) * 8 : VO_OOB;
+    return o;
 }
 template <class P>
-__device__ inline Tile loadRhsL(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
+__device__ inline Off4 offRhsL(const RhsSpec &sp, int lane)
 {
-    constexpr int NL = Lay<P>::NL, NX = P::NX;
     const int g = lane >> 4, i = lane & 15;
-    Tile t = tileZero();
     const int kind = colKind(sp, i);
-    if (kind)
-    {
+    Off4 o;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            const int row = g + 4 * r;
-            if (row < NL)
-                t.v[r] = kind == 1 ? c.S[k * NX + row] : xs.ld(xsStage<P>(k), Lay<P>::X_RHO + row);
-        }
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        o.v[r] = (kind && row < Lay<P>::NL) ? ((kind == 1 ? Lay<P>::X_S : Lay<P>::X_RHO) + row) * 8 : VO_OOB;
     }
-    return t;
+    return o;
 }
-// border column stores -S: sign applied at use so that the load itself carries no arithmetic
+template <class P>
+__device__ inline Off4 offSolW(const RhsSpec &sp, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const int kind = colKind(sp, i);
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.v[r] = kind ? ((kind == 1 ? Lay<P>::X_BCW : Lay<P>::X_VW) + g + 4 * r) * 8 : VO_OOB;
+    return o;
+}
+template <class P>
+__device__ inline Off4 offSolL(const RhsSpec &sp, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    const int kind = colKind(sp, i);
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        o.v[r] = (kind && row < Lay<P>::NL) ? ((kind == 1 ? Lay<P>::X_BCL : Lay<P>::X_VL) + row) * 8 : VO_OOB;
+    }
+    return o;
+}
+// border column stores S: the sign is applied at use so that the load itself carries no arithmetic
 __device__ inline Tile rhsLSign(const RhsSpec &sp, int lane, const Tile &t)
 {
     const int i = lane & 15;
@@ -135,28 +262,6 @@ __device__ inline Tile rhsLSign(const RhsSpec &sp, int lane, const Tile &t)
         for (int r = 0; r < 4; r++)
             o.v[r] = -t.v[r];
         return o;
-    }
-    return t;
-}
-__device__ inline void saveCols(double *p, int n, int lane, const Tile &t)
-{
-    const int g = lane >> 4, i = lane & 15;
-    if (i < n)
-    {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            p[i * 16 + g + 4 * r] = t.v[r];
-    }
-}
-__device__ inline Tile loadCols(const double *p, int n, int lane)
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t = tileZero();
-    if (i < n)
-    {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            t.v[r] = p[i * 16 + g + 4 * r];
     }
     return t;
 }
@@ -188,6 +293,7 @@ struct HRaw
 struct HsLane
 {
     int idx[4];
+    Off4 off; // byte offsets in the exchange record (VO_OOB outside the pattern: the load returns 0)
 };
 template <class P>
 __device__ inline HsLane hsLane(int lane)
@@ -196,25 +302,27 @@ __device__ inline HsLane hsLane(int lane)
     HsLane h;
 #pragma unroll
     for (int r = 0; r < 4; r++)
+    {
         h.idx[r] = hsIndex<P>(g + 4 * r, i);
+        h.off.v[r] = h.idx[r] >= 0 ? (Lay<P>::X_HS + h.idx[r]) * 8 : VO_OOB;
+    }
     return h;
 }
 template <class P>
-__device__ inline HRaw loadHRaw(const XS &xs, const HsLane &hl, int k, int lane)
+__device__ inline HRaw loadHRaw(const SweepIO<P> &io, const HsLane &hl, int k, int lane)
 {
     using L = Lay<P>;
     const int g = lane >> 4, i = lane & 15;
-    const int sk = xsStage<P>(k);
+    const int sk = io.sX(k);
     HRaw h;
-    h.e2 = xs.ld(sk, L::X_HC);
-    h.cc = xs.ld(sk, L::X_HC + 1);
-    h.wcol = xs.ld(sk, L::X_WBT + i);
+    h.e2 = io.sx.ld(L::X_HC * 8, sk);
+    h.cc = io.sx.ld((L::X_HC + 1) * 8, sk);
+    h.wcol = io.sx.ld((L::X_WBT + i) * 8, sk);
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
-        const int row = g + 4 * r;
-        h.wrow[r] = xs.ld(sk, L::X_WBT + row);
-        h.hs[r] = xs.ld(sk, L::X_HS + (hl.idx[r] >= 0 ? hl.idx[r] : 0));
+        h.wrow[r] = io.sx.ld((L::X_WBT + g + 4 * r) * 8, sk);
+        h.hs[r] = io.sx.ld(hl.off.v[r], sk);
     }
     return h;
 }
@@ -232,15 +340,13 @@ __device__ inline Tile buildHTile(const HRaw &h, const HsLane &hl, int k, int K,
         double v = h.e2 * ((row == i ? 1. : 0.) - h.cc * h.wrow[r] * h.wcol);
         if (scvx && (row < P::NXV || i < P::NXV)) // SCvx: the trust cone has no state rows
             v = 0.;
-        if (hl.idx[r] >= 0)
-            v += h.hs[r];
+        v += h.hs[r]; // 0 outside the pattern
         if ((fm & (1u << row)) || (fm & (1u << i)))
             v = (row == i) ? 1. : 0.;
         t.v[r] = v;
     }
     return t;
 }
-// raw entries of [A|B] / C arranged for the M' and N tiles (mask and sign applied at use)
 // state / input column a stage variable reads from A / B (lane-dependent index: small constant table)
 template <class P>
 __device__ inline int varColumn(int j)
@@ -251,22 +357,42 @@ __device__ inline int varColumn(int j)
     else
         return j < P::NXV ? P::XMAP[j] : (j < L::NVU ? P::UMAP[j - P::NXV] : 0);
 }
+// raw entries of [A|B] / C arranged for the M' and N tiles (mask and sign applied at use)
+// M' tile: entry (var j = g+4r, dyn row i); the A part and the B part come from different arrays
 template <class P>
-__device__ inline Tile loadMtRaw(const Ctx &c, int k, int lane) // entry (var j = g+4r, dyn row i)
+struct OffMt
+{
+    Off4 a, b;
+};
+template <class P>
+__device__ inline OffMt<P> offMt(int lane)
 {
     using L = Lay<P>;
-    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
-    Tile t = tileZero();
-    if (i < L::NL)
-    {
+    OffMt<P> o;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            const int j = g + 4 * r;
-            if (j < L::NVU)
-                t.v[r] = j < P::NXV ? c.A[size_t(k) * NX * NX + i * NX + varColumn<P>(j)] : c.B[size_t(k) * NX * NU + i * NU + varColumn<P>(j)];
-        }
+    for (int r = 0; r < 4; r++)
+    {
+        const int j = g + 4 * r;
+        o.a.v[r] = (i < L::NL && j < P::NXV) ? (i * P::NX + varColumn<P>(j)) * 8 : VO_OOB;
+        o.b.v[r] = (i < L::NL && j >= P::NXV && j < L::NVU) ? (i * P::NU + varColumn<P>(j)) * 8 : VO_OOB;
+    }
+    return o;
+}
+template <class P>
+__device__ inline Tile loadMtRaw(const SweepIO<P> &io, const OffMt<P> &o, int k)
+{
+    Tile t;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        // register r holds variables 4r .. 4r+3: all states, all inputs (or unused), or both
+        if (4 * r + 3 < P::NXV)
+            t.v[r] = io.A.ld(o.a.v[r], io.sA(k));
+        else if (4 * r >= P::NXV)
+            t.v[r] = (4 * r < Lay<P>::NVU) ? io.B.ld(o.b.v[r], io.sBC(k)) : 0.;
+        else
+            t.v[r] = io.A.ld(o.a.v[r], io.sA(k)) + io.B.ld(o.b.v[r], io.sBC(k)); // one of the two is out of range -> 0
     }
     return t;
 }
@@ -280,23 +406,18 @@ __device__ inline Tile finishMt(const Tile &raw, unsigned fm, int lane)
     return t;
 }
 template <class P>
-__device__ inline Tile loadNRaw(const Ctx &c, int k, int lane) // entry (dyn row g+4r, var i): only the C part is loaded
+__device__ inline Off4 offN(int lane) // entry (dyn row g+4r, var i): only the C part is loaded
 {
     using L = Lay<P>;
-    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
-    Tile t = tileZero();
-    if (i >= P::NXV && i < L::NVU)
-    {
+    Off4 o;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            const int row = g + 4 * r;
-            if (row < L::NL)
-                t.v[r] = c.C[size_t(k) * NX * NU + row * NU + varColumn<P>(i)];
-        }
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        o.v[r] = (i >= P::NXV && i < L::NVU && row < L::NL) ? (row * P::NU + varColumn<P>(i)) * 8 : VO_OOB;
     }
-    return t;
+    return o;
 }
 template <class P>
 __device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
@@ -315,24 +436,31 @@ __device__ inline Tile finishN(const Tile &raw, unsigned fmn, int lane)
     }
     return t;
 }
-
 // N' tile: entry (var a = g+4r, dyn row b = i) = N[b][a]; only the C part is loaded
 template <class P>
-__device__ inline Tile loadNtRaw(const Ctx &c, int k, int lane)
+__device__ inline Off4 offNt(int lane)
 {
     using L = Lay<P>;
-    constexpr int NX = P::NX, NU = P::NU;
     const int g = lane >> 4, i = lane & 15;
+    Off4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = g + 4 * r;
+        o.v[r] = (i < L::NL && a >= P::NXV && a < L::NVU) ? (i * P::NU + varColumn<P>(a)) * 8 : VO_OOB;
+    }
+    return o;
+}
+template <class P>
+__device__ inline Tile loadNtRaw(const SweepIO<P> &io, const Off4 &o, int k)
+{
     Tile t = tileZero();
 #pragma unroll
     for (int r = 0; r < 4; r++)
     {
-        if (4 * r + 3 < P::NXV || 4 * r >= L::NVU) // this register holds no input variable (RocketQuat: inputs 13..15 live in register 3)
+        if (4 * r + 3 < P::NXV || 4 * r >= Lay<P>::NVU) // this register holds no input variable (RocketQuat: inputs 13..15 live in register 3)
             continue;
-        const int a = g + 4 * r;
-        const bool in = i < L::NL && a >= P::NXV && a < L::NVU;
-        const double v = c.C[size_t(k) * NX * NU + (i < L::NL ? i : 0) * NU + (in ? varColumn<P>(a) : 0)];
-        t.v[r] = in ? v : 0.;
+        t.v[r] = io.C.ld(o.v[r], io.sBC(k));
     }
     return t;
 }
@@ -364,32 +492,18 @@ struct FactorRest
     double einv;
 };
 template <class P>
-__device__ inline FactorRest loadFactorRest(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
+struct FactorOffs
 {
-    constexpr int NL = Lay<P>::NL;
-    const int i = lane & 15;
-    FactorRest f;
-    if (k < c.K - 1)
-    {
-        f.mt = loadMtRaw<P>(c, k, lane);
-        f.n = loadNRaw<P>(c, k, lane);
-        f.rl = loadRhsL<P>(c, xs, sp, k, lane);
-        f.rwn = loadRhsW<P>(xs, sp, k + 1, lane);
-        f.einv = xs.ld(xsStage<P>(k), Lay<P>::X_EINV + (i < NL ? i : 0));
-    }
-    else
-    {
-        f.mt = f.n = f.rl = f.rwn = tileZero();
-        f.einv = 1.;
-    }
-    return f;
-}
+    OffMt<P> mt;
+    Off4 n, rl, rw, cols, triV, triL, yt;
+    int einv;
+};
 
 template <class P>
 SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
     using L = Lay<P>;
-    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
+    constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
@@ -398,31 +512,56 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
     const double dual_reg = scvx ? 1e-9 : 0.;
-    const XS xs = makeXS<P>(c);
-    Tile Z = tileZero(), G = loadRhsW<P>(xs, sp, 0, lane);
+    const SweepIO<P> io(c);
+    FactorOffs<P> o;
+    o.mt = offMt<P>(lane);
+    o.n = offN<P>(lane);
+    o.rl = offRhsL<P>(sp, lane);
+    o.rw = offRhsW<P>(sp, lane);
+    o.cols = offCols(lane, sp.n, 0);
+    o.triV = offTri<NV>(lane, L::FAC_LI);
+    o.triL = offTri<NL>(lane, L::FAC_TI);
+    o.yt = offYt<NL>(lane, L::FAC_YT);
+    o.einv = i < NL ? (L::X_EINV + i) * 8 : VO_OOB;
+#ifdef IPM_PROFILE
+    double pf0 = 0., pf1 = 0.;
+    const long long tfs = clock64();
+#endif
+    Tile Z = tileZero(), G = ldTile(io.sx, o.rw, io.sX(0));
     const HsLane hl = hsLane<P>(lane);
-    HRaw hcur = loadHRaw<P>(xs, hl, 0, lane);
+    HRaw hcur = loadHRaw<P>(io, hl, 0, lane);
     for (int k = 0; k < K; k++)
     {
-        const FactorRest cur = loadFactorRest<P>(c, xs, sp, k, lane); // arrives during the first elimination below
-        HRaw hnxt = hcur;
-        if (k + 1 < K)
-            hnxt = loadHRaw<P>(xs, hl, k + 1, lane); // prefetch
-        double *fk = c.fac + size_t(k) * FACREC;
-        double *svk = c.sv + size_t(k) * SVREC;
+        // this stage's coupling tiles and right-hand sides: they arrive during the first elimination below.  (The last stage
+        // has none: it re-reads those of segment K-2 and leaves the loop before they would be used.)
+        const int ks = k < K - 1 ? k : K - 2;
+        FactorRest cur;
+        cur.mt = loadMtRaw<P>(io, o.mt, ks);
+        cur.n = ldTile(io.C, o.n, io.sBC(ks));
+        cur.rl = ldTile(io.sx, o.rl, io.sX(ks));
+        cur.rwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
+        cur.einv = io.sx.ld(o.einv, io.sX(ks));
+        const HRaw hnxt = loadHRaw<P>(io, hl, k + 1 < K ? k + 1 : k, lane); // prefetch
         Tile Phi = buildHTile<P>(hcur, hl, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
+#ifdef IPM_PROFILE
+        const long long tf0 = clock64();
+#endif
         const Tile Li = INVCHOL<NV>(Phi, sh, lane);
-        storeTri<NV>(fk + FAC_LI, lane, Li);
+#ifdef IPM_PROFILE
+        const long long tf1 = clock64();
+        pf0 += double(tf1 - tf0);
+#endif
+        stTile(io.fac, o.triV, io.sFac(k), Li);
         const Tile Lit = transposeTile(Li, sh, lane);
         const Tile a = mm(Lit, G);
-        saveCols(svk, sp.n, lane, a);
+        stTile(io.sv, o.cols, io.sSv(k), a);
         if (k == K - 1)
             break;
         const unsigned fm = L::fixedMask(k, K), fmn = L::fixedMask(k + 1, K);
         const Tile Yt = mm(Lit, finishMt(cur.mt, fm, lane));
-        storeYt<NL>(fk + FAC_YT, lane, Yt);
+        stTile(io.fac, o.yt, io.sFac(k), Yt);
         Tile Th = mm(Yt, Yt);
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -431,16 +570,31 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
             if (row == i)
                 Th.v[r] = (row < NL) ? Th.v[r] + cur.einv + dual_reg : 1.;
         }
+#ifdef IPM_PROFILE
+        const long long tf2 = clock64();
+#endif
         const Tile Ti = INVCHOL<NL>(Th, sh, lane);
-        storeTri<NL>(fk + FAC_TI, lane, Ti);
+#ifdef IPM_PROFILE
+        pf1 += double(clock64() - tf2);
+#endif
+        stTile(io.fac, o.triL, io.sFac(k), Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
         Z = mm(Tit, finishN<P>(cur.n, fmn, lane));
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(Yt, a));
         const Tile cc = mm(Tit, gl);
-        saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
+        stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
         G = tileAdd(cur.rwn, mm(Z, cc));
         hcur = hnxt;
     }
+#ifdef IPM_PROFILE
+    if (lane == 0)
+    {
+        sh.prof[0] += pf0;
+        sh.prof[1] += pf1;
+        sh.prof[2] += double(clock64() - tfs);
+        sh.prof[3] += 1.;
+    }
+#endif
     WAVE_SYNC();
 }
 
@@ -449,89 +603,68 @@ struct FwdIn
     Tile lit, yt, tit, ti, n, rl, rwn;
 };
 template <class P>
-__device__ inline FwdIn loadFwdIn(const Ctx &c, const XS &xs, const RhsSpec &sp, int k, int lane)
+struct FwdOffs
 {
-    using L = Lay<P>;
-    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
-    const double *fk = c.fac + size_t(k) * FACREC;
+    Off4 lit, yt, tit, ti, n, rl, rw, cols;
+};
+template <class P>
+__device__ inline FwdIn loadFwdIn(const SweepIO<P> &io, const FwdOffs<P> &o, int k, int K)
+{
+    // the last stage has no segment: it re-reads segment K-2 (in range, unused)
+    const int ks = k < K - 1 ? k : K - 2;
     FwdIn f;
-    f.lit = loadTriT<NV>(fk + FAC_LI, lane);
-    if (k < c.K - 1)
-    {
-        f.yt = loadYt<NL>(fk + FAC_YT, lane);
-        f.tit = loadTriT<NL>(fk + FAC_TI, lane);
-        f.ti = loadTri<NL>(fk + FAC_TI, lane);
-        f.n = loadNRaw<P>(c, k, lane);
-        f.rl = loadRhsL<P>(c, xs, sp, k, lane);
-        f.rwn = loadRhsW<P>(xs, sp, k + 1, lane);
-    }
-    else
-        f.yt = f.tit = f.ti = f.n = f.rl = f.rwn = tileZero();
+    f.lit = ldTile(io.fac, o.lit, io.sFac(k));
+    f.yt = ldTile(io.fac, o.yt, io.sFac(ks));
+    f.tit = ldTile(io.fac, o.tit, io.sFac(ks));
+    f.ti = ldTile(io.fac, o.ti, io.sFac(ks));
+    f.n = ldTile(io.C, o.n, io.sBC(ks));
+    f.rl = ldTile(io.sx, o.rl, io.sX(ks));
+    f.rwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
     return f;
 }
 template <class P>
 SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
     using L = Lay<P>;
+    constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
-    const XS xs = makeXS<P>(c);
-    Tile G = loadRhsW<P>(xs, sp, 0, lane);
-    // two stages of loads in flight: the per-stage MFMA chain (~1k cycles) is much shorter than the loaded-HBM
-    // latency, so a distance-1 prefetch still stalls every stage
-    FwdIn cur = loadFwdIn<P>(c, xs, sp, 0, lane);
-    FwdIn nx1 = K > 1 ? loadFwdIn<P>(c, xs, sp, 1, lane) : cur;
+    const SweepIO<P> io(c);
+    FwdOffs<P> o;
+    o.lit = offTriT<NV>(lane, L::FAC_LI);
+    o.yt = offYt<NL>(lane, L::FAC_YT);
+    o.tit = offTriT<NL>(lane, L::FAC_TI);
+    o.ti = offTri<NL>(lane, L::FAC_TI);
+    o.n = offN<P>(lane);
+    o.rl = offRhsL<P>(sp, lane);
+    o.rw = offRhsW<P>(sp, lane);
+    o.cols = offCols(lane, sp.n, 0);
+    Tile G = ldTile(io.sx, o.rw, io.sX(0));
+    FwdIn cur = loadFwdIn<P>(io, o, 0, K);
+#if SWEEP_PREFETCH == 2
+    FwdIn nx1 = loadFwdIn<P>(io, o, K > 1 ? 1 : 0, K);
+#endif
     for (int k = 0; k < K; k++)
     {
-        FwdIn nxt = nx1;
-        if (k + 2 < K)
-            nx1 = loadFwdIn<P>(c, xs, sp, k + 2, lane);
-        double *svk = c.sv + size_t(k) * SVREC;
-        const Tile a = mm(cur.lit, G);
-        saveCols(svk, sp.n, lane, a);
+#if SWEEP_PREFETCH == 2
+        const FwdIn nxt = nx1;
+        nx1 = loadFwdIn<P>(io, o, k + 2 < K ? k + 2 : K - 1, K);
+#else
+        const FwdIn nxt = loadFwdIn<P>(io, o, k + 1 < K ? k + 1 : K - 1, K);
+#endif
+        const Tile a = mm(finishTri<NV>(cur.lit, lane), G);
+        stTile(io.sv, o.cols, io.sSv(k), a);
         if (k == K - 1)
             break;
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(cur.yt, a));
-        const Tile cc = mm(cur.tit, gl);
-        saveCols(svk + NRHS_MAX * 16, sp.n, lane, cc);
+        const Tile cc = mm(finishTri<NL>(cur.tit, lane), gl);
+        stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
         // Z' cc = N' (Ti' cc)
-        G = tileAdd(cur.rwn, mm(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mm(cur.ti, cc)));
+        G = tileAdd(cur.rwn, mm(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mm(finishTri<NL>(cur.ti, lane), cc)));
         cur = nxt;
     }
     WAVE_SYNC();
-}
-
-template <class P>
-__device__ inline void storeSolW(const XS &xs, const RhsSpec &sp, int k, int lane, const Tile &x)
-{
-    const int g = lane >> 4, i = lane & 15;
-    const int kind = colKind(sp, i);
-    if (kind)
-    {
-        const int f = kind == 1 ? int(Lay<P>::X_BCW) : int(Lay<P>::X_VW);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            xs.st(xsStage<P>(k), f + g + 4 * r, x.v[r]);
-    }
-}
-template <class P>
-__device__ inline void storeSolL(const XS &xs, const RhsSpec &sp, int k, int lane, const Tile &l)
-{
-    constexpr int NL = Lay<P>::NL;
-    const int g = lane >> 4, i = lane & 15;
-    const int kind = colKind(sp, i);
-    if (kind)
-    {
-        const int f = kind == 1 ? int(Lay<P>::X_BCL) : int(Lay<P>::X_VL);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-            const int row = g + 4 * r;
-            if (row < NL)
-                xs.st(xsStage<P>(k), f + row, l.v[r]);
-        }
-    }
 }
 
 struct BwdIn
@@ -539,57 +672,69 @@ struct BwdIn
     Tile nt, tit, ti, y, li, cs, as;
 };
 template <class P>
-__device__ inline BwdIn loadBwdIn(const Ctx &c, const RhsSpec &sp, int k, int lane)
+struct BwdOffs
 {
-    using L = Lay<P>;
-    constexpr int NL = L::NL, FAC_LI = L::FAC_LI, FAC_YT = L::FAC_YT, FAC_TI = L::FAC_TI, FACREC = L::FACREC;
-    const double *fk = c.fac + size_t(k) * FACREC;
-    const double *svk = c.sv + size_t(k) * SVREC;
+    Off4 nt, tit, ti, y, li, cols, solW, solL;
+};
+template <class P>
+__device__ inline BwdIn loadBwdIn(const SweepIO<P> &io, const BwdOffs<P> &o, int k, int K)
+{
+    const int ks = k < K - 1 ? k : K - 2;
     BwdIn b;
-    b.li = loadTri<NV>(fk + FAC_LI, lane);
-    b.as = loadCols(svk, sp.n, lane);
-    if (k < c.K - 1)
-    {
-        b.nt = loadNtRaw<P>(c, k, lane);
-        b.tit = loadTriT<NL>(fk + FAC_TI, lane);
-        b.ti = loadTri<NL>(fk + FAC_TI, lane);
-        b.y = loadYtT<NL>(fk + FAC_YT, lane);
-        b.cs = loadCols(svk + NRHS_MAX * 16, sp.n, lane);
-    }
-    else
-        b.nt = b.tit = b.ti = b.y = b.cs = tileZero();
+    b.li = ldTile(io.fac, o.li, io.sFac(k));
+    b.as = ldTile(io.sv, o.cols, io.sSv(k));
+    b.nt = loadNtRaw<P>(io, o.nt, ks);
+    b.tit = ldTile(io.fac, o.tit, io.sFac(ks));
+    b.ti = ldTile(io.fac, o.ti, io.sFac(ks));
+    b.y = ldTile(io.fac, o.y, io.sFac(ks));
+    b.cs = ldTile(io.sv, o.cols, io.sSv(ks) + NRHS_MAX * 16 * 8);
     return b;
 }
 template <class P>
 SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
     using L = Lay<P>;
+    constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
     const RhsSpec sp = uniformSpec(spin);
     const int lane = c.lane, K = c.K;
-    const XS xs = makeXS<P>(c);
-    BwdIn cur = loadBwdIn<P>(c, sp, K - 1, lane);
-    BwdIn nx1 = K > 1 ? loadBwdIn<P>(c, sp, K - 2, lane) : cur;
+    const SweepIO<P> io(c);
+    BwdOffs<P> o;
+    o.nt = offNt<P>(lane);
+    o.tit = offTriT<NL>(lane, L::FAC_TI);
+    o.ti = offTri<NL>(lane, L::FAC_TI);
+    o.y = offYtT<NL>(lane, L::FAC_YT);
+    o.li = offTri<NV>(lane, L::FAC_LI);
+    o.cols = offCols(lane, sp.n, 0);
+    o.solW = offSolW<P>(sp, lane);
+    o.solL = offSolL<P>(sp, lane);
+    BwdIn cur = loadBwdIn<P>(io, o, K - 1, K);
+#if SWEEP_PREFETCH == 2
+    BwdIn nx1 = loadBwdIn<P>(io, o, K > 1 ? K - 2 : 0, K);
+#endif
     Tile x = tileZero();
     for (int k = K - 1; k >= 0; k--)
     {
-        BwdIn nxt = nx1;
-        if (k > 1)
-            nx1 = loadBwdIn<P>(c, sp, k - 2, lane);
+#if SWEEP_PREFETCH == 2
+        const BwdIn nxt = nx1;
+        nx1 = loadBwdIn<P>(io, o, k > 1 ? k - 2 : 0, K);
+#else
+        const BwdIn nxt = loadBwdIn<P>(io, o, k > 0 ? k - 1 : 0, K);
+#endif
         if (k == K - 1)
         {
-            x = mm(cur.li, cur.as); // Li' a = L^-T a
+            x = mm(finishTri<NV>(cur.li, lane), cur.as); // Li' a = L^-T a
         }
         else
         {
             // Z x' - c  with  Z x' = Ti (N x')
-            const Tile t = tileSub(mm(cur.tit, mm(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x)), cur.cs);
-            const Tile lam = mm(cur.ti, t);                 // Ti' t = T^-T t
-            const Tile s = tileSub(cur.as, mm(cur.y, lam)); // a - Y' lam
-            x = mm(cur.li, s);
-            storeSolL<P>(xs, sp, k, lane, lam);
+            const Tile t = tileSub(mm(finishTri<NL>(cur.tit, lane), mm(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x)), cur.cs);
+            const Tile lam = mm(finishTri<NL>(cur.ti, lane), t); // Ti' t = T^-T t
+            const Tile s = tileSub(cur.as, mm(cur.y, lam));      // a - Y' lam
+            x = mm(finishTri<NV>(cur.li, lane), s);
+            stTile(io.sx, o.solL, io.sX(k), lam);
         }
-        storeSolW<P>(xs, sp, k, lane, x);
+        stTile(io.sx, o.solW, io.sX(k), x);
         cur = nxt;
     }
     WAVE_SYNC();

@@ -75,89 +75,6 @@ __device__ inline void storeTile(double *p, int lane, const Tile &t)
 
 // ---- packed factor storage ----
 __device__ inline int triIdx(int row, int col) { return (row * (row + 1)) / 2 + col; }
-// lower triangle of the leading n x n block (row-major packed); outside it the tile is the identity
-template <int n>
-__device__ inline void storeTri(double *p, int lane, const Tile &t)
-{
-    const int g = lane >> 4, i = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int row = g + 4 * r;
-        if (row < n && i <= row)
-            p[triIdx(row, i)] = t.v[r];
-    }
-}
-template <int n>
-__device__ inline Tile loadTri(const double *p, int lane) // tile[row][col] = L[row][col]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int row = g + 4 * r;
-        const bool in = row < n && i <= row;
-        const double v = p[in ? triIdx(row, i) : 0];
-        t.v[r] = in ? v : ((row >= n && row == i) ? 1. : 0.);
-    }
-    return t;
-}
-template <int n>
-__device__ inline Tile loadTriT(const double *p, int lane) // tile[a][b] = L[b][a]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int a = g + 4 * r;
-        const bool in = i < n && a <= i;
-        const double v = p[in ? triIdx(i, a) : 0];
-        t.v[r] = in ? v : ((a >= n && a == i) ? 1. : 0.);
-    }
-    return t;
-}
-// Yt (16 variables x NL dynamics rows), row-major with pitch NL
-template <int NL>
-__device__ inline void storeYt(double *p, int lane, const Tile &t)
-{
-    const int g = lane >> 4, i = lane & 15;
-    if (i < NL)
-    {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            p[(g + 4 * r) * NL + i] = t.v[r];
-    }
-}
-template <int NL>
-__device__ inline Tile loadYt(const double *p, int lane) // tile[a][b] = Yt[a][b]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const double v = p[(g + 4 * r) * NL + (i < NL ? i : 0)];
-        t.v[r] = i < NL ? v : 0.;
-    }
-    return t;
-}
-template <int NL>
-__device__ inline Tile loadYtT(const double *p, int lane) // tile[a][b] = Yt[b][a]
-{
-    const int g = lane >> 4, i = lane & 15;
-    Tile t;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        const int a = g + 4 * r;
-        const double v = p[i * NL + (a < NL ? a : 0)];
-        t.v[r] = a < NL ? v : 0.;
-    }
-    return t;
-}
-
 struct TileShared
 {
     double colA[2][16];
@@ -165,6 +82,9 @@ struct TileShared
     double od[16];
     double pv[16];
     double tr[16 * 17]; // transpose scratch
+#ifdef IPM_PROFILE
+    double prof[4]; // factor sweep: cycles in the two eliminations, in the rest of the stage loop, stages
+#endif
 };
 
 // transpose a D-layout tile through LDS
@@ -188,11 +108,17 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 // resolved at compile time (which register holds pivot row j, which register rows lie entirely above /
 // below the pivot).  Per step: ONE LDS turnaround (publish pivot column of A and pivot row of R, read the
 // <= 8 values this lane needs in one batch), a Newton reciprocal, <= 8 predicated FMAs.
+// Inlined into its callers: as a called function its entry waits for every outstanding memory operation of the wavefront
+// (s_waitcnt vmcnt(0) is part of the function-call ABI), which exposes the latency of the stage loads the factor sweep issues
+// to run under the elimination, and of the factor-record stores in front of the second elimination.
+#ifndef INVCHOL_LINKAGE
+#define INVCHOL_LINKAGE __device__ inline __attribute__((always_inline))
+#endif
 #ifndef INVCHOL_UNROLL
 #define INVCHOL_UNROLL _Pragma("unroll")
 #endif
 template <int n>
-__device__ inline Tile invCholFactor(Tile A, TileShared &sh, int lane)
+INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
 {
     const int g = lane >> 4, i = lane & 15;
     Tile R;

@@ -26,6 +26,9 @@ def emu_lib():
 def hip_lib():
     import __graft_entry__ as g
 
+    alt = os.environ.get("SCPP_HIP_LIBRARY")  # an alternative build of the same sources (tools/r02_variant.sh)
+    if alt:
+        return alt
     if not os.path.exists(g.HIP_LIB):
         g.build_hip()
     return g.HIP_LIB
