@@ -491,16 +491,22 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         Hs[i] = 0.;
     {
         const bool scvx = c.ip[IP_SCVX] != 0.;
-        const double e2 = 1. / (eta[0] * eta[0]);
-        const double den = 2. * wb[0] * wb[0] - 1.;
+        // load group first: a store between two loads pins their order (one memory round trip per entry otherwise)
+        double w[NV + 1];
+#pragma unroll
+        for (int j = 0; j <= NV; j++)
+            w[j] = wb[j];
+        const double e0 = eta[0];
+        const double e2 = 1. / (e0 * e0);
+        const double den = 2. * w[0] * w[0] - 1.;
         // SC: delta_k eliminated -> H = e2 (I - (2/den) w w').  SCvx: delta_k constant -> plain L'W^-2 L = e2 (I + 2 w w')
         // on the rows that exist (the mask is applied where the tile is built, sweeps.h buildHTile)
         st[L::F_HDD] = scvx ? 1. : den * e2;
+#pragma unroll
         for (int j = 0; j < NV; j++)
         {
-            const double wj = wb[1 + j];
-            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * wb[0] * wj * e2;
-            xs[L::X_WBT + j] = wj;
+            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * w[0] * w[1 + j] * e2;
+            xs[L::X_WBT + j] = w[1 + j];
         }
         xs[L::X_HC] = e2;
         xs[L::X_HC + 1] = scvx ? -2. : 2. / den;

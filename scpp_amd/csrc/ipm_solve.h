@@ -62,19 +62,42 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
+        // load group -> compute -> store group: a row-by-row loop puts a store between consecutive rows' loads, which the
+        // compiler may not reorder, i.e. one exposed memory round trip per row
+        double einv[L::NL], qv[L::NL];
+        if (identity)
+        {
+#pragma unroll
+            for (int i = 0; i < L::NL; i++)
+            {
+                einv[i] = 0.5;
+                qv[i] = 0.;
+            }
+        }
+        else
+        {
+            double s1[L::NL], z1[L::NL], s2[L::NL], z2[L::NL];
+#pragma unroll
+            for (int i = 0; i < L::NL; i++)
+            {
+                s1[i] = sg[G_S1 * L::NL + i];
+                z1[i] = sg[G_Z1 * L::NL + i];
+                s2[i] = sg[G_S2 * L::NL + i];
+                z2[i] = sg[G_Z2 * L::NL + i];
+            }
+#pragma unroll
+            for (int i = 0; i < L::NL; i++)
+            {
+                const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i];
+                einv[i] = 0.25 * (r1 + r2);
+                qv[i] = (r1 - r2) / (r1 + r2);
+            }
+        }
+#pragma unroll
         for (int i = 0; i < L::NL; i++)
         {
-            if (identity)
-            {
-                xs[L::X_EINV + i] = 0.5;
-                sg[G_QV * L::NL + i] = 0.;
-            }
-            else
-            {
-                const double r1 = sg[G_S1 * L::NL + i] / sg[G_Z1 * L::NL + i], r2 = sg[G_S2 * L::NL + i] / sg[G_Z2 * L::NL + i];
-                xs[L::X_EINV + i] = 0.25 * (r1 + r2);
-                sg[G_QV * L::NL + i] = (r1 - r2) / (r1 + r2);
-            }
+            xs[L::X_EINV + i] = einv[i];
+            sg[G_QV * L::NL + i] = qv[i];
         }
     }
     if (k < K)
@@ -604,6 +627,7 @@ struct Iter
     double bts;
     // ECOS-style safeguarding: scalars of the last iterate that met the reduced tolerances (its W / delta are in L::F_WBK)
     double bk_sig, bk_dsg, bk_n1, pres_prev;
+    double part_ainv, part_fin; // partial step-length bound / finiteness check handed from phDirStage to phDirSeg
     int D, bad, bk_valid;
 };
 
@@ -1525,8 +1549,32 @@ __device__ inline void dirSegChunk(const SV &sg, const SV &xs, double om, double
     stf<N>(sg, G_DZ2 * L::NL + I0, dz2);
     stf<N>(sg, G_DS2 * L::NL + I0, ds2);
 }
+// One chunk as a function of its own: inside phDirSeg the scheduler of the (long) enclosing block turned the last chunk into
+// load / spill / load chains with one exposed memory round trip each; compiled alone a chunk is one batch of loads, the
+// arithmetic, one batch of stores.  (Calls cost nothing here: no callee-saved registers, see PHASE_FN.)
+struct DirChunkOut
+{
+    double ainv, sumdnb;
+};
+template <class P, int I0, int N>
+PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, int store_final, double ainv, double sumdnb)
+{
+    using L = Lay<P>;
+    const Ctx c = uniformCtx(cin);
+    const int k = c.lane, K = c.K;
+    DirChunkOut o{ainv, sumdnb}; // running maximum / sum of this lane (same order of additions as one pass over all rows)
+    if (k < K - 1)
+    {
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
+        dirSegChunk<P, I0, N>(sg, xs, om, dsig, o.ainv, o.sumdnb, uniformInt(store_final) != 0);
+    }
+    return o;
+}
+// Newton direction, part 1: sigma row (border correction) and the stage cones.  Leaves dsig / ddsg and its share of the
+// step-length bound (Iter::part_ainv) and of the finiteness check (Iter::part_fin) in the wave-uniform state.
 template <class P>
-PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
@@ -1630,18 +1678,49 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
             stf<NLP>(st, L::F_DS + LP0, dsv);
         }
     }
+    ainv = wave_max(ainv);
+    finite_chk = wave_sum(finite_chk);
+    it.part_ainv = ainv;
+    it.part_fin = finite_chk;
+    PUT_BEGIN();
+    if (pass == 0)
+        PUT(gp, g, schur);
+    PUT(ip_, it, bad);
+    PUT(ip_, it, part_ainv);
+    PUT(ip_, it, part_fin);
+    PUT(gp, g, dsig);
+    PUT(gp, g, ddsg);
+    PUT_END();
+}
+// part 2: the segment rows (nu, nu_b and their LP cones), the wave-uniform rows and the step length
+template <class P>
+PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+{
+    using L = Lay<P>;
+    const Ctx c = uniformCtx(cin);
+    const int pass = uniformInt(passIn);
+    const Views v = makeViews<P>(c);
+    const SV &sg = v.sg;
+    Glob g; // the fields this phase produces
+    Iter it;
+    it.bad = ip_->bad;
+    g.dsig = gp->dsig;
+    g.ddsg = gp->ddsg;
+    const double sigma_c = pass ? double(ip_->sigma_c) : 0.;
+    const double om = 1. - sigma_c;
+    double ainv = ip_->part_ainv, finite_chk = ip_->part_fin;
     double sumdnb = 0.;
-    if (v.vsg)
-    {
-        forSegChunks<P, IPM_DIR_CHUNK>(
-            [&](auto i0, auto n) { dirSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, om, g.dsig, ainv, sumdnb, pass != 0); });
-    }
+    forSegChunks<P, IPM_DIR_CHUNK>([&](auto i0, auto n) {
+        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value>(cin, om, g.dsig, pass, ainv, sumdnb);
+        ainv = o.ainv;
+        sumdnb = o.sumdnb;
+    });
     sumdnb = wave_sum(sumdnb);
     const Glob gt = reloadPriv(gp);
     const Iter itt = reloadPriv(ip_);
     // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
     // (sumdnb carries dlam through dnu / dnub)
-    finite_chk = wave_sum(finite_chk + sumdnb * 0.);
+    finite_chk = finite_chk + wave_sum(sumdnb * 0.);
     if (!(finite_chk == 0.))
         it.bad = 1;
     g.dn1 = sumdnb - (gt.s3 / gt.z3) * gt.dz3 - itt.b.rhs3;
@@ -1693,15 +1772,10 @@ PHASE_FN void phDirection(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, in
     }
     PUT_BEGIN();
     if (pass == 0)
-    {
-        PUT(gp, g, schur);
         PUT(ip_, it, sigma_c);
-    }
     else
         PUT(ip_, it, alpha);
     PUT(ip_, it, bad);
-    PUT(gp, g, dsig);
-    PUT(gp, g, ddsg);
     PUT(gp, g, dn1);
     PUT(gp, g, dzs);
     PUT(gp, g, dss);
@@ -1998,7 +2072,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
             }
             PROF_T(tq2);
             PROF_ADD(5, tq1, tq2);
-            phDirection<P>(cs, gp, itp, pass);
+            phDirStage<P>(cs, gp, itp, pass);
+            phDirSeg<P>(cs, gp, itp, pass);
             PROF_T(tq3);
             PROF_ADD(6, tq2, tq3);
             if (it.bad)
