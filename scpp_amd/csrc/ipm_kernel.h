@@ -191,6 +191,15 @@ __device__ inline SV makeSX(double *block, int xrec, int K, unsigned stage)
     return SV{__builtin_amdgcn_make_buffer_rsrc(block, 0, K * xrec * 8, 0x00020000), int(stage * unsigned(xrec) * 8u), 0, 8};
 }
 
+// End of a load group: nothing is scheduled across this point, so every load written above it is issued before the arithmetic
+// below starts (left alone, the pressure heuristics of the scheduler sink loads into the arithmetic and turn one memory round
+// trip per group into one per handful of values -- counted in the ISA with tools/isa_round_trips.py).
+#ifdef SCPP_HIP_EMU
+#define LOADS_ISSUED()
+#else
+#define LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 struct Settings
 {
     double feastol, abstol, reltol, gamma;

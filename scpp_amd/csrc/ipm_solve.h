@@ -505,6 +505,7 @@ __device__ inline int coneScaling(const SV &st, int cix)
     double s[D], z[D], w[D], ls[D], eta;
     ldv<OFF, D>(st, L::F_S, s);
     ldv<OFF, D>(st, L::F_Z, z);
+    LOADS_ISSUED();
     if (!cone::nt_scalingS<D>(s, z, eta, w))
         return 1;
     cone::applyWS<D>(eta, w, z, ls);
@@ -519,27 +520,35 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
 {
     using L = Lay<P>;
     double w[D], rz[D], b2[D], t[D];
+    // one load group: what both passes read, then what this pass reads (z | the scaled affine directions and lambda)
+    double q1[D], q2[D], q3[D];
     const double eta = st[L::F_ETA + cix];
     ldv<OFF, D>(st, L::F_WB, w);
     ldv<OFF, D>(st, L::F_RZ, rz);
+    if (pass == 0)
+        ldv<OFF, D>(st, L::F_Z, q1);
+    else
+    {
+        ldv<OFF, D>(st, L::F_DSS, q1);
+        ldv<OFF, D>(st, L::F_DZS, q2);
+        ldv<OFF, D>(st, L::F_LS, q3);
+    }
+    LOADS_ISSUED();
 #pragma unroll
     for (int i = 0; i < D; i++)
         rz[i] *= om;
     cone::applyWinv2S<D>(eta, w, rz, b2);
     if (pass == 0)
     {
-        double z[D];
-        ldv<OFF, D>(st, L::F_Z, z);
+        const double(&z)[D] = q1;
 #pragma unroll
         for (int i = 0; i < D; i++)
             t[i] = b2[i] - z[i];
     }
     else
     {
-        double dss[D], dzs[D], ls[D], dsv[D], aa[D];
-        ldv<OFF, D>(st, L::F_DSS, dss);
-        ldv<OFF, D>(st, L::F_DZS, dzs);
-        ldv<OFF, D>(st, L::F_LS, ls);
+        const double(&dss)[D] = q1, (&dzs)[D] = q2, (&ls)[D] = q3;
+        double dsv[D], aa[D];
         cone::conicProductS<D>(dss, dzs, dsv);
 #pragma unroll
         for (int i = 0; i < D; i++)
@@ -568,6 +577,7 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
     ldv<OFF, D>(st, L::F_TZ, t);
     ldv<OFF, D>(st, L::F_RZ, rz);
     ldv<OFF, D>(st, L::F_LS, ls);
+    LOADS_ISSUED();
 #pragma unroll
     for (int i = 0; i < D; i++)
         Ld[i] = Ldall[OFF + i];
@@ -585,8 +595,12 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
         stv<OFF, D>(st, L::F_DZ, dz);
         stv<OFF, D>(st, L::F_DS, ds);
     }
-    stv<OFF, D>(st, L::F_DSS, dss);
-    stv<OFF, D>(st, L::F_DZS, dzs);
+    else
+    {
+        // the scaled directions feed the corrector's right-hand side (coneT, pass 1) and nothing else
+        stv<OFF, D>(st, L::F_DSS, dss);
+        stv<OFF, D>(st, L::F_DZS, dzs);
+    }
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
     return a1 > a2 ? a1 : a2;
 }
@@ -1059,6 +1073,7 @@ __device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc
     ldf<N>(sg, G_Z2 * L::NL + I0, z2);
     ldf<N>(sg, G_LAM * L::NL + I0, lam);
     ldf<N>(dy, L::DY_S + I0, S);
+    LOADS_ISSUED();
     double r1[N], r2[N], rnu[N], rnub[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
@@ -1342,13 +1357,17 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
     ldf<N>(sg, G_QV * L::NL + I0, qv);
     ldf<N>(xs, L::X_EINV + I0, einv);
     double c1[N], c2[N];
+    double ds1[N], dz1[N], ds2[N], dz2[N];
     if (pass)
     {
-        double ds1[N], dz1[N], ds2[N], dz2[N];
         ldf<N>(sg, G_DS1 * L::NL + I0, ds1);
         ldf<N>(sg, G_DZ1 * L::NL + I0, dz1);
         ldf<N>(sg, G_DS2 * L::NL + I0, ds2);
         ldf<N>(sg, G_DZ2 * L::NL + I0, dz2);
+    }
+    LOADS_ISSUED();
+    if (pass)
+    {
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
@@ -1384,12 +1403,12 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
     stf<N>(sg, G_BTN * L::NL + I0, btn);
     stf<N>(xs, L::X_RHO + I0, rho);
 }
-template <class P>
-PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+template <class P, int PASS>
+PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const int pass = uniformInt(passIn);
+    constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
     const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg;
     const double *ip = c.ip;
@@ -1462,6 +1481,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
             ldf<NLP>(st, L::F_RZ + LP0, rz);
             ldf<NLP>(st, L::F_DS + LP0, dsv);
             ldf<NLP>(st, L::F_DZ + LP0, dzv);
+            LOADS_ISSUED();
 #pragma unroll
             for (int w = 0; w < NLP; w++)
             {
@@ -1471,13 +1491,14 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int pass
             stf<NLP>(st, L::F_TZ + LP0, tz);
         }
         double tzv[L::NS], uh[3], gw[NV], gdl;
+        double rxw[NV], hdw[NV], beta[NV];
         ldf<L::NS>(st, L::F_TZ, tzv);
         ldf<3>(st, L::F_UHAT, uh);
-        LTmul<P>(ip, fm, tzv, uh, gw, &gdl);
-        double rxw[NV], hdw[NV], beta[NV];
         ldf<NV>(st, L::F_RXW, rxw);
         ldf<NV>(st, L::F_HDW, hdw);
         const double rxd = st[L::F_RXD], hdd = st[L::F_HDD];
+        LOADS_ISSUED();
+        LTmul<P>(ip, fm, tzv, uh, gw, &gdl);
         const double bxd = -om * rxd + gdl;
         const double q = bxd / hdd;
 #pragma unroll
@@ -1519,6 +1540,7 @@ __device__ inline void dirSegChunk(const SV &sg, const SV &xs, double om, double
     ldf<N>(sg, G_TZ2 * L::NL + I0, tz2);
     ldf<N>(sg, G_RZ1 * L::NL + I0, rz1);
     ldf<N>(sg, G_RZ2 * L::NL + I0, rz2);
+    LOADS_ISSUED();
     double dlam[N], dnu[N], dnub[N], dz1[N], ds1[N], dz2[N], ds2[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
@@ -1556,8 +1578,8 @@ struct DirChunkOut
 {
     double ainv, sumdnb;
 };
-template <class P, int I0, int N>
-PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, int store_final, double ainv, double sumdnb)
+template <class P, int I0, int N, bool STORE_FINAL>
+PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, double ainv, double sumdnb)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
@@ -1567,18 +1589,18 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, 
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N>(sg, xs, om, dsig, o.ainv, o.sumdnb, uniformInt(store_final) != 0);
+        dirSegChunk<P, I0, N>(sg, xs, om, dsig, o.ainv, o.sumdnb, STORE_FINAL);
     }
     return o;
 }
 // Newton direction, part 1: sigma row (border correction) and the stage cones.  Leaves dsig / ddsg and its share of the
 // step-length bound (Iter::part_ainv) and of the finiteness check (Iter::part_fin) in the wave-uniform state.
-template <class P>
-PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+template <class P, int PASS>
+PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const int pass = uniformInt(passIn);
+    constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
     const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
@@ -1664,6 +1686,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int
             ldf<NLP>(st, L::F_Z + LP0, zv);
             ldf<NLP>(st, L::F_RZ + LP0, rz);
             ldf<NLP>(st, L::F_TZ + LP0, tz);
+            LOADS_ISSUED();
 #pragma unroll
             for (int w = 0; w < NLP; w++)
             {
@@ -1693,12 +1716,12 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int
     PUT_END();
 }
 // part 2: the segment rows (nu, nu_b and their LP cones), the wave-uniform rows and the step length
-template <class P>
-PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int passIn)
+template <class P, int PASS>
+PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
-    const int pass = uniformInt(passIn);
+    constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
     const Views v = makeViews<P>(c);
     const SV &sg = v.sg;
     Glob g; // the fields this phase produces
@@ -1711,7 +1734,7 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int p
     double ainv = ip_->part_ainv, finite_chk = ip_->part_fin;
     double sumdnb = 0.;
     forSegChunks<P, IPM_DIR_CHUNK>([&](auto i0, auto n) {
-        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value>(cin, om, g.dsig, pass, ainv, sumdnb);
+        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, pass != 0>(cin, om, g.dsig, ainv, sumdnb);
         ainv = o.ainv;
         sumdnb = o.sumdnb;
     });
@@ -2045,7 +2068,10 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         for (int pass = 0; pass < 2; pass++)
         {
             PROF_T(tq0);
-            phRhs<P>(cs, gp, itp, pass);
+            if (pass == 0)
+                phRhs<P, 0>(cs, gp, itp);
+            else
+                phRhs<P, 1>(cs, gp, itp);
             PROF_T(tq1);
             PROF_ADD(4, tq0, tq1);
             if (pass == 0)
@@ -2072,8 +2098,16 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
             }
             PROF_T(tq2);
             PROF_ADD(5, tq1, tq2);
-            phDirStage<P>(cs, gp, itp, pass);
-            phDirSeg<P>(cs, gp, itp, pass);
+            if (pass == 0)
+            {
+                phDirStage<P, 0>(cs, gp, itp);
+                phDirSeg<P, 0>(cs, gp, itp);
+            }
+            else
+            {
+                phDirStage<P, 1>(cs, gp, itp);
+                phDirSeg<P, 1>(cs, gp, itp);
+            }
             PROF_T(tq3);
             PROF_ADD(6, tq2, tq3);
             if (it.bad)
