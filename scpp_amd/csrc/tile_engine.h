@@ -79,7 +79,6 @@ struct TileShared
 {
     double colA[2][16];
     double rowR[2][16];
-    double od[16];
     double pv[16];
     double tr[16 * 17]; // transpose scratch
 #ifdef IPM_PROFILE
@@ -131,47 +130,50 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         pvr[r] = 1.;
         od = (g + 4 * r == i) ? A.v[r] : od;
     }
-    // every lane of column i learns A[i][i]: lanes (g', i) with g' = i & 3 hold it -> publish once
-    WAVE_SYNC();
-    if (g == (i & 3))
-        sh.od[i] = od;
-    WAVE_SYNC();
+    // pivot floor 1e-14 A[i][i] of column i: held by lane (i & 3, i), read by v_readlane at step i (the eliminations of the
+    // 8 wavefronts of a CU are bound by the bandwidth of the one LDS they share: everything wave-uniform stays out of it)
+    od *= 1e-14;
     INVCHOL_UNROLL
     for (int j = 0; j < n; j++)
     {
         const int b = j & 1, rj_ = j >> 2;
+        // The pivot column is published with ZEROS in rows <= j (the pivot itself goes to its own slot): the multipliers
+        // m = A[row][j] / d and the pivot-row entries A[j][i] the readers take from it are then structurally zero wherever the
+        // elimination must not act, and no reader has to mask them (rows >= n of an n < 16 block are zero in column j anyway;
+        // R[j][i] = 0 for i > j by construction).  One predicated write by the 4 lanes of column j replaces ~10 selects per
+        // step in all 64 lanes.
         if (i == j)
         {
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (4 * r + 3 >= j) // rows above the pivot are never read
-                    sh.colA[b][g + 4 * r] = A.v[r];
+                {
+                    const int row = g + 4 * r;
+                    sh.colA[b][row] = row > j ? A.v[r] : 0.;
+                }
         }
         if (g == (j & 3))
             sh.rowR[b][i] = rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3];
         WAVE_SYNC();
         // one batch of LDS reads (no control flow in between)
-        double d = sh.colA[b][j];
-        const double orig = sh.od[j];
-        const double aj = sh.colA[b][i];
-        const double rj = sh.rowR[b][i];
+        double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
+        const double floor_ = readLane(od, (j & 3) * 16 + j);
+        const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
+        const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
         double cr[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
             cr[r] = (4 * r + 3 > j) ? sh.colA[b][g + 4 * r] : 0.;
-        d = fmax(d, 1e-14 * orig);
+        d = fmax(d, floor_);
         const double p = fastRcp(d);
-        const double ajm = (i > j) ? aj : 0.;
-        const double rjm = (i > j) ? 0. : rj;
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
             if (4 * r + 3 > j) // some row of this register lies below the pivot
             {
-                const int row = g + 4 * r;
-                const double m = (row > j && row < n) ? cr[r] * p : 0.;
-                A.v[r] -= m * ajm;
-                R.v[r] -= m * rjm;
+                const double m = cr[r] * p; // 0 for rows <= j
+                A.v[r] -= m * aj;
+                R.v[r] -= m * rj;
             }
             if (r == rj_)
                 pvr[r] = (g + 4 * r == j) ? d : pvr[r];
