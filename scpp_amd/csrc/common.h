@@ -90,6 +90,8 @@ inline double rowMirror(double v) { const int l = threadIdx.x & 63; return __shf
 inline double rowRor8(double v) { return __shfl_xor(v, 8); }
 inline double pairHead(double v) { const int l = threadIdx.x & 63; return __shfl(v, l & ~1); }
 inline double readLane(double v, int src) { return __shfl(v, src); }
+template <int J>
+inline double rowBcast(double v) { const int l = threadIdx.x & 63; return __shfl(v, (l & ~15) | J); }
 inline bool anyLane(bool p) { int v = p ? 1 : 0; for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m); return v != 0; }
 #else
 template <int CTRL>
@@ -106,6 +108,12 @@ __device__ __forceinline__ double rowHalfMirror(double v) { return dppMove<0x141
 __device__ __forceinline__ double rowMirror(double v) { return dppMove<0x140>(v); }     // row_mirror
 __device__ __forceinline__ double rowRor8(double v) { return dppMove<0x128>(v); } // row_ror:8
 __device__ __forceinline__ double pairHead(double v) { return dppMove<0xA0>(v); } // quad_perm:[0,0,2,2]
+// lane J of every row of 16 lanes to the whole row (row_newbcast, gfx90a+)
+template <int J>
+__device__ __forceinline__ double rowBcast(double v)
+{
+    return dppMove<0x150 + J>(v);
+}
 __device__ __forceinline__ double readLane(double v, int src)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);

@@ -133,15 +133,15 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
     // pivot floor 1e-14 A[i][i] of column i: held by lane (i & 3, i), read by v_readlane at step i (the eliminations of the
     // 8 wavefronts of a CU are bound by the bandwidth of the one LDS they share: everything wave-uniform stays out of it)
     od *= 1e-14;
-    INVCHOL_UNROLL
-    for (int j = 0; j < n; j++)
-    {
-        const int b = j & 1, rj_ = j >> 2;
-        // The pivot column is published with ZEROS in rows <= j (the pivot itself goes to its own slot): the multipliers
-        // m = A[row][j] / d and the pivot-row entries A[j][i] the readers take from it are then structurally zero wherever the
+    // compile-time step index: which register holds pivot row j, which registers lie entirely above the pivot, and the DPP
+    // control word of the row broadcast are all constants of the step
+    sfor<n>([&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        constexpr int b = j & 1, rj_ = j >> 2;
+        // The pivot column is published with ZEROS in rows <= j: the pivot-row entries A[j][i] = A[i][j] the readers take from
+        // it (and the multipliers m = A[row][j] / d, which come by row broadcast) are then structurally zero wherever the
         // elimination must not act, and no reader has to mask them (rows >= n of an n < 16 block are zero in column j anyway;
-        // R[j][i] = 0 for i > j by construction).  One predicated write by the 4 lanes of column j replaces ~10 selects per
-        // step in all 64 lanes.
+        // R[j][i] = 0 for i > j by construction).
         if (i == j)
         {
 #pragma unroll
@@ -160,10 +160,15 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         const double floor_ = readLane(od, (j & 3) * 16 + j);
         const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
         const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
+        // column j below the pivot, for this lane's rows: lane (g, j) holds it -> row broadcast on the VALU data path
         double cr[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            cr[r] = (4 * r + 3 > j) ? sh.colA[b][g + 4 * r] : 0.;
+        {
+            cr[r] = 0.;
+            if (4 * r + 3 > j)
+                cr[r] = rowBcast<j>((g + 4 * r > j) ? A.v[r] : 0.);
+        }
         d = fmax(d, floor_);
         const double p = fastRcp(d);
 #pragma unroll
@@ -178,7 +183,7 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
             if (r == rj_)
                 pvr[r] = (g + 4 * r == j) ? d : pvr[r];
         }
-    }
+    });
     Tile Li;
 #pragma unroll
     for (int r = 0; r < 4; r++)
