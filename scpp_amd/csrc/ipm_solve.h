@@ -481,7 +481,7 @@ __device__ inline void forSegChunks(F &&f)
 #define IPM_RHS_CHUNK 5
 #endif
 #ifndef IPM_RES_CHUNK
-#define IPM_RES_CHUNK 5
+#define IPM_RES_CHUNK 7
 #endif
 template <int OFF, int D>
 __device__ inline void ldv(const SV &st, int f, double (&v)[D])
@@ -1127,6 +1127,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             ldf<3>(st, L::F_UHAT, uh);
             dl = st[L::F_DL];
             ldf<L::NS>(st, L::F_S, sv);
+            LOADS_ISSUED();
             saff<P>(ip, v.act, x0, dl, wbar, uh, sa);
 #pragma unroll
             for (int i = 0; i < L::NS; i++)
@@ -1135,9 +1136,10 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 p.rz += sa[i] * sa[i];
                 p.ss += sv[i] * sv[i];
             }
-            stf<L::NS>(st, L::F_RZ, sa);
             double zv[L::NS];
-            ldf<L::NS>(st, L::F_Z, zv);
+            ldf<L::NS>(st, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
+            LOADS_ISSUED();
+            stf<L::NS>(st, L::F_RZ, sa);
 #pragma unroll
             for (int i = 0; i < L::NS; i++)
             {
