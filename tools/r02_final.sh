@@ -9,7 +9,7 @@ grep '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
 timeout -k 5 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_driver.log 2>&1; echo "bench driver-style rc=$?"
 grep '^{' $OUT/bench_driver.log | tail -1 > $OUT/bench_driver.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 1 --pools 1 --no-extras --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 0 --pools 1 --no-extras --no-cpu-baseline > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 cd $ROOT
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats_single_pool.csv; done
