@@ -1823,9 +1823,30 @@ __device__ inline void axpyFields(const SV &rec, int fDst, int fSrc, double alph
         d[i] = rec[fDst + i];
         x[i] = rec[fSrc + i];
     }
+    LOADS_ISSUED();
 #pragma unroll
     for (int i = 0; i < N; i++)
         rec[fDst + i] = d[i] + alpha * x[i];
+}
+// NF fields of N rows each in ONE load group / store group (dst field f at fDst[f], its direction at fSrc[f])
+template <int N, int NF>
+__device__ inline void axpyFieldGroup(const SV &rec, const int (&fDst)[NF], const int (&fSrc)[NF], double alpha)
+{
+    double d[NF][N], x[NF][N];
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            d[f][i] = rec[fDst[f] + i];
+            x[f][i] = rec[fSrc[f] + i];
+        }
+    LOADS_ISSUED();
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            rec[fDst[f] + i] = d[f][i] + alpha * x[f][i];
 }
 template <class P>
 PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
@@ -1836,6 +1857,7 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &sg = v.sg;
     Glob g = loadPriv(gp);
     const double alpha = ip_->alpha;
+    // few, large load groups: a group's loads wait for the stores of the group before it (one memory round trip per group)
     if (v.vst)
     {
         double d[NV], x[NV];
@@ -1845,25 +1867,20 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             d[j] = st[L::F_W + j];
             x[j] = st[L::F_DW + j];
         }
+        const double dl = st[L::F_DL], ddl = st[L::F_DDL];
+        LOADS_ISSUED();
 #pragma unroll
         for (int j = 0; j < NV; j++)
             st[L::F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
-        axpyFields<1>(st, L::F_DL, L::F_DDL, alpha);
-        constexpr int H1 = (L::NS + 1) / 2, H2 = L::NS - H1;
-        axpyFields<H1>(st, L::F_S, L::F_DS, alpha);
-        axpyFields<H2>(st, L::F_S + H1, L::F_DS + H1, alpha);
-        axpyFields<H1>(st, L::F_Z, L::F_DZ, alpha);
-        axpyFields<H2>(st, L::F_Z + H1, L::F_DZ + H1, alpha);
+        st[L::F_DL] = dl + alpha * ddl;
+        axpyFields<L::NS>(st, L::F_S, L::F_DS, alpha);
+        axpyFields<L::NS>(st, L::F_Z, L::F_DZ, alpha);
     }
     if (v.vsg)
     {
-        axpyFields<L::NL>(sg, G_NU * L::NL, G_DNU * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_NUB * L::NL, G_DNUB * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_LAM * L::NL, G_DLAM * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_S1 * L::NL, G_DS1 * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_Z1 * L::NL, G_DZ1 * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_S2 * L::NL, G_DS2 * L::NL, alpha);
-        axpyFields<L::NL>(sg, G_Z2 * L::NL, G_DZ2 * L::NL, alpha);
+        axpyFieldGroup<L::NL, 3>(sg, {G_NU * L::NL, G_NUB * L::NL, G_LAM * L::NL}, {G_DNU * L::NL, G_DNUB * L::NL, G_DLAM * L::NL}, alpha);
+        axpyFieldGroup<L::NL, 2>(sg, {G_S1 * L::NL, G_Z1 * L::NL}, {G_DS1 * L::NL, G_DZ1 * L::NL}, alpha);
+        axpyFieldGroup<L::NL, 2>(sg, {G_S2 * L::NL, G_Z2 * L::NL}, {G_DS2 * L::NL, G_DZ2 * L::NL}, alpha);
     }
     g.sig += alpha * g.dsig;
     g.dsg += alpha * g.ddsg;
