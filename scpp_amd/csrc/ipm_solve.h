@@ -516,7 +516,7 @@ __device__ inline int coneScaling(const SV &st, int cix)
 }
 // t = W^-2 rz' + W^-1(lambda \ ds) of one cone
 template <class P, int OFF, int D>
-__device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu)
+__device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu, double *tout)
 {
     using L = Lay<P>;
     double w[D], rz[D], b2[D], t[D];
@@ -564,6 +564,9 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
             t[i] = b2[i] + aa[i];
     }
     stv<OFF, D>(st, L::F_TZ, t);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        tout[OFF + i] = t[i]; // stays in registers for the L't product of the same phase (no re-read of F_TZ)
 }
 // dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
 // store_final = false (predictor pass): only the scaled directions are needed afterwards (corrector term)
@@ -1467,12 +1470,18 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     // ---- stages ----
     if (v.vst)
     {
+        double tzv[L::NS];
         forEachCone<P>([&](auto ci) {
             constexpr int C = decltype(ci)::value;
             if (act & (1u << C))
-                coneT<P, L::coneOff(C), L::coneDim(C)>(st, C, pass, om, sigmu);
+                coneT<P, L::coneOff(C), L::coneDim(C)>(st, C, pass, om, sigmu, tzv);
             else
+            {
                 zeroT<P, L::coneOff(C), L::coneDim(C)>(st);
+#pragma unroll
+                for (int i = 0; i < L::coneDim(C); i++)
+                    tzv[L::coneOff(C) + i] = 0.;
+            }
         });
         {
             // the LP rows of the table
@@ -1491,10 +1500,12 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 tz[w] = (act & (1u << (L::NCONES + w))) ? (zv[w] / sv[w]) * om * rz[w] - zv[w] + corr : 0.;
             }
             stf<NLP>(st, L::F_TZ + LP0, tz);
+#pragma unroll
+            for (int w = 0; w < NLP; w++)
+                tzv[LP0 + w] = tz[w];
         }
-        double tzv[L::NS], uh[3], gw[NV], gdl;
+        double uh[3], gw[NV], gdl;
         double rxw[NV], hdw[NV], beta[NV];
-        ldf<L::NS>(st, L::F_TZ, tzv);
         ldf<3>(st, L::F_UHAT, uh);
         ldf<NV>(st, L::F_RXW, rxw);
         ldf<NV>(st, L::F_HDW, hdw);
