@@ -1,11 +1,11 @@
 #!/bin/bash
-# robustness / rate across horizons (SC mode + a small SCvx sub-run)
+# robustness / rate across horizons: the headline workload (SCvx, streaming engine) and SC mode at other K.   usage: k_sweep.sh [K ...]
 for k in ${@:-15 30 64}; do
-  timeout 300 python bench.py --K $k --batch 4096 --steps 1 --warmup 0 --no-cpu-baseline --scvx-batch 1024 2>/dev/null | tail -1 > /tmp/ks.json
+  timeout 400 python bench.py --K $k --batch 4096 --steps 1 --warmup 0 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > /tmp/ks.json
   K=$k python - <<'PY'
 import json, os
-d = json.load(open('/tmp/ks.json')); v = d["config"]["scvx_mode"]
-print("K", os.environ["K"], "traj/s %.0f" % d["value"], "fails", d["config"]["solver_failures"], "ipm/traj %.0f" % d["config"]["mean_ipm_iterations_per_trajectory"],
-      "| scvx converged", v.get("converged_fraction"), "fails", v.get("solver_failures"))
+d = json.load(open('/tmp/ks.json')); c = d["config"]; s = c.get("sc_mode", {})
+print("K", os.environ["K"], "converged SCvx traj/s %.0f" % d["value"], "converged fraction", c["converged_fraction"], "solver failures", c["solver_failures"],
+      "ipm/traj %.0f" % c["mean_ipm_iterations_per_trajectory"], "| SC mode traj/s %.0f" % s.get("terminated_trajectories_per_s", 0), "failures", s.get("solver_failures"))
 PY
 done
