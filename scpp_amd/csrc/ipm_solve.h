@@ -1668,6 +1668,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             ldf<NV>(st, L::F_HDW, hdw);
             ldf<3>(st, L::F_UHAT, uh);
             const double bxd = st[L::F_BXD], hdd = st[L::F_HDD];
+            LOADS_ISSUED(); // (without it the loads that only the SC branch below consumes sink into it, one round trip each)
             double acc = 0.;
 #pragma unroll
             for (int j = 0; j < NV; j++)
