@@ -542,6 +542,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         cur.rwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
         cur.einv = io.sx.ld(o.einv, io.sX(ks));
         const HRaw hnxt = loadHRaw<P>(io, hl, k + 1 < K ? k + 1 : k, lane); // prefetch
+        LOADS_ISSUED();
         Tile Phi = buildHTile<P>(hcur, hl, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
@@ -641,28 +642,38 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
     o.rw = offRhsW<P>(sp, lane);
     o.cols = offCols(lane, sp.n, 0);
     Tile G = ldTile(io.sx, o.rw, io.sX(0));
-    FwdIn cur = loadFwdIn<P>(io, o, 0, K);
-#if SWEEP_PREFETCH == 2
-    FwdIn nx1 = loadFwdIn<P>(io, o, K > 1 ? 1 : 0, K);
-#endif
-    for (int k = 0; k < K; k++)
-    {
-#if SWEEP_PREFETCH == 2
-        const FwdIn nxt = nx1;
-        nx1 = loadFwdIn<P>(io, o, k + 2 < K ? k + 2 : K - 1, K);
-#else
-        const FwdIn nxt = loadFwdIn<P>(io, o, k + 1 < K ? k + 1 : K - 1, K);
-#endif
+    // Three prefetch buffers rotated BY NAME (stage loop unrolled three-fold): loads of stage k+2 are in flight while stage k
+    // computes.  Rotating them by register copies (cur = nxt; nxt = nx1) makes every copy wait for the load it copies --
+    // i.e. for the newest loads -- now that the waits are counted exactly (see the header), which was one exposed memory round
+    // trip per stage.
+    auto stage = [&](int k, const FwdIn &cur) -> bool {
         const Tile a = mm(finishTri<NV>(cur.lit, lane), G);
         stTile(io.sv, o.cols, io.sSv(k), a);
         if (k == K - 1)
-            break;
+            return false;
         const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(cur.yt, a));
         const Tile cc = mm(finishTri<NL>(cur.tit, lane), gl);
         stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
         // Z' cc = N' (Ti' cc)
         G = tileAdd(cur.rwn, mm(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mm(finishTri<NL>(cur.ti, lane), cc)));
-        cur = nxt;
+        return true;
+    };
+    auto clampK = [&](int k) { return k < K ? k : K - 1; };
+    FwdIn b0 = loadFwdIn<P>(io, o, 0, K), b1 = loadFwdIn<P>(io, o, clampK(1), K), b2;
+    for (int k = 0; k < K; k += 3)
+    {
+        b2 = loadFwdIn<P>(io, o, clampK(k + 2), K);
+        LOADS_ISSUED();
+        if (!stage(k, b0))
+            break;
+        b0 = loadFwdIn<P>(io, o, clampK(k + 3), K);
+        LOADS_ISSUED();
+        if (!stage(k + 1, b1))
+            break;
+        b1 = loadFwdIn<P>(io, o, clampK(k + 4), K);
+        LOADS_ISSUED();
+        if (!stage(k + 2, b2))
+            break;
     }
     WAVE_SYNC();
 }
@@ -708,19 +719,9 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
     o.cols = offCols(lane, sp.n, 0);
     o.solW = offSolW<P>(sp, lane);
     o.solL = offSolL<P>(sp, lane);
-    BwdIn cur = loadBwdIn<P>(io, o, K - 1, K);
-#if SWEEP_PREFETCH == 2
-    BwdIn nx1 = loadBwdIn<P>(io, o, K > 1 ? K - 2 : 0, K);
-#endif
     Tile x = tileZero();
-    for (int k = K - 1; k >= 0; k--)
-    {
-#if SWEEP_PREFETCH == 2
-        const BwdIn nxt = nx1;
-        nx1 = loadBwdIn<P>(io, o, k > 1 ? k - 2 : 0, K);
-#else
-        const BwdIn nxt = loadBwdIn<P>(io, o, k > 0 ? k - 1 : 0, K);
-#endif
+    // three prefetch buffers rotated by name, see fwdSweep
+    auto stage = [&](int k, const BwdIn &cur) {
         if (k == K - 1)
         {
             x = mm(finishTri<NV>(cur.li, lane), cur.as); // Li' a = L^-T a
@@ -735,7 +736,24 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
             stTile(io.sx, o.solL, io.sX(k), lam);
         }
         stTile(io.sx, o.solW, io.sX(k), x);
-        cur = nxt;
+    };
+    auto clampK = [&](int k) { return k > 0 ? k : 0; };
+    BwdIn b0 = loadBwdIn<P>(io, o, K - 1, K), b1 = loadBwdIn<P>(io, o, clampK(K - 2), K), b2;
+    for (int k = K - 1; k >= 0; k -= 3)
+    {
+        b2 = loadBwdIn<P>(io, o, clampK(k - 2), K);
+        LOADS_ISSUED();
+        stage(k, b0);
+        if (k - 1 < 0)
+            break;
+        b0 = loadBwdIn<P>(io, o, clampK(k - 3), K);
+        LOADS_ISSUED();
+        stage(k - 1, b1);
+        if (k - 2 < 0)
+            break;
+        b1 = loadBwdIn<P>(io, o, clampK(k - 4), K);
+        LOADS_ISSUED();
+        stage(k - 2, b2);
     }
     WAVE_SYNC();
 }
