@@ -524,8 +524,9 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     o.yt = offYt<NL>(lane, L::FAC_YT);
     o.einv = i < NL ? (L::X_EINV + i) * 8 : VO_OOB;
 #ifdef IPM_PROFILE
-    double pf0 = 0., pf1 = 0.;
+    double pf0 = 0., pf1 = 0., pfA = 0., pfC = 0.;
     const long long tfs = clock64();
+    long long tstage = tfs;
 #endif
     Tile Z = tileZero(), G = ldTile(io.sx, o.rw, io.sX(0));
     const HsLane hl = hsLane<P>(lane);
@@ -548,6 +549,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
             Phi = tileAdd(Phi, mm(Z, Z));
 #ifdef IPM_PROFILE
         const long long tf0 = clock64();
+        pfA += double(tf0 - tstage); // stage head: loads issued, H tile, Z'Z
 #endif
         const Tile Li = INVCHOL<NV>(Phi, sh, lane);
 #ifdef IPM_PROFILE
@@ -573,10 +575,12 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         }
 #ifdef IPM_PROFILE
         const long long tf2 = clock64();
+        pfC += double(tf2 - tf1); // between the eliminations: store Li, transpose, a, Yt, Theta
 #endif
         const Tile Ti = INVCHOL<NL>(Th, sh, lane);
 #ifdef IPM_PROFILE
-        pf1 += double(clock64() - tf2);
+        tstage = clock64();
+        pf1 += double(tstage - tf2);
 #endif
         stTile(io.fac, o.triL, io.sFac(k), Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
@@ -592,6 +596,8 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     {
         sh.prof[0] += pf0;
         sh.prof[1] += pf1;
+        sh.prof[4] += pfA;
+        sh.prof[5] += pfC;
         sh.prof[2] += double(clock64() - tfs);
         sh.prof[3] += 1.;
     }
@@ -659,6 +665,20 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         return true;
     };
     auto clampK = [&](int k) { return k < K ? k : K - 1; };
+#if SWEEP_PREFETCH == 1
+    FwdIn b0 = loadFwdIn<P>(io, o, 0, K), b1;
+    for (int k = 0; k < K; k += 2)
+    {
+        b1 = loadFwdIn<P>(io, o, clampK(k + 1), K);
+        LOADS_ISSUED();
+        if (!stage(k, b0))
+            break;
+        b0 = loadFwdIn<P>(io, o, clampK(k + 2), K);
+        LOADS_ISSUED();
+        if (!stage(k + 1, b1))
+            break;
+    }
+#else
     FwdIn b0 = loadFwdIn<P>(io, o, 0, K), b1 = loadFwdIn<P>(io, o, clampK(1), K), b2;
     for (int k = 0; k < K; k += 3)
     {
@@ -675,6 +695,7 @@ SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         if (!stage(k + 2, b2))
             break;
     }
+#endif
     WAVE_SYNC();
 }
 
@@ -738,6 +759,20 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         stTile(io.sx, o.solW, io.sX(k), x);
     };
     auto clampK = [&](int k) { return k > 0 ? k : 0; };
+#if SWEEP_PREFETCH == 1
+    BwdIn b0 = loadBwdIn<P>(io, o, K - 1, K), b1;
+    for (int k = K - 1; k >= 0; k -= 2)
+    {
+        b1 = loadBwdIn<P>(io, o, clampK(k - 1), K);
+        LOADS_ISSUED();
+        stage(k, b0);
+        if (k - 1 < 0)
+            break;
+        b0 = loadBwdIn<P>(io, o, clampK(k - 2), K);
+        LOADS_ISSUED();
+        stage(k - 1, b1);
+    }
+#else
     BwdIn b0 = loadBwdIn<P>(io, o, K - 1, K), b1 = loadBwdIn<P>(io, o, clampK(K - 2), K), b2;
     for (int k = K - 1; k >= 0; k -= 3)
     {
@@ -755,6 +790,7 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
         LOADS_ISSUED();
         stage(k - 2, b2);
     }
+#endif
     WAVE_SYNC();
 }
 

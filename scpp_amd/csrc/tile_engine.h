@@ -82,7 +82,7 @@ struct TileShared
     double pv[16];
     double tr[16 * 17]; // transpose scratch
 #ifdef IPM_PROFILE
-    double prof[4]; // factor sweep: cycles in the two eliminations, in the rest of the stage loop, stages
+    double prof[6]; // factor sweep: cycles in the two eliminations, whole sweep, calls, stage head, between the eliminations
 #endif
 };
 

@@ -23,8 +23,9 @@ print(f"B={B} mean ipm iters {it:.1f}; cycles are 100 MHz s_memtime ticks? (raw 
 for n, v in zip(names, p):
     if n != "-":
         print(f"  {n:14s} total {v:14.0f}   per-iter {v / it:12.0f}   share {100 * v / p[11]:5.1f}%")
-f = info[:, 20:24].mean(axis=0)
+f = info[:, 20:26].mean(axis=0)
 if f[3] > 0:
     print(f"  factor sweep detail (per call, {f[3]:.1f} calls): elimination<16> {f[0] / f[3]:.0f}  elimination<NL> {f[1] / f[3]:.0f}  whole sweep {f[2] / f[3]:.0f}"
-          f"  -> eliminations {100 * (f[0] + f[1]) / f[2]:.1f}% of the sweep")
+          f"  -> eliminations {100 * (f[0] + f[1]) / f[2]:.1f}% of the sweep;"
+          f" stage head (loads, H tile, Z'Z) {f[4] / f[3]:.0f}  between the eliminations {f[5] / f[3]:.0f}  tail {(f[2] - f[0] - f[1] - f[4] - f[5]) / f[3]:.0f}")
 print(alg.ctx.timing())
