@@ -530,21 +530,32 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
 #endif
     Tile Z = tileZero(), G = ldTile(io.sx, o.rw, io.sX(0));
     const HsLane hl = hsLane<P>(lane);
-    HRaw hcur = loadHRaw<P>(io, hl, 0, lane);
-    for (int k = 0; k < K; k++)
+    // One stage.  What is consumed right after the first elimination (M' and E^-1: 12 VGPRs) and the Hessian entries are
+    // requested ONE STAGE AHEAD into buffers that rotate by name (stage loop unrolled two-fold) -- under this traffic a load
+    // takes about as long as the first elimination, which left a wait in front of Yt = Li M'; the tiles of the stage's tail (N,
+    // right-hand sides: 24 VGPRs) are requested at the start of their own stage (prefetching them as well spills).
+    struct Early
     {
-        // this stage's coupling tiles and right-hand sides: they arrive during the first elimination below.  (The last stage
-        // has none: it re-reads those of segment K-2 and leaves the loop before they would be used.)
-        const int ks = k < K - 1 ? k : K - 2;
-        FactorRest cur;
-        cur.mt = loadMtRaw<P>(io, o.mt, ks);
-        cur.n = ldTile(io.C, o.n, io.sBC(ks));
-        cur.rl = ldTile(io.sx, o.rl, io.sX(ks));
-        cur.rwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
-        cur.einv = io.sx.ld(o.einv, io.sX(ks));
-        const HRaw hnxt = loadHRaw<P>(io, hl, k + 1 < K ? k + 1 : k, lane); // prefetch
+        Tile mt;
+        double einv;
+        HRaw h;
+    };
+    auto loadEarly = [&](int k) {
+        const int ks = k < K - 1 ? k : K - 2; // the last stage has no segment: it re-reads segment K-2 (in range, unused)
+        Early e;
+        e.mt = loadMtRaw<P>(io, o.mt, ks);
+        e.einv = io.sx.ld(o.einv, io.sX(ks));
+        e.h = loadHRaw<P>(io, hl, k, lane);
+        return e;
+    };
+    auto stage = [&](int k, const Early &cur, Early &nxt) -> bool {
+        const int ks = k < K - 1 ? k : K - 2, kn = k + 1 < K ? k + 1 : k;
+        const Tile cn = ldTile(io.C, o.n, io.sBC(ks));
+        const Tile crl = ldTile(io.sx, o.rl, io.sX(ks));
+        const Tile crwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
+        nxt = loadEarly(kn);
         LOADS_ISSUED();
-        Tile Phi = buildHTile<P>(hcur, hl, k, K, lane, scvx);
+        Tile Phi = buildHTile<P>(cur.h, hl, k, K, lane, scvx);
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
 #ifdef IPM_PROFILE
@@ -561,7 +572,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const Tile a = mm(Lit, G);
         stTile(io.sv, o.cols, io.sSv(k), a);
         if (k == K - 1)
-            break;
+            return false;
         const unsigned fm = L::fixedMask(k, K), fmn = L::fixedMask(k + 1, K);
         const Tile Yt = mm(Lit, finishMt(cur.mt, fm, lane));
         stTile(io.fac, o.yt, io.sFac(k), Yt);
@@ -584,12 +595,20 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
 #endif
         stTile(io.fac, o.triL, io.sFac(k), Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
-        Z = mm(Tit, finishN<P>(cur.n, fmn, lane));
-        const Tile gl = tileSub(rhsLSign(sp, lane, cur.rl), mm(Yt, a));
+        Z = mm(Tit, finishN<P>(cn, fmn, lane));
+        const Tile gl = tileSub(rhsLSign(sp, lane, crl), mm(Yt, a));
         const Tile cc = mm(Tit, gl);
         stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
-        G = tileAdd(cur.rwn, mm(Z, cc));
-        hcur = hnxt;
+        G = tileAdd(crwn, mm(Z, cc));
+        return true;
+    };
+    Early e0 = loadEarly(0), e1;
+    for (int k = 0; k < K; k += 2)
+    {
+        if (!stage(k, e0, e1))
+            break;
+        if (!stage(k + 1, e1, e0))
+            break;
     }
 #ifdef IPM_PROFILE
     if (lane == 0)
