@@ -56,9 +56,8 @@ struct Lay : Derived<P>
     static constexpr int F_RZ = F_DZ + NS;
     static constexpr int F_TZ = F_RZ + NS;
     static constexpr int F_LS = F_TZ + NS;        // lambda (scaled)
-    static constexpr int F_DSS = F_LS + NS;       // W^-1 ds
-    static constexpr int F_DZS = F_DSS + NS;      // W dz
-    static constexpr int F_ETA = F_DZS + NS;      // [NCONES]
+    static constexpr int F_DSS = F_LS + NS;       // (W^-1 ds_aff) o (W dz_aff): conic product of the scaled affine directions
+    static constexpr int F_ETA = F_DSS + NS;      // [NCONES]
     static constexpr int F_WB = F_ETA + D::NCONES; // [LP0] wbar of the cones, same offsets as the slack layout
     static constexpr int F_BXW = F_WB + D::LP0;   // [16] right-hand side (w part)
     static constexpr int F_BXD = F_BXW + NV;

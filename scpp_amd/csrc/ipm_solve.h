@@ -521,7 +521,7 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     using L = Lay<P>;
     double w[D], rz[D], b2[D], t[D];
     // one load group: what both passes read, then what this pass reads (z | the scaled affine directions and lambda)
-    double q1[D], q2[D], q3[D];
+    double q1[D], q3[D];
     const double eta = st[L::F_ETA + cix];
     ldv<OFF, D>(st, L::F_WB, w);
     ldv<OFF, D>(st, L::F_RZ, rz);
@@ -529,8 +529,7 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
         ldv<OFF, D>(st, L::F_Z, q1);
     else
     {
-        ldv<OFF, D>(st, L::F_DSS, q1);
-        ldv<OFF, D>(st, L::F_DZS, q2);
+        ldv<OFF, D>(st, L::F_DSS, q1); // (W^-1 ds_aff) o (W dz_aff), formed by the predictor's direction phase
         ldv<OFF, D>(st, L::F_LS, q3);
     }
     LOADS_ISSUED();
@@ -547,12 +546,11 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     }
     else
     {
-        const double(&dss)[D] = q1, (&dzs)[D] = q2, (&ls)[D] = q3;
+        const double(&ls)[D] = q3;
         double dsv[D], aa[D];
-        cone::conicProductS<D>(dss, dzs, dsv);
 #pragma unroll
         for (int i = 0; i < D; i++)
-            dsv[i] = -dsv[i];
+            dsv[i] = -q1[i];
         dsv[0] += sigmu;
         cone::conicDivisionS<D>(ls, dsv);
 #pragma unroll
@@ -600,9 +598,10 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
     }
     else
     {
-        // the scaled directions feed the corrector's right-hand side (coneT, pass 1) and nothing else
-        stv<OFF, D>(st, L::F_DSS, dss);
-        stv<OFF, D>(st, L::F_DZS, dzs);
+        // the scaled affine directions feed the corrector's right-hand side (coneT, pass 1) through their conic product only
+        double prod[D];
+        cone::conicProductS<D>(dss, dzs, prod);
+        stv<OFF, D>(st, L::F_DSS, prod);
     }
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
     return a1 > a2 ? a1 : a2;
@@ -1362,13 +1361,11 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
     ldf<N>(sg, G_QV * L::NL + I0, qv);
     ldf<N>(xs, L::X_EINV + I0, einv);
     double c1[N], c2[N];
-    double ds1[N], dz1[N], ds2[N], dz2[N];
+    double p1[N], p2[N]; // ds_aff dz_aff of the two LP cones (written by the predictor's direction phase)
     if (pass)
     {
-        ldf<N>(sg, G_DS1 * L::NL + I0, ds1);
-        ldf<N>(sg, G_DZ1 * L::NL + I0, dz1);
-        ldf<N>(sg, G_DS2 * L::NL + I0, ds2);
-        ldf<N>(sg, G_DZ2 * L::NL + I0, dz2);
+        ldf<N>(sg, G_DS1 * L::NL + I0, p1);
+        ldf<N>(sg, G_DS2 * L::NL + I0, p2);
     }
     LOADS_ISSUED();
     if (pass)
@@ -1376,8 +1373,8 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
-            c1[i] = (sigmu - ds1[i] * dz1[i]) / s1[i];
-            c2[i] = (sigmu - ds2[i] * dz2[i]) / s2[i];
+            c1[i] = (sigmu - p1[i]) / s1[i];
+            c2[i] = (sigmu - p2[i]) / s2[i];
         }
     }
     else
@@ -1520,8 +1517,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             rxw[j] = -om * rxw[j] + gw[j];
             beta[j] = (fm & (1u << j)) ? 0. : rxw[j] - hdw[j] * q;
         }
-        stf<NV>(st, L::F_BXW, rxw);
-        st[L::F_BXD] = bxd;
+        st[L::F_BXD] = bxd; // (F_BXW is an input of the initialisation's kktPrep only: not stored here)
         stf<NV>(v.xs, L::X_BETA, beta);
     }
     if (v.vsg)
@@ -1579,10 +1575,26 @@ __device__ inline void dirSegChunk(const SV &sg, const SV &xs, double om, double
         stf<N>(sg, G_DNU * L::NL + I0, dnu);
         stf<N>(sg, G_DNUB * L::NL + I0, dnub);
     }
-    stf<N>(sg, G_DZ1 * L::NL + I0, dz1);
-    stf<N>(sg, G_DS1 * L::NL + I0, ds1);
-    stf<N>(sg, G_DZ2 * L::NL + I0, dz2);
-    stf<N>(sg, G_DS2 * L::NL + I0, ds2);
+    if (store_final)
+    {
+        stf<N>(sg, G_DZ1 * L::NL + I0, dz1);
+        stf<N>(sg, G_DS1 * L::NL + I0, ds1);
+        stf<N>(sg, G_DZ2 * L::NL + I0, dz2);
+        stf<N>(sg, G_DS2 * L::NL + I0, ds2);
+    }
+    else
+    {
+        // predictor: the corrector's right-hand side needs the products ds_aff dz_aff only (rhsSegChunk, pass 1)
+        double p1[N], p2[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            p1[i] = ds1[i] * dz1[i];
+            p2[i] = ds2[i] * dz2[i];
+        }
+        stf<N>(sg, G_DS1 * L::NL + I0, p1);
+        stf<N>(sg, G_DS2 * L::NL + I0, p2);
+    }
 }
 // One chunk as a function of its own: inside phDirSeg the scheduler of the (long) enclosing block turned the last chunk into
 // load / spill / load chains with one exposed memory round trip each; compiled alone a chunk is one batch of loads, the
