@@ -500,10 +500,12 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
     {
         const bool scvx = c.ip[IP_SCVX] != 0.;
         // load group first: a store between two loads pins their order (one memory round trip per entry otherwise)
+        // (SCvx: the state rows 1 .. NXV of wbar are structural zeros and are read through an out-of-range view, ipm_solve.h: padView)
+        const SV wbz = SV{st.rsrc, scvx ? 0x40000000 : st.lb, st.fo, st.pb} + L::F_WB;
         double w[NV + 1];
 #pragma unroll
         for (int j = 0; j <= NV; j++)
-            w[j] = wb[j];
+            w[j] = (j >= 1 && j <= P::NXV) ? double(wbz[j]) : double(wb[j]);
         const double e0 = eta[0];
         const double e2 = 1. / (e0 * e0);
         const double den = 2. * w[0] * w[0] - 1.;

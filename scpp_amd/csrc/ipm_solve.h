@@ -483,54 +483,80 @@ __device__ inline void forSegChunks(F &&f)
 #ifndef IPM_RES_CHUNK
 #define IPM_RES_CHUNK 7
 #endif
-template <int OFF, int D>
-__device__ inline void ldv(const SV &st, int f, double (&v)[D])
+// Rows 1 .. NP of a vector that starts at the trust-region cone are STRUCTURAL ZEROS in SCvx mode (the state rows of the cone:
+// saff / Lmul produce 0 there, and every cone operation maps zero rows to zero rows).  They are accessed through a second view
+// `rz` of the same record whose lane offset lies beyond the record block in SCvx mode: the buffer hardware then returns 0 for
+// the load and drops the store -- 13 of the 33 slack rows of a RocketQuat stage cost no memory traffic, without a branch.
+// (In SC mode rz == r.)  NP = 0: a plain vector.
+__device__ inline SV padView(const SV &r, bool scvx)
 {
-#pragma unroll
-    for (int i = 0; i < D; i++)
-        v[i] = st[f + OFF + i];
+    return SV{r.rsrc, scvx ? 0x40000000 : r.lb, r.fo, r.pb};
 }
-template <int OFF, int D>
-__device__ inline void stv(const SV &st, int f, const double (&v)[D])
+template <int N, int NP>
+__device__ inline void ldPad(const SV &r, const SV &rz, int f, double (&v)[N])
 {
 #pragma unroll
-    for (int i = 0; i < D; i++)
-        st[f + OFF + i] = v[i];
+    for (int i = 0; i < N; i++)
+        v[i] = (i >= 1 && i <= NP) ? double(rz[f + i]) : double(r[f + i]);
+}
+template <int N, int NP>
+__device__ inline void stPad(const SV &r, const SV &rz, int f, const double (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        if (i >= 1 && i <= NP)
+            rz[f + i] = v[i];
+        else
+            r[f + i] = v[i];
+    }
+}
+__device__ inline bool scvxMode(const double *ip) { return uniformInt(int(ip[IP_SCVX] != 0.)) != 0; }
+// one cone's part of a stage vector: cone 0 (OFF == 0) is the trust-region cone with its NXV state rows
+template <class P, int OFF, int D>
+__device__ inline void ldv(const SV &st, int f, double (&v)[D], const SV &stz)
+{
+    ldPad<D, (OFF == 0 ? P::NXV : 0)>(st, stz, f + OFF, v);
+}
+template <class P, int OFF, int D>
+__device__ inline void stv(const SV &st, int f, const double (&v)[D], const SV &stz)
+{
+    stPad<D, (OFF == 0 ? P::NXV : 0)>(st, stz, f + OFF, v);
 }
 // NT scaling of one cone + lambda = W z ; returns 1 if the iterate left the cone
 template <class P, int OFF, int D>
-__device__ inline int coneScaling(const SV &st, int cix)
+__device__ inline int coneScaling(const SV &st, int cix, const SV &stz)
 {
     using L = Lay<P>;
     double s[D], z[D], w[D], ls[D], eta;
-    ldv<OFF, D>(st, L::F_S, s);
-    ldv<OFF, D>(st, L::F_Z, z);
+    ldv<P, OFF, D>(st, L::F_S, s, stz);
+    ldv<P, OFF, D>(st, L::F_Z, z, stz);
     LOADS_ISSUED();
     if (!cone::nt_scalingS<D>(s, z, eta, w))
         return 1;
     cone::applyWS<D>(eta, w, z, ls);
     st[L::F_ETA + cix] = eta;
-    stv<OFF, D>(st, L::F_WB, w);
-    stv<OFF, D>(st, L::F_LS, ls);
+    stv<P, OFF, D>(st, L::F_WB, w, stz);
+    stv<P, OFF, D>(st, L::F_LS, ls, stz);
     return 0;
 }
 // t = W^-2 rz' + W^-1(lambda \ ds) of one cone
 template <class P, int OFF, int D>
-__device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu, double *tout)
+__device__ inline void coneT(const SV &st, int cix, int pass, double om, double sigmu, double *tout, const SV &stz)
 {
     using L = Lay<P>;
     double w[D], rz[D], b2[D], t[D];
     // one load group: what both passes read, then what this pass reads (z | the scaled affine directions and lambda)
     double q1[D], q3[D];
     const double eta = st[L::F_ETA + cix];
-    ldv<OFF, D>(st, L::F_WB, w);
-    ldv<OFF, D>(st, L::F_RZ, rz);
+    ldv<P, OFF, D>(st, L::F_WB, w, stz);
+    ldv<P, OFF, D>(st, L::F_RZ, rz, stz);
     if (pass == 0)
-        ldv<OFF, D>(st, L::F_Z, q1);
+        ldv<P, OFF, D>(st, L::F_Z, q1, stz);
     else
     {
-        ldv<OFF, D>(st, L::F_DSS, q1); // (W^-1 ds_aff) o (W dz_aff), formed by the predictor's direction phase
-        ldv<OFF, D>(st, L::F_LS, q3);
+        ldv<P, OFF, D>(st, L::F_DSS, q1, stz); // (W^-1 ds_aff) o (W dz_aff), formed by the predictor's direction phase
+        ldv<P, OFF, D>(st, L::F_LS, q3, stz);
     }
     LOADS_ISSUED();
 #pragma unroll
@@ -561,7 +587,7 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
         for (int i = 0; i < D; i++)
             t[i] = b2[i] + aa[i];
     }
-    stv<OFF, D>(st, L::F_TZ, t);
+    stv<P, OFF, D>(st, L::F_TZ, t, stz);
 #pragma unroll
     for (int i = 0; i < D; i++)
         tout[OFF + i] = t[i]; // stays in registers for the L't product of the same phase (no re-read of F_TZ)
@@ -569,15 +595,15 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
 // dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
 // store_final = false (predictor pass): only the scaled directions are needed afterwards (corrector term)
 template <class P, int OFF, int D>
-__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final)
+__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final, const SV &stz)
 {
     using L = Lay<P>;
     double w[D], Ld[D], aa[D], t[D], rz[D], dz[D], ds[D], dss[D], dzs[D], ls[D];
     const double eta = st[L::F_ETA + cix];
-    ldv<OFF, D>(st, L::F_WB, w);
-    ldv<OFF, D>(st, L::F_TZ, t);
-    ldv<OFF, D>(st, L::F_RZ, rz);
-    ldv<OFF, D>(st, L::F_LS, ls);
+    ldv<P, OFF, D>(st, L::F_WB, w, stz);
+    ldv<P, OFF, D>(st, L::F_TZ, t, stz);
+    ldv<P, OFF, D>(st, L::F_RZ, rz, stz);
+    ldv<P, OFF, D>(st, L::F_LS, ls, stz);
     LOADS_ISSUED();
 #pragma unroll
     for (int i = 0; i < D; i++)
@@ -593,15 +619,15 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
     cone::applyWS<D>(eta, w, dz, dzs);
     if (store_final)
     {
-        stv<OFF, D>(st, L::F_DZ, dz);
-        stv<OFF, D>(st, L::F_DS, ds);
+        stv<P, OFF, D>(st, L::F_DZ, dz, stz);
+        stv<P, OFF, D>(st, L::F_DS, ds, stz);
     }
     else
     {
         // the scaled affine directions feed the corrector's right-hand side (coneT, pass 1) through their conic product only
         double prod[D];
         cone::conicProductS<D>(dss, dzs, prod);
-        stv<OFF, D>(st, L::F_DSS, prod);
+        stv<P, OFF, D>(st, L::F_DSS, prod, stz);
     }
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
     return a1 > a2 ? a1 : a2;
@@ -1111,6 +1137,8 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const double *ip = c.ip;
     const unsigned fm = v.fm;
     const double g_z3 = gp->z3, g_sig = gp->sig, it_wtrx = ip_->wtrx;
+    const bool scvx = scvxMode(ip);
+    const SV stz = padView(v.st, scvx);
     ResAcc p;
     p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
     double p_dl = 0.;
@@ -1128,7 +1156,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             ldf<NV>(st, L::F_WBAR, wbar);
             ldf<3>(st, L::F_UHAT, uh);
             dl = st[L::F_DL];
-            ldf<L::NS>(st, L::F_S, sv);
+            ldPad<L::NS, P::NXV>(st, stz, L::F_S, sv);
             LOADS_ISSUED();
             saff<P>(ip, v.act, x0, dl, wbar, uh, sa);
 #pragma unroll
@@ -1139,9 +1167,9 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 p.ss += sv[i] * sv[i];
             }
             double zv[L::NS];
-            ldf<L::NS>(st, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
+            ldPad<L::NS, P::NXV>(st, stz, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
             LOADS_ISSUED();
-            stf<L::NS>(st, L::F_RZ, sa);
+            stPad<L::NS, P::NXV>(st, stz, L::F_RZ, sa);
 #pragma unroll
             for (int i = 0; i < L::NS; i++)
             {
@@ -1302,6 +1330,8 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const Views v = makeViews<P>(c);
     const SV &st = v.st;
     const unsigned act = v.act;
+    const bool scvx = scvxMode(c.ip);
+    const SV stz = padView(v.st, scvx);
     Glob g = loadPriv(gp);
     int bad = 0;
     if (v.vst)
@@ -1309,7 +1339,7 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         forEachCone<P>([&](auto ci) {
             constexpr int C = decltype(ci)::value;
             if (act & (1u << C))
-                bad |= coneScaling<P, L::coneOff(C), L::coneDim(C)>(st, C);
+                bad |= coneScaling<P, L::coneOff(C), L::coneDim(C)>(st, C, stz);
         });
     }
 #ifdef SCPP_HIP_EMU
@@ -1415,6 +1445,8 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &sg = v.sg;
     const double *ip = c.ip;
     const unsigned fm = v.fm, act = v.act;
+    const bool scvx = scvxMode(ip);
+    const SV stz = padView(v.st, scvx);
     Glob g = loadPriv(gp);
     Iter it = loadPriv(ip_);
     const double sigma_c = pass ? it.sigma_c : 0., mu = it.mu;
@@ -1471,7 +1503,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         forEachCone<P>([&](auto ci) {
             constexpr int C = decltype(ci)::value;
             if (act & (1u << C))
-                coneT<P, L::coneOff(C), L::coneDim(C)>(st, C, pass, om, sigmu, tzv);
+                coneT<P, L::coneOff(C), L::coneDim(C)>(st, C, pass, om, sigmu, tzv, stz);
             else
             {
                 zeroT<P, L::coneOff(C), L::coneDim(C)>(st);
@@ -1630,6 +1662,8 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &sg = v.sg, &dy = v.dy;
     const double *ip = c.ip;
     const unsigned act = v.act;
+    const bool scvx = scvxMode(ip);
+    const SV stz = padView(v.st, scvx);
     Glob g;   // the fields this phase produces (the rest is read where it is needed)
     Iter it;
     it.bad = ip_->bad;
@@ -1701,7 +1735,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             constexpr int C = decltype(ci)::value;
             if (act & (1u << C))
             {
-                const double a0 = coneDir<P, L::coneOff(C), L::coneDim(C)>(st, C, om, Ld, pass != 0);
+                const double a0 = coneDir<P, L::coneOff(C), L::coneDim(C)>(st, C, om, Ld, pass != 0, stz);
                 ainv = a0 > ainv ? a0 : ainv;
             }
         });
@@ -1852,6 +1886,19 @@ __device__ inline void axpyFields(const SV &rec, int fDst, int fSrc, double alph
     for (int i = 0; i < N; i++)
         rec[fDst + i] = d[i] + alpha * x[i];
 }
+// dst += alpha src for a stage vector that starts at the trust-region cone (rows 1 .. NP: structural zeros in SCvx mode)
+template <int N, int NP>
+__device__ inline void axpyPad(const SV &rec, const SV &recz, int fDst, int fSrc, double alpha)
+{
+    double d[N], x[N];
+    ldPad<N, NP>(rec, recz, fDst, d);
+    ldPad<N, NP>(rec, recz, fSrc, x);
+    LOADS_ISSUED();
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        d[i] = d[i] + alpha * x[i];
+    stPad<N, NP>(rec, recz, fDst, d);
+}
 // NF fields of N rows each in ONE load group / store group (dst field f at fDst[f], its direction at fSrc[f])
 template <int N, int NF>
 __device__ inline void axpyFieldGroup(const SV &rec, const int (&fDst)[NF], const int (&fSrc)[NF], double alpha)
@@ -1881,6 +1928,8 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &sg = v.sg;
     Glob g = loadPriv(gp);
     const double alpha = ip_->alpha;
+    const bool scvx = scvxMode(c.ip);
+    const SV stz = padView(v.st, scvx);
     // few, large load groups: a group's loads wait for the stores of the group before it (one memory round trip per group)
     if (v.vst)
     {
@@ -1897,8 +1946,8 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         for (int j = 0; j < NV; j++)
             st[L::F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
         st[L::F_DL] = dl + alpha * ddl;
-        axpyFields<L::NS>(st, L::F_S, L::F_DS, alpha);
-        axpyFields<L::NS>(st, L::F_Z, L::F_DZ, alpha);
+        axpyPad<L::NS, P::NXV>(st, stz, L::F_S, L::F_DS, alpha);
+        axpyPad<L::NS, P::NXV>(st, stz, L::F_Z, L::F_DZ, alpha);
     }
     if (v.vsg)
     {
