@@ -501,7 +501,8 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         const bool scvx = c.ip[IP_SCVX] != 0.;
         // load group first: a store between two loads pins their order (one memory round trip per entry otherwise)
         // (SCvx: the state rows 1 .. NXV of wbar are structural zeros and are read through an out-of-range view, ipm_solve.h: padView)
-        const SV wbz = SV{st.rsrc, scvx ? 0x40000000 : st.lb, st.fo, st.pb} + L::F_WB;
+        const SV stz = SV{st.rsrc, scvx ? 0x40000000 : st.lb, st.fo, st.pb};
+        const SV wbz = stz + L::F_WB;
         double w[NV + 1];
 #pragma unroll
         for (int j = 0; j <= NV; j++)
@@ -515,7 +516,7 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
 #pragma unroll
         for (int j = 0; j < NV; j++)
         {
-            st[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * w[0] * w[1 + j] * e2;
+            stz[L::F_HDW + j] = ((fm & (1u << j)) || scvx) ? 0. : 2. * w[0] * w[1 + j] * e2; // SCvx: stays 0 (cleared by phSetup)
             xs[L::X_WBT + j] = w[1 + j];
         }
         xs[L::X_HC] = e2;

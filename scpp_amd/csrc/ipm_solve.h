@@ -1537,7 +1537,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         double rxw[NV], hdw[NV], beta[NV];
         ldf<3>(st, L::F_UHAT, uh);
         ldf<NV>(st, L::F_RXW, rxw);
-        ldf<NV>(st, L::F_HDW, hdw);
+        ldf<NV>(stz, L::F_HDW, hdw); // (all zero in SCvx mode: delta_k is not a variable there)
         const double rxd = st[L::F_RXD], hdd = st[L::F_HDD];
         LOADS_ISSUED();
         LTmul<P>(ip, fm, tzv, uh, gw, &gdl);
@@ -1711,7 +1711,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             double dw[NV], bcw[NV], hdw[NV], uh[3];
             ldf<NV>(v.xs, L::X_VW, dw);
             ldf<NV>(v.xs, L::X_BCW, bcw);
-            ldf<NV>(st, L::F_HDW, hdw);
+            ldf<NV>(stz, L::F_HDW, hdw);
             ldf<3>(st, L::F_UHAT, uh);
             const double bxd = st[L::F_BXD], hdd = st[L::F_HDD];
             LOADS_ISSUED(); // (without it the loads that only the SC branch below consumes sink into it, one round trip each)
