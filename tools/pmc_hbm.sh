@@ -4,6 +4,8 @@
 #   usage: bash tools/pmc_hbm.sh [tag] [batch]      -> gpurun_out/pmc_<tag>/summary.json (copy to profiles/r02_pmc_hbm_<tag>.json)
 TAG=${1:-v1}; BATCH=${2:-4096}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
+# the calibration kernels (tools/bin/ is not tracked: built here if the checkout is fresh)
+[ -x $ROOT/tools/bin/hbm_calib ] || { mkdir -p $ROOT/tools/bin && hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/bin/hbm_calib $ROOT/tools/hbm_calib.hip; }
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --batch $BATCH --steps 1 --warmup 0 --no-extras --no-cpu-baseline"
 run_pass () { # name, counters..., -- command
