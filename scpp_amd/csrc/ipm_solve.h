@@ -1561,13 +1561,13 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
 template <class P, int I0, int N>
-__device__ inline void dirSegChunk(const SV &sg, const SV &xs, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
+__device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
 {
     using L = Lay<P>;
     double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
     double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
     ldf<N>(xs, L::X_VL + I0, vl);
-    ldf<N>(xs, L::X_BCL + I0, bcl);
+    ldf<N>(xsz, L::X_BCL + I0, bcl); // border column: zero in SCvx mode (not stored)
     ldf<N>(xs, L::X_EINV + I0, einv);
     ldf<N>(sg, G_BTN * L::NL + I0, btn);
     ldf<N>(sg, G_BNB * L::NL + I0, bnb);
@@ -1646,7 +1646,7 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, 
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N>(sg, xs, om, dsig, o.ainv, o.sumdnb, STORE_FINAL);
+        dirSegChunk<P, I0, N>(sg, xs, padView(xs, scvxMode(c.ip)), om, dsig, o.ainv, o.sumdnb, STORE_FINAL);
     }
     return o;
 }
@@ -1678,7 +1678,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             double S[L::NL], vl[L::NL], bcl[L::NL];
             ldf<L::NL>(dy, L::DY_S, S);
             ldf<L::NL>(v.xs, L::X_VL, vl);
-            ldf<L::NL>(v.xs, L::X_BCL, bcl);
+            ldf<L::NL>(padView(v.xs, scvx), L::X_BCL, bcl);
 #pragma unroll
             for (int i = 0; i < L::NL; i++)
             {
@@ -1710,7 +1710,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         {
             double dw[NV], bcw[NV], hdw[NV], uh[3];
             ldf<NV>(v.xs, L::X_VW, dw);
-            ldf<NV>(v.xs, L::X_BCW, bcw);
+            ldf<NV>(padView(v.xs, scvx), L::X_BCW, bcw);
             ldf<NV>(stz, L::F_HDW, hdw);
             ldf<3>(st, L::F_UHAT, uh);
             const double bxd = st[L::F_BXD], hdd = st[L::F_HDD];
@@ -2169,8 +2169,9 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
             if (pass == 0)
             {
                 // one factorisation per iteration, fused with the forward substitution of the sigma border
-                // column and of the affine right-hand side
-                const RhsSpec sp = specBorderPlus();
+                // column and of the affine right-hand side.  SCvx (fixed final time): S = 0, the border column is identically
+                // zero -- it is neither solved for nor stored; its readers see zeros through an out-of-range view (padView)
+                const RhsSpec sp = (c.ip[IP_SCVX] != 0.) ? specSingle() : specBorderPlus();
                 factorSweepFused<P>(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
