@@ -1089,7 +1089,7 @@ struct ResAcc
     double gap, rx, ry, rz, xx, yy, zz, ss, rxs, sumnb;
 };
 template <class P, int I0, int N>
-__device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc &p)
+__device__ inline void resSegChunk(const SV &sg, const SV &dyz, double z3, ResAcc &p)
 {
     using L = Lay<P>;
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N], S[N];
@@ -1100,7 +1100,7 @@ __device__ inline void resSegChunk(const SV &sg, const SV &dy, double z3, ResAcc
     ldf<N>(sg, G_S2 * L::NL + I0, s2);
     ldf<N>(sg, G_Z2 * L::NL + I0, z2);
     ldf<N>(sg, G_LAM * L::NL + I0, lam);
-    ldf<N>(dy, L::DY_S + I0, S);
+    ldf<N>(dyz, L::DY_S + I0, S); // dS/dsigma column: zero for a fixed final time (SCvx), read through the padded view
     LOADS_ISSUED();
     double r1[N], r2[N], rnu[N], rnub[N];
 #pragma unroll
@@ -1139,12 +1139,13 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const double g_z3 = gp->z3, g_sig = gp->sig, it_wtrx = ip_->wtrx;
     const bool scvx = scvxMode(ip);
     const SV stz = padView(v.st, scvx);
+    const SV dyz = padView(v.dy, scvx); // for the S column only
     ResAcc p;
     p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
     double p_dl = 0.;
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, dy, g_z3, p); });
+        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, dyz, g_z3, p); });
     }
     if (v.vst)
     {
@@ -1198,7 +1199,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = dyP[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
             const double l = mk * double(sg[G_LAM * L::NL + i]), lp = mp * double(sgP[G_LAM * L::NL + i]);
             const int xi = L::XINV.v[i]; // stage variable of state i, -1: pinned
-            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dy[L::DY_S + i] * g_sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
+            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dyz[L::DY_S + i] * g_sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
 #pragma unroll
             for (int j = 0; j < NXV; j++)
             {
@@ -1676,7 +1677,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         if (v.vsg)
         {
             double S[L::NL], vl[L::NL], bcl[L::NL];
-            ldf<L::NL>(dy, L::DY_S, S);
+            ldf<L::NL>(padView(dy, scvx), L::DY_S, S);
             ldf<L::NL>(v.xs, L::X_VL, vl);
             ldf<L::NL>(padView(v.xs, scvx), L::X_BCL, bcl);
 #pragma unroll
