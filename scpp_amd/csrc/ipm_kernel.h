@@ -87,8 +87,6 @@ struct Lay : Derived<P>
     static constexpr int FAC_LI = 0, FAC_YT = NV * (NV + 1) / 2, FAC_TI = FAC_YT + NV * NL;
     static constexpr int FACREC = (FAC_TI + NL * (NL + 1) / 2 + 7) & ~7;
     // field-major copy of the segment dynamics (A, B, C, s, z) for the lane = segment phases
-    // the lane = segment phases walk the NL rows of a segment in three register-sized chunks
-    static constexpr int SC1 = (NL + 2) / 3, SC2 = (NL - SC1 + 1) / 2, SC3 = NL - SC1 - SC2;
     static constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX;
 };
 // ---- segment record fields (each NL doubles) ----

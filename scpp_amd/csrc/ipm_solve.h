@@ -645,10 +645,13 @@ __device__ inline void zeroT(const SV &st)
 // =====================================================================================================
 // The solver is split into OUT-OF-LINE phases.  Each phase gets its own register allocation (the monolithic
 // kernel kept >1000 values alive and spilled inside every hot loop); what survives a phase boundary lives in
-// the field-major records (global memory) or in the two small wave-uniform structs Glob / Iter, which the
-// kernel keeps in LDS (one copy per wavefront, 1.4 KB) and every phase copies in and out.  (They lived in private memory
-// first: 64 per-lane copies of ~100 wave-uniform doubles, stored and re-loaded by every phase, were ~0.9 MB of scratch
-// traffic per interior-point iteration on a kernel that is HBM-bandwidth bound.)
+// the records in global memory or in the two small wave-uniform structs Glob / Iter, which the kernel keeps in LDS (one
+// copy per wavefront, 1.4 KB).  The per-iteration phases read their fields where they need them and write back only what
+// they change (PUT); the once-per-solve phases copy them in and out whole (loadPriv / storePriv).
+// PHASE_FN: static + noinline + disable_tail_calls.  LLVM skips the save / restore of callee-saved VGPRs for functions with
+// internal linkage that are never the target of a tail call, and every call that passes no pointer into the caller's stack
+// frame is a tail-call candidate unless the attribute says otherwise.  Without it each heavy phase saved and restored 108
+// VGPRs (57 KB of scratch traffic per call and wavefront) -- DESIGN.md 4.2 / 5.0.
 // =====================================================================================================
 #define PRIV LDSP
 #ifdef SCPP_HIP_EMU

@@ -24,9 +24,6 @@ namespace ipm
 #ifndef SWEEP_PREFETCH
 #define SWEEP_PREFETCH 2
 #endif
-#ifndef FACTOR_PREFETCH_REST
-#define FACTOR_PREFETCH_REST 0
-#endif
 #ifndef SWEEPS_INLINE
 #define SWEEP_FN static __device__ __attribute__((noinline, disable_tail_calls))
 #else
