@@ -1382,7 +1382,7 @@ template <class P, int I0, int N>
 __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double om, double sigmu, double dz3)
 {
     using L = Lay<P>;
-    double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N], qv[N], einv[N];
+    double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N];
     ldf<N>(sg, G_S1 * L::NL + I0, s1);
     ldf<N>(sg, G_Z1 * L::NL + I0, z1);
     ldf<N>(sg, G_S2 * L::NL + I0, s2);
@@ -1392,8 +1392,6 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
     ldf<N>(sg, G_RXNU * L::NL + I0, rxnu);
     ldf<N>(sg, G_RXNUB * L::NL + I0, rxnub);
     ldf<N>(sg, G_RY * L::NL + I0, ry);
-    ldf<N>(sg, G_QV * L::NL + I0, qv);
-    ldf<N>(xs, L::X_EINV + I0, einv);
     double c1[N], c2[N];
     double p1[N], p2[N]; // ds_aff dz_aff of the two LP cones (written by the predictor's direction phase)
     if (pass)
@@ -1417,7 +1415,7 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
         for (int i = 0; i < N; i++)
             c1[i] = c2[i] = 0.;
     }
-    double t1[N], t2[N], dinv[N], bnb[N], btn[N], rho[N];
+    double t1[N], t2[N], bnb[N], btn[N], rho[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
@@ -1427,14 +1425,16 @@ __device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double 
         const double bxnu = -om * rxnu[i] + (-t1[i] + t2[i]);
         const double bxnub = -om * rxnub[i] + (t1[i] + t2[i]);
         const double by = -om * ry[i];
-        dinv[i] = 1. / (d1 + d2);
+        // E^-1 and q of the eliminated LP pair, recomputed from the slacks this chunk holds anyway (same expressions as
+        // prepareFactor, whose X_EINV the factor sweep uses): three divisions instead of two more rows from memory
+        const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i];
+        const double einv = 0.25 * (r1 + r2), qv = (r1 - r2) / (r1 + r2);
         bnb[i] = bxnub - dz3;
-        btn[i] = bxnu - qv[i] * bnb[i];
-        rho[i] = by + einv[i] * btn[i];
+        btn[i] = bxnu - qv * bnb[i];
+        rho[i] = by + einv * btn[i];
     }
     stf<N>(sg, G_TZ1 * L::NL + I0, t1);
     stf<N>(sg, G_TZ2 * L::NL + I0, t2);
-    stf<N>(sg, G_DINV * L::NL + I0, dinv);
     stf<N>(sg, G_BNB * L::NL + I0, bnb);
     stf<N>(sg, G_BTN * L::NL + I0, btn);
     stf<N>(xs, L::X_RHO + I0, rho);
@@ -1568,15 +1568,12 @@ template <class P, int I0, int N>
 __device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
 {
     using L = Lay<P>;
-    double vl[N], bcl[N], einv[N], btn[N], bnb[N], dinv[N], qv[N];
+    double vl[N], bcl[N], btn[N], bnb[N];
     double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
     ldf<N>(xs, L::X_VL + I0, vl);
     ldf<N>(xsz, L::X_BCL + I0, bcl); // border column: zero in SCvx mode (not stored)
-    ldf<N>(xs, L::X_EINV + I0, einv);
     ldf<N>(sg, G_BTN * L::NL + I0, btn);
     ldf<N>(sg, G_BNB * L::NL + I0, bnb);
-    ldf<N>(sg, G_DINV * L::NL + I0, dinv);
-    ldf<N>(sg, G_QV * L::NL + I0, qv);
     ldf<N>(sg, G_S1 * L::NL + I0, s1);
     ldf<N>(sg, G_Z1 * L::NL + I0, z1);
     ldf<N>(sg, G_S2 * L::NL + I0, s2);
@@ -1590,14 +1587,17 @@ __device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, do
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
+        // E^-1, q and 1/(d1 + d2) of the eliminated LP pair from the slacks (same expressions as prepareFactor / rhsSegChunk)
+        const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i], d1 = z1[i] / s1[i], d2 = z2[i] / s2[i];
+        const double einv = 0.25 * (r1 + r2), qv = (r1 - r2) / (r1 + r2), dinv = 1. / (d1 + d2);
         dlam[i] = vl[i] - bcl[i] * dsig;
-        dnu[i] = einv[i] * (dlam[i] + btn[i]);
-        dnub[i] = bnb[i] * dinv[i] - qv[i] * dnu[i];
+        dnu[i] = einv * (dlam[i] + btn[i]);
+        dnub[i] = bnb[i] * dinv - qv * dnu[i];
         sumdnb += dnub[i];
         const double L1v = dnub[i] - dnu[i], L2v = dnub[i] + dnu[i];
-        dz1[i] = -(z1[i] / s1[i]) * L1v + tz1[i];
+        dz1[i] = -d1 * L1v + tz1[i];
         ds1[i] = -om * rz1[i] + L1v;
-        dz2[i] = -(z2[i] / s2[i]) * L2v + tz2[i];
+        dz2[i] = -d2 * L2v + tz2[i];
         ds2[i] = -om * rz2[i] + L2v;
         double m1 = -ds1[i] / s1[i], m2 = -dz1[i] / z1[i], m3 = -ds2[i] / s2[i], m4 = -dz2[i] / z2[i];
         m1 = m1 > m2 ? m1 : m2;
