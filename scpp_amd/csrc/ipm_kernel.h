@@ -147,6 +147,8 @@ __host__ __device__ inline size_t workspaceDoubles(int K)
 // i.e. ONE 32-bit VGPR (lane*8) serves all fields and the field offsets live in SGPRs.  (Plain global
 // pointers made the compiler keep ~70 loop-invariant 64-bit VGPR addresses -- one per 4 KB window of the
 // field-major record -- and spill them.)
+// byte offset beyond every record block of an instance: a buffer load at it returns 0, a buffer store is dropped
+constexpr int VO_OOB = 0x40000000;
 typedef unsigned int u32x2_t __attribute__((vector_size(8)));
 struct SV
 {
@@ -499,7 +501,7 @@ __device__ inline void buildHs(const Ctx &c, int k, bool identity)
         const bool scvx = c.ip[IP_SCVX] != 0.;
         // load group first: a store between two loads pins their order (one memory round trip per entry otherwise)
         // (SCvx: the state rows 1 .. NXV of wbar are structural zeros and are read through an out-of-range view, ipm_solve.h: padView)
-        const SV stz = SV{st.rsrc, scvx ? 0x40000000 : st.lb, st.fo, st.pb};
+        const SV stz = SV{st.rsrc, scvx ? VO_OOB : st.lb, st.fo, st.pb};
         const SV wbz = stz + L::F_WB;
         double w[NV + 1];
 #pragma unroll

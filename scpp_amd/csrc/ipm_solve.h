@@ -490,7 +490,7 @@ __device__ inline void forSegChunks(F &&f)
 // (In SC mode rz == r.)  NP = 0: a plain vector.
 __device__ inline SV padView(const SV &r, bool scvx)
 {
-    return SV{r.rsrc, scvx ? 0x40000000 : r.lb, r.fo, r.pb};
+    return SV{r.rsrc, scvx ? VO_OOB : r.lb, r.fo, r.pb};
 }
 template <int N, int NP>
 __device__ inline void ldPad(const SV &r, const SV &rz, int f, double (&v)[N])

@@ -58,7 +58,6 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
     return c;
 }
 // ---- branch-free buffer access ----
-constexpr int VO_OOB = 0x40000000; // byte offset beyond every record block of an instance
 struct Buf
 {
     __amdgpu_buffer_rsrc_t r;
