@@ -154,36 +154,10 @@ __device__ inline void tileSolve(const Tile &Li, const Tile &LiT, Shared &sh, in
 
 // Nesterov-Todd scaling of the slot-1 cones, one component per lane.  Lanes that hold no row are their own "head" with
 // zero data: they contribute 0 to every cone sum and every helper returns 0 for them.
-// A/B switches.  MPC_NEW_*: shared reciprocals (one division per cone and iteration, multiplications at the uses) instead of a
-// division per use -- measured on 256 states against the twin: W, DIV, STEP, LP keep identical statuses and iteration
-// counts and take the kernel from 6.5 M to 8.0 M solves/s; SCAL does not (8 of 256 counts differ) and stays off.
-// MPC_FAST_*: hardware seed + Newton (fastRcp / fastRsqrt) instead of correctly rounded reciprocals: +1 %, left off.
-#ifndef MPC_NEW_W
-#define MPC_NEW_W 1
-#endif
-#ifndef MPC_NEW_DIV
-#define MPC_NEW_DIV 1
-#endif
-#ifndef MPC_NEW_STEP
-#define MPC_NEW_STEP 1
-#endif
-#ifndef MPC_NEW_SCAL
-#define MPC_NEW_SCAL 0 // measured: the normalised-vector form of the NT scaling loses the iterate-for-iterate agreement with the twin
-#endif
-#ifndef MPC_NEW_LP
-#define MPC_NEW_LP 1
-#endif
-#ifndef MPC_FAST_SCAL
-#define MPC_FAST_SCAL 0
-#endif
-#ifndef MPC_FAST_LAM
-#define MPC_FAST_LAM 0
-#endif
-#ifndef MPC_FAST_LP
-#define MPC_FAST_LP 0
-#endif
-__device__ __forceinline__ double rcpSel(double d, bool fast) { return fast ? fastRcp(d) : 1. / d; }
-__device__ __forceinline__ double rsqrtSel(double d, bool fast) { return fast ? fastRsqrt(d) : 1. / sqrt(d); }
+// Reciprocals are SHARED: one correctly rounded division per cone / row and iteration with multiplications at the uses (measured on
+// 256 states against the twin: identical statuses and iteration counts, 6.5 M -> 8.0 M solves/s).  Two variants were measured
+// and dropped: the same treatment of the NT scaling itself (8 of 256 iteration counts then differ from the twin) and hardware
+// seed + Newton reciprocals instead of IEEE divisions (+1 %).
 
 struct ConeScal
 {
@@ -206,34 +180,21 @@ template <class RowsT>
 __device__ inline double applyW(const ConeScal &c, const RowsT &R, double v)
 {
     const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
-#if MPC_NEW_W
     const double f = v0 + zeta * c.iw01;
-#else
-    const double f = v0 + zeta / (1. + c.w0);
-#endif
     return !R.act1 ? 0. : R.head ? c.eta * (c.w0 * v0 + zeta) : c.eta * (v + f * c.w);
 }
 template <class RowsT>
 __device__ inline double applyWinv(const ConeScal &c, const RowsT &R, double v)
 {
     const double zeta = csum(R.head ? 0. : c.w * v, R.lane), v0 = headv(v, R.lane);
-#if MPC_NEW_W
     const double f = -v0 + zeta * c.iw01;
     return !R.act1 ? 0. : R.head ? (c.w0 * v0 - zeta) * c.ieta : (v + f * c.w) * c.ieta;
-#else
-    const double f = -v0 + zeta / (1. + c.w0);
-    return !R.act1 ? 0. : R.head ? (c.w0 * v0 - zeta) / c.eta : (v + f * c.w) / c.eta;
-#endif
 }
 template <class RowsT>
 __device__ inline double applyWinv2(const ConeScal &c, const RowsT &R, double v)
 {
     const double tv = csum(R.head ? c.w * v : -c.w * v, R.lane), v0 = headv(v, R.lane);
-#if MPC_NEW_W
     const double e2 = c.ieta * c.ieta;
-#else
-    const double e2 = 1. / (c.eta * c.eta);
-#endif
     return !R.act1 ? 0. : R.head ? e2 * (2. * c.w0 * tv - v0) : e2 * (-2. * c.w * tv + v);
 }
 template <class RowsT>
@@ -251,8 +212,8 @@ __device__ inline LamInfo lamInfo(const RowsT &R, double lam)
     const double l1 = csum(R.head ? 0. : lam * lam, R.lane);
     const double ln2 = L.lam0 * L.lam0 - l1;
     L.ln2 = ln2;
-    L.iln = rsqrtSel(ln2, MPC_FAST_LAM);
-    L.f_den = rcpSel(L.lam0 * L.iln + 1., MPC_FAST_LAM);
+    L.iln = 1. / sqrt(ln2);
+    L.f_den = 1. / (L.lam0 * L.iln + 1.);
     return L;
 }
 // lam \ dd
@@ -261,31 +222,18 @@ __device__ inline double conicDivision(const RowsT &R, const LamInfo &L, double 
 {
     const double l1d1 = csum(R.head ? 0. : L.lam * dd, R.lane), dd0 = headv(dd, R.lane);
     // rho = lam0^2 - |lam1|^2 = 1 / iln^2
-#if MPC_NEW_DIV
     const double u0 = (L.lam0 * dd0 - l1d1) * (L.iln * L.iln);
-    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * L.lam) * rcpSel(L.lam0, MPC_FAST_LAM);
-#else
-    const double u0 = (L.lam0 * dd0 - l1d1) / L.ln2;
-    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * L.lam) / L.lam0;
-#endif
+    return !R.act1 ? 0. : R.head ? u0 : (dd - u0 * L.lam) * (1. / L.lam0);
 }
 // 1 / (largest step keeping lam + alpha v in the cone)   (ECOS lineSearch)
 template <class RowsT>
 __device__ inline double stepInv(const RowsT &R, const LamInfo &L, double v)
 {
     const double v0 = headv(v, R.lane);
-#if MPC_NEW_STEP
     const double lbJv = csum(R.head ? L.lam * v : -L.lam * v, R.lane) * L.iln;
     const double rho0 = lbJv * L.iln;
     const double f = (lbJv + v0) * L.f_den;
     const double ri = R.head ? 0. : (v - f * L.lam * L.iln) * L.iln;
-#else
-    const double ln = sqrt(L.ln2);
-    const double lbJv = csum(R.head ? L.lam * v : -L.lam * v, R.lane) / ln;
-    const double rho0 = lbJv / ln;
-    const double f = (lbJv + v0) / (L.lam0 / ln + 1.);
-    const double ri = R.head ? 0. : (v - f * L.lam / ln) / ln;
-#endif
     const double r1 = csum(ri * ri, R.lane);
     return R.act1 ? sqrt(r1) - rho0 : 0.;
 }
@@ -475,28 +423,14 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
         }
         // ---- scalings ----
         bool ok = !R.act0 || (s0 > 0. && z0 > 0.);
-        const double is0 = rcpSel(s0, MPC_FAST_LP), iz0 = rcpSel(z0, MPC_FAST_LP);
-#if MPC_NEW_LP
+        const double is0 = 1. / s0, iz0 = 1. / z0;
         const double zos = R.act0 ? z0 * is0 : 0.; // W^-2 of the LP rows
-#else
-        const double zos = R.act0 ? z0 / s0 : 0.;
-#endif
         ConeScal cs;
         {
             const double sh_ = headv(s1, lane), zh_ = headv(z1, lane);
             const double s2 = csum(R.head ? 0. : s1 * s1, lane), z2 = csum(R.head ? 0. : z1 * z1, lane);
             const double sres = sh_ * sh_ - s2, zres = zh_ * zh_ - z2;
             ok = ok && (!R.act1 || (sres > 0. && zres > 0.));
-#if MPC_NEW_SCAL
-            const double isn = rsqrtSel(sres, MPC_FAST_SCAL), izn = rsqrtSel(zres, MPC_FAST_SCAL); // 1/||s||_J, 1/||z||_J
-            const double sb = s1 * isn, zb = z1 * izn;
-            const double sz = csum(sb * zb, lane);
-            const double a = 0.5 * rsqrtSel(0.5 * (1. + sz), MPC_FAST_SCAL); // 1/(2 gamma)
-            cs.w = R.act1 ? (R.head ? a * (sb + zb) : a * (sb - zb)) : 0.;
-            const double e2 = (sres * isn) * izn; // ||s||_J / ||z||_J = eta^2
-            cs.ieta = R.act1 ? rsqrtSel(e2, MPC_FAST_SCAL) : 1.;
-            cs.eta = R.act1 ? e2 * cs.ieta : 1.;
-#else
             const double sn = sqrt(sres), zn = sqrt(zres);
             const double sz = csum(s1 * z1, lane) / (sn * zn);
             const double gamma = sqrt(0.5 * (1. + sz));
@@ -504,10 +438,9 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             cs.w = R.act1 ? (R.head ? a * (s1 / sn + z1 / zn) : a * (s1 / sn - z1 / zn)) : 0.;
             cs.eta = R.act1 ? sqrt(sn / zn) : 1.;
             cs.ieta = 1. / cs.eta;
-#endif
             const double hw = headv(cs.w, lane); // (shuffles are never issued under a lane-dependent condition)
             cs.w0 = R.act1 ? hw : 1.;
-            cs.iw01 = rcpSel(1. + cs.w0, MPC_FAST_SCAL);
+            cs.iw01 = 1. / (1. + cs.w0);
         }
         if (anyLane(!ok))
         {
@@ -574,11 +507,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             // t = W^-2 (om rz) + [ -z | W^-1( lam \ (sigma mu e - dsS o dzS) - lam ) ]
             double t0, t1;
             {
-#if MPC_NEW_LP
                 const double corr0 = (pass && R.act0) ? (sigma_c * mu - ds0 * dz0) * is0 : 0.;
-#else
-                const double corr0 = (pass && R.act0) ? (sigma_c * mu - ds0 * dz0) / s0 : 0.;
-#endif
                 t0 = R.act0 ? zos * om * rz0 - z0 + corr0 : 0.;
                 const double b2 = applyWinv2(cs, R, om * rz1);
                 if (pass == 0)
@@ -614,11 +543,7 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             // dz = W^-2 G dx + t ; ds = -om rz - G dx
             dz0 = R.act0 ? zos * gd0 + t0 : 0.;
             ds0 = R.act0 ? -om * rz0 - gd0 : 0.;
-#if MPC_NEW_LP
             double ainv = R.act0 ? fmax(-ds0 * is0, -dz0 * iz0) : 0.;
-#else
-            double ainv = R.act0 ? fmax(-ds0 / s0, -dz0 / z0) : 0.;
-#endif
             const double w2g = applyWinv2(cs, R, R.act1 ? gd1 : 0.);
             dz1 = R.act1 ? w2g + t1 : 0.;
             ds1 = R.act1 ? -om * rz1 - gd1 : 0.;

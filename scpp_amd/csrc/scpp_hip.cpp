@@ -3,6 +3,7 @@
 #include "../../include/scpp_hip.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -366,12 +367,36 @@ int countActive(scpp_hip_ctx *c, int *n)
 extern "C"
 {
 
+// The toolchain this source was validated with on hardware (every kernel instantiation has a whole-run parity test under
+// `pytest -m gpu`, DESIGN.md 4.2 "Toolchain hazard").  Two miscompilations of ipm_kernel were seen with it -- both in the
+// SGPR-spill path under heavy VGPR pressure, both worked around in source -- so a build with ANY other compiler, or at another
+// occupancy, is unvalidated until the GPU tests have run against it: the version string says so and scpp_hip_create warns once.
+#define SCPP_VALIDATED_CLANG_MAJOR 22
+#define SCPP_VALIDATED_HIP_MAJOR 7
+#define SCPP_VALIDATED_HIP_MINOR 2
+#define SCPP_STR2(x) #x
+#define SCPP_STR(x) SCPP_STR2(x)
+#ifndef SCPP_HIP_EMU
+static_assert(IPM_WAVES_PER_SIMD <= 2 && DISC_WAVES_PER_SIMD <= 2,
+              "three waves per SIMD (168 VGPRs) gave wrong results / memory faults on hardware with this toolchain (SGPR spills to VGPR "
+              "lanes, DESIGN.md 4.2) and were slower: the occupancy-3 variants are not built");
+#if defined(__clang_major__) && __clang_major__ == SCPP_VALIDATED_CLANG_MAJOR && HIP_VERSION_MAJOR == SCPP_VALIDATED_HIP_MAJOR &&         \
+    HIP_VERSION_MINOR == SCPP_VALIDATED_HIP_MINOR
+#define SCPP_TOOLCHAIN_VALIDATED 1
+#define SCPP_TOOLCHAIN_NOTE "validated toolchain"
+#else
+#define SCPP_TOOLCHAIN_VALIDATED 0
+#define SCPP_TOOLCHAIN_NOTE "UNVALIDATED toolchain: run pytest -m gpu before trusting results"
+#endif
+#endif
+
 const char *scpp_hip_version(void)
 {
 #ifdef SCPP_HIP_EMU
-    return "scpp_hip 0.1 (CPU emulation build: TEST ONLY)";
+    return "scpp_hip 0.3 (CPU emulation build: TEST ONLY)";
 #else
-    return "scpp_hip 0.1 (gfx950)";
+    return "scpp_hip 0.3 (gfx950; clang " __clang_version__ "; HIP " SCPP_STR(HIP_VERSION_MAJOR) "." SCPP_STR(HIP_VERSION_MINOR) "." SCPP_STR(
+        HIP_VERSION_PATCH) "; ipm_kernel " SCPP_STR(IPM_WAVES_PER_SIMD) " waves/SIMD, discretize_kernel " SCPP_STR(DISC_WAVES_PER_SIMD) " waves/SIMD; " SCPP_TOOLCHAIN_NOTE ")";
 #endif
 }
 
@@ -381,6 +406,16 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
         return SCPP_E_ARG;
     if (model_id != SCPP_MODEL_ROCKETQUAT && model_id != SCPP_MODEL_ROCKET2D)
         return SCPP_E_ARG;
+#if !defined(SCPP_HIP_EMU) && !SCPP_TOOLCHAIN_VALIDATED
+    {
+        static bool warned = false;
+        if (!warned)
+        {
+            warned = true;
+            std::fprintf(stderr, "scpp_hip: built with an unvalidated toolchain (%s); run `pytest -m gpu` before trusting results\n", scpp_hip_version());
+        }
+    }
+#endif
     int prev_device = -1;
     (void)hipGetDevice(&prev_device);
     CHECK_HIP(hipSetDevice(device_id));
@@ -1066,11 +1101,16 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     // pools: disjoint slot ranges, each on its own stream, all pulling from the one queue.  Their rounds drift apart, so the
     // memory-bound interior-point kernel of one pool overlaps the ALU/LDS-bound discretisation of another without any of
     // the explicit skewing scpp_hip_sc_solve needs.
-    int P = pools > 0 ? pools : 2;
+    // pools == 0 (and no SCPP_STREAM_POOLS): heuristic -- two pools once each of them still fills the chip (>= 2048 slots
+    // = 2048 resident wavefronts), one below that.  An explicit request (argument or environment) is honoured as given and
+    // only clamped to the slot count (a pool has at least one slot) and to 8.
+    int P = pools;
     if (const char *e = std::getenv("SCPP_STREAM_POOLS"))
         P = std::atoi(e) > 0 ? std::atoi(e) : P;
-    if (S < 2048 * P)
+    if (P <= 0)
         P = S >= 4096 ? 2 : 1;
+    if (P > S)
+        P = S;
     if (P > 8)
         P = 8;
     if (int rc = ensurePoll(c))
@@ -1079,7 +1119,8 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
         return rc;
     std::vector<Range> pool;
     {
-        const int per = ((S + P - 1) / P + 7) & ~7; // keep the XCD groups of 8 instances intact
+        // keep the XCD groups of 8 instances intact (a performance nicety: tiny jobs split evenly instead)
+        const int per = S >= 16 * P ? (((S + P - 1) / P + 7) & ~7) : (S + P - 1) / P;
         int first = 0;
         for (int p = 0; p < P && first < S; p++)
         {
@@ -1108,6 +1149,17 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     bool pending = false;
     volatile int *h_done = c->h_poll;
     long round = 0;
+    // every failure exit: wait for whatever is still in flight on the pool streams (later calls on the context must not race
+    // with it) and invalidate the result rows, so that stream_download / stream_rows report SCPP_E_STATE instead of stale rows
+    auto fail = [&](int rc) {
+        for (int p = 0; p < P; p++)
+            (void)hipStreamSynchronize(pool[size_t(p)].stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->q_N = 0;
+        c->stream_rounds = round;
+        c->stream_pools = P;
+        return rc;
+    };
     for (; round < max_rounds; round++)
     {
         for (int p = 0; p < P; p++)
@@ -1119,9 +1171,8 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
             qp.slot_inst = c->q_slot_inst + r.first;
             qp.warm = c->ipm_warm + r.first;
             hipLaunchKernelGGL(scvx_stream_refill_kernel, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, qp, *mp, sc, *so);
-            int rc = scvxRound(c, r);
-            if (rc)
-                return rc;
+            if (int rc = scvxRound(c, r))
+                return fail(rc);
         }
         if (round % POLL == POLL - 1)
         {
@@ -1130,7 +1181,8 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
                 int done = 0;
                 for (int p = 0; p < P; p++)
                 {
-                    CHECK_HIP(hipEventSynchronize(c->pool_events[size_t(p)]));
+                    if (hipEventSynchronize(c->pool_events[size_t(p)]) != hipSuccess)
+                        return fail(SCPP_E_HIP);
                     done = h_done[p] > done ? h_done[p] : done;
                 }
                 if (done >= N)
@@ -1138,8 +1190,9 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
             }
             for (int p = 0; p < P; p++)
             {
-                CHECK_HIP(hipMemcpyAsync(c->h_poll + p, c->q_counters + 1, sizeof(int), hipMemcpyDeviceToHost, pool[size_t(p)].stream));
-                CHECK_HIP(hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream));
+                if (hipMemcpyAsync(c->h_poll + p, c->q_counters + 1, sizeof(int), hipMemcpyDeviceToHost, pool[size_t(p)].stream) != hipSuccess ||
+                    hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream) != hipSuccess)
+                    return fail(SCPP_E_HIP);
             }
             pending = true;
         }
@@ -1148,16 +1201,20 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     c->stream_pools = P;
     for (int p = 1; p < P; p++)
     {
-        CHECK_HIP(hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream));
-        CHECK_HIP(hipStreamWaitEvent(c->stream, c->pool_events[size_t(p)], 0));
+        if (hipEventRecord(c->pool_events[size_t(p)], pool[size_t(p)].stream) != hipSuccess ||
+            hipStreamWaitEvent(c->stream, c->pool_events[size_t(p)], 0) != hipSuccess)
+            return fail(SCPP_E_HIP);
     }
     int counters[4] = {0, 0, 0, 0};
-    CHECK_HIP(hipMemcpyAsync(counters, c->q_counters, sizeof counters, hipMemcpyDeviceToHost, c->stream));
-    CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (hipMemcpyAsync(counters, c->q_counters, sizeof counters, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return fail(SCPP_E_HIP);
     c->last_active = 0;
     if (n_converged)
         *n_converged = counters[2];
-    return counters[1] == N ? SCPP_OK : SCPP_E_STATE; // round cap hit with instances still running: cannot happen with finite max_iterations
+    if (counters[1] != N) // round cap hit with instances still running: cannot happen with finite max_iterations
+        return fail(SCPP_E_STATE);
+    return SCPP_OK;
 }
 
 int scpp_hip_stream_rows(scpp_hip_ctx *c, void **rows, int *row_doubles, int *n)

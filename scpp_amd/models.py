@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from ._lib import MODEL_ROCKET2D, MODEL_ROCKETQUAT, Rocket2dParams, RocketQuatParams
+from ._lib import MODEL_ROCKET2D, MODEL_ROCKETQUAT, Rocket2dParams, RocketQuatParams, ScppHipError
 from .parameter_server import ParameterServer
 
 CONFIG_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
@@ -130,7 +130,12 @@ class Rocket2D:
         return self.p.x_init
 
     def sc_params(self):
-        """scpp_rocket2d_params for scpp_hip_sc_setup_rocket2d"""
+        """scpp_rocket2d_params for scpp_hip_sc_setup_rocket2d.  The device problem always carries the x_init / x_final /
+        U(0, K-1) = 0 equalities (rocket2d.cpp:54-59 with constrain_initial_final true, the SC configuration of model.info:55-56);
+        a model with the flag off would silently get a different problem, so it is refused (like host/rocket_2d.hpp: scSetup)."""
+        if not self.p.constrain_initial_final:
+            raise ScppHipError("Rocket2D: constrain_initial_final must be enabled for SC / SCvx (model.info: 'enable for SC and "
+                               "disable for MPC/LQR'); the device sub-problem has the initial / final equalities built in")
         p, q = self.p, Rocket2dParams()
         q.g_I[:] = p.g_I
         q.r_T_B[:] = p.r_T_B

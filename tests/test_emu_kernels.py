@@ -125,6 +125,7 @@ def test_emu_scvx_stream_equals_batch(model, emu_lib):
         n = alg.solveStream(x0, slots=slots, pools=pools)
         o = alg.getStreamSolution()
         assert n == nref
+        assert alg.ctx.stream_rounds()["pools"] == pools  # an explicit pool count is honoured
         assert (o["instance"] == np.arange(N)).all()
         for key in ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",
                     "ipm_iters"):

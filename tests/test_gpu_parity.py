@@ -311,14 +311,37 @@ def test_scvx_stream_equals_batch_on_gpu(model, hip_lib):
     r = ref.getSolution()
     ref.ctx.close()
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=512, library=hip_lib).initialize()
-    for slots, pools in ((512, 2), (300, 1)):
+    for slots, pools in ((512, 2), (300, 1), (96, 3)):
         n = alg.solveStream(x0, slots=slots, pools=pools)
         o = alg.getStreamSolution()
         assert n == nref and n >= 0.95 * N  # the shipped scenario converges in SCvx mode
+        assert alg.ctx.stream_rounds()["pools"] == pools  # explicit pool counts are honoured, concurrent refills included
         assert (o["instance"] == np.arange(N)).all()
         for key in ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",
                     "ipm_iters"):
             assert np.array_equal(o[key], r[key]), (slots, pools, key)
+    alg.ctx.close()
+
+
+def test_scvx_stream_default_pools_at_bench_size_on_gpu(model, hip_lib):
+    """The configuration bench.py times: >= 4096 resident slots, pools = 0 -> the library's default of two pools on two HIP
+    streams whose refill kernels share the queue head / done / converged atomics.  4608 instances through 4096 slots must give,
+    bitwise, what the batch entry point computes (the first 512 and the last 64 are compared; every row is checked for order,
+    status and the converged count)."""
+    K, N, S = 50, 4608, 4096
+    x0 = model.randomized_initial_states(N, first=40_000)
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=hip_lib).initialize()
+    n = alg.solveStream(x0, slots=S, pools=0)
+    o = alg.getStreamSolution()
+    assert alg.ctx.stream_rounds()["pools"] == 2
+    assert (o["instance"] == np.arange(N)).all() and (o["status"] == 0).all()
+    assert n == int(o["converged"].sum()) and n >= 0.95 * N
+    for lo, hi in ((0, 512), (N - 64, N)):
+        nb = alg.solve(x0[lo:hi])
+        r = alg.getSolution()
+        assert nb == int(o["converged"][lo:hi].sum())
+        for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+            assert np.array_equal(o[key][lo:hi], r[key]), (lo, key)
     alg.ctx.close()
 
 
