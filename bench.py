@@ -82,12 +82,18 @@ def cpu_baseline(K, seed, seconds_budget=12.0):
     """The oracle (CPU restatement of SCpp's algorithm, g++ -O2 -- NOT ECOS: the reference cannot be built)
     on the GPU box's host cores, same workload as the headline: converged SCvx trajectories/s."""
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = cores
+    threads = max(1, min(usable, 32))
     tw = _scvx_cpu(K, seed, 1, seconds_budget, threads)
     out = {
         "value": tw["converged"] / tw["dt"],
         "unit": "converged SCvx trajectories/s",
         "cores": threads,
+        "host_logical_cpus": cores,       # os.cpu_count() of the GPU box
+        "host_usable_cpus": usable,       # sched_getaffinity: what this process may run on
         "kind": "port",
         "single_thread_latency_s": tw["latency"],
         "sample": f"{tw['n']} RocketQuat K={K} SCvx instances (seed {seed}, instances 0..{tw['n'] - 1}), oracle structured-IPM twin "
@@ -140,6 +146,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of this script)")
     ap.add_argument("--library", default=None, help="path of the C-ABI library (tests pass the CPU emulation build)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered result rows to this .npy (tests)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the multi-GPU result path (zero-copy view of the library's rows -> torch staging tensor -> "
+                         "all_gather_into_tensor, in chunks) inside the timed region even with ONE rank: a world-1 process group "
+                         "of --backend is created, so a 1-GPU box executes the RCCL branch")
+    ap.add_argument("--gather-chunk-mb", type=float, default=64.0, help="largest per-rank payload of one all-gather (MB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (SC mode, single batch, single pool, MPC)")
     ap.add_argument("--mpc-batch", type=int, default=32768)
@@ -153,10 +164,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = args.backend != "gloo"
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if on_gpu:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
@@ -173,7 +186,7 @@ def main():
     rowd = K * 18 + len(ctx.STREAM_SCALARS)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
@@ -188,22 +201,37 @@ def main():
         nconv = alg.solveStream(x0, slots=B, pools=args.pools)
         n = x0.shape[0]
         gathered = None
-        if world > 1:
+        if use_dist:
             ptr, rd, nrows = ctx.stream_rows_device()
             assert rd == rowd and nrows == n
             if on_gpu:
-                # the library's result rows live in hipMalloc'ed memory torch's allocator does not own: stage them through a
-                # torch tensor (one device-to-device copy of 7.3 KB per instance, noise next to the solve)
+                # zero-copy view of the library's result rows (hipMalloc'ed memory torch's allocator does not own)
                 src = torch.as_tensor(_DevArray(ptr, (n, rowd)), device=dev)
-                mine = torch.empty((n, rowd), dtype=torch.float64, device=dev)
-                mine.copy_(src)
             else:
-                mine = torch.from_numpy(ctx.stream_download_rows())
+                src = torch.from_numpy(ctx.stream_download_rows())
+            # One collective per chunk of <= --gather-chunk-mb per rank: the receive buffer of a collective is world x chunk
+            # (512 MB on 8 GPUs at the default) instead of the whole job at once, and the staging copy of chunk i+1 (torch's
+            # stream) is independent of the collective of chunk i.  Every rank holds the same n, so the chunking is identical
+            # everywhere.  Rank r's rows of chunk c land at gathered[r * n + lo : r * n + hi].
+            rows_per = max(1, int(args.gather_chunk_mb * 1e6) // (rowd * 8))
             gathered = torch.empty((world * n, rowd), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(gathered, mine)
+            gview = gathered.view(world, n, rowd)
+            n_coll = 0
+            for lo in range(0, n, rows_per):
+                hi = min(n, lo + rows_per)
+                mine = torch.empty((hi - lo, rowd), dtype=torch.float64, device=dev)  # torch-owned staging tensor
+                mine.copy_(src[lo:hi])
+                recv = torch.empty((world * (hi - lo), rowd), dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(recv, mine)
+                gview[:, lo:hi, :] = recv.view(world, hi - lo, rowd)
+                n_coll += 1
+            gather_stats["collectives"] = n_coll
+            gather_stats["rows_per_collective"] = rows_per
+            gather_stats["bytes_per_rank_per_collective"] = min(n, rows_per) * rowd * 8
         out = ctx.stream_download()  # D2H of this rank's rows: getSolution is part of the path's contract
         return nconv, out, gathered
 
+    gather_stats = {}
     x_warm = states(0, args.warmup) if args.warmup > 0 else None
     x_timed = states(args.warmup, args.steps)  # host-side generation outside the timed region
     if x_warm is not None:
@@ -222,6 +250,13 @@ def main():
                       int((out["status"] != 0).sum())], dtype=np.float64)
     assert (out["instance"] == np.arange(total)).all(), "result rows out of order"
     assert int(out["converged"].sum()) == nconv
+    if use_dist:
+        # the gathered rows of this rank are, bitwise, the rows the library holds (the zero-copy view, the staging copy and the
+        # collective moved bytes, nothing else)
+        local_rows = ctx.stream_download_rows()
+        mine_back = gathered.view(world, total, rowd)[rank].cpu().numpy()
+        assert np.array_equal(mine_back.view(np.uint64), local_rows.view(np.uint64)), "gathered rows differ from the library's rows"
+        gather_stats["gathered_equals_local_bitwise"] = True
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,7 +272,7 @@ def main():
     else:
         g_conv, g_total, g_iters, g_solves, g_ipm, g_fail = [float(v) for v in local]
         if args.dump:
-            np.save(args.dump, ctx.stream_download_rows())
+            np.save(args.dump, gathered.cpu().numpy() if gathered is not None else ctx.stream_download_rows())
 
     extras = {}
     if rank == 0 and not args.no_extras:
@@ -338,20 +373,33 @@ def main():
         # the per-launch duration is an upper bound of the kernel's own time; `single_pool` has the un-overlapped figure.
         ipm_iters0 = float(out["ipm_iters"].sum())
         socp_flops = ipm_iters0 * FLOP_PER_IPM_ITER + total * FLOP_PER_SOCP_INIT
-        socp_s = tm["ms_socp"] * 1e-3
-        achieved_tf = socp_flops / socp_s / 1e12 if socp_s > 0 else 0.0
         launches = max(tm["n_socp"], 1)
+        # kernel time = length of the UNION of the launches' hipEvent spans on a common time axis (launches of the two slot pools
+        # overlap in time: the plain sum of spans exceeds the wall clock).  By construction <= the timed region; asserted.
+        span_sum_s = tm["ms_socp"] * 1e-3
+        socp_s = tm.get("ms_socp_union", 0.0) * 1e-3 or span_sum_s
+        assert socp_s <= dt * 1.001, f"ipm_kernel time {socp_s:.3f} s exceeds the timed region {dt:.3f} s"
+        achieved_tf = socp_flops / socp_s / 1e12 if socp_s > 0 else 0.0
+        achieved_tf_span_sum = socp_flops / span_sum_s / 1e12 if span_sum_s > 0 else 0.0
         pmc = measured_traffic()
         traffic = None
+        traffic_source = None
         traffic_note = "no profiles/r*_pmc_hbm_*.json summary found: traffic unmeasured"
         if pmc is not None:
             f, d = pmc
             traffic = d["ipm_bytes_per_instance_iteration"] * ipm_iters0 / launches
-            traffic_note = (f"{os.path.relpath(f, ROOT)}: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE (separate passes) of ipm_kernel = "
-                            f"{d['ipm_bytes_per_instance_iteration']:.3e} B per instance-IPM-iteration (commit {d.get('commit', '?')}, "
-                            f"{d.get('calibration', 'uncalibrated')}), scaled by this run's iterations per launch; algorithmic minimum "
-                            f"(read dd + td, write X, U) = {IPM_ALGO_BYTES_PER_SOLVE} B per instance-solve")
-        disc_s = tm["ms_discretize"] * 1e-3
+            traffic_source = {"imported_from": os.path.relpath(f, ROOT), "commit_of_that_profile": d.get("commit", "?"),
+                              "measured_in_this_run": False}
+            traffic_note = (f"IMPORTED, not measured in this run: {os.path.relpath(f, ROOT)} (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate "
+                            f"passes, of ipm_kernel at commit {d.get('commit', '?')}, {d.get('calibration', 'uncalibrated')}) = "
+                            f"{d['ipm_bytes_per_instance_iteration']:.3e} B per instance-IPM-iteration, scaled by this run's iterations "
+                            f"per launch; algorithmic minimum (read dd + td, write X, U) = {IPM_ALGO_BYTES_PER_SOLVE} B per instance-solve")
+        measured_gbs = (traffic * launches / socp_s / 1e9) if (traffic is not None and socp_s > 0) else None
+        mfma_frac = achieved_tf / PEAK_FP64_TFLOPS
+        hbm_frac = measured_gbs / PEAK_HBM_GBS if measured_gbs is not None else None
+        limiting = ("hbm traffic of the workspace (measured bytes): %.0f GB/s = %.1f %% of peak, against %.1f %% of the FP64 matrix peak"
+                    % (measured_gbs, 100 * hbm_frac, 100 * mfma_frac)) if (hbm_frac is not None and hbm_frac > mfma_frac) else "fp64 mfma"
+        disc_s = tm.get("ms_discretize_union", 0.0) * 1e-3 or tm["ms_discretize"] * 1e-3
         # discretize launches are masked (needs_disc): instances that re-solve after a rejection skip it, so count solves
         line = {
             "metric": "converged SCvx trajectories/sec (RocketQuat, K=50) at 1/2/4/8 MI355X",
@@ -374,8 +422,9 @@ def main():
                 "engine": f"scpp_hip_scvx_solve_stream: continuous batching over {B} resident slots per GPU, steps x batch instances queued",
                 "global_batch": int(B * world),
                 "instances_timed": int(g_total),
-                "parallelism": (f"instance-sharded x{world}, no collective in the loop, one {args.backend} all-gather of the result rows "
-                                f"({rowd * 8} B per instance)") if world > 1 else "single GPU",
+                "parallelism": (f"instance-sharded x{world}, no collective in the loop, {args.backend} all-gather of the result rows "
+                                f"({rowd * 8} B per instance) in chunks of <= {args.gather_chunk_mb:g} MB per rank") if use_dist else "single GPU",
+                "gather": gather_stats if use_dist else None,
                 "converged_fraction": g_conv / g_total if g_total else 0.0,
                 "terminated_trajectories_per_s": g_total / dt,
                 "mean_scvx_iterations": g_iters / g_total if g_total else 0.0,
@@ -389,21 +438,29 @@ def main():
             },
             "roofline": {
                 "kernel": "ipm_kernel (batched structured IPM, one wavefront per instance, block factorisations on v_mfma_f64_16x16x4_f64)",
-                "bound": "mfma",
+                "bound": "mfma",  # the roof north_star prices the KKT factorisation against; see limiting_resource
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP64_TFLOPS,
+                "frac": mfma_frac,
+                "limiting_resource": limiting,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "traffic_note": traffic_note,
-                "avg_launch_ms": tm["ms_socp"] / launches,
+                "kernel_time_s": socp_s,
+                "kernel_time_definition": "union of the launches' hipEvent spans (exclusive wall time with >= 1 ipm_kernel in flight)",
+                "timed_region_s": dt,
+                "exclusive_ms_per_launch": 1e3 * socp_s / launches,
+                "avg_launch_ms": tm["ms_socp"] / launches,  # average hipEvent span of one launch = what rocprofv3 --stats averages
+                "frac_of_span_sum": achieved_tf_span_sum / PEAK_FP64_TFLOPS,
                 "launches": tm["n_socp"],
                 "flop_model": f"{FLOP_PER_IPM_ITER:.2e} flop per IPM iteration x {ipm_iters0:.0f} measured IPM iterations + "
                               f"{FLOP_PER_SOCP_INIT:.2e} per cold start x {total} instances (rank 0)",
                 "hbm_view": {
                     "algorithmic_bytes_per_launch": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / launches,
                     "algorithmic_GBs": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / socp_s / 1e9 if socp_s > 0 else None,
-                    "measured_GBs": (traffic * launches / socp_s / 1e9) if (traffic is not None and socp_s > 0) else None,
+                    "measured_GBs": measured_gbs,
+                    "measured_frac": hbm_frac,
                     "peak_GBs": PEAK_HBM_GBS,
                 },
             },
@@ -413,8 +470,10 @@ def main():
                     "avg_launch_ms": tm["ms_discretize"] / max(tm["n_discretize"], 1),
                     "launches": tm["n_discretize"],
                     "instance_calls": g_iters / world,
-                    "fp64_TFLOPs_of_span_time": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 if disc_s > 0 else None,
-                    "hbm_GBs_of_span_time": (g_iters / world) * DISC_BYTES_PER_INSTANCE / disc_s / 1e9 if disc_s > 0 else None,
+                    "kernel_time_s": disc_s,
+                    "fp64_TFLOPs": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 if disc_s > 0 else None,
+                    "fp64_frac": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 / PEAK_FP64_TFLOPS if disc_s > 0 else None,
+                    "hbm_GBs": (g_iters / world) * DISC_BYTES_PER_INSTANCE / disc_s / 1e9 if disc_s > 0 else None,
                     "bound": "fp64-alu (450 flop/B: HBM is not the binding roof, SURVEY §8(d))",
                 },
             },
@@ -425,7 +484,7 @@ def main():
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 line["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -132,6 +132,10 @@ extern "C"
         double ms_discretize, ms_socp, ms_other;
         long long n_discretize, n_socp;          /* kernel launches */
         long long inst_discretize, inst_socp;    /* sum over launches of ACTIVE instances processed */
+        /* launches of different slot pools (streams) overlap in time, so ms_socp / ms_discretize (sums of spans) can exceed
+           the wall clock; *_union is the length of the UNION of the spans on a common time axis since the last reset: the
+           time with at least one launch of the family in flight (<= wall clock by construction) */
+        double ms_discretize_union, ms_socp_union;
     } scpp_timing;
 
     int scpp_hip_create(scpp_hip_ctx **ctx, int device_id, int model_id, int K, int batch_max, unsigned flags);

@@ -106,6 +106,8 @@ class Timing(C.Structure):
         ("n_socp", C.c_longlong),
         ("inst_discretize", C.c_longlong),
         ("inst_socp", C.c_longlong),
+        ("ms_discretize_union", C.c_double),
+        ("ms_socp_union", C.c_double),
     ]
 
 

@@ -2,7 +2,9 @@
 // -DSCPP_HIP_EMU, by g++ against tests/emu/hip_emu.h (CPU-side kernel unit tests only).
 #include "../../include/scpp_hip.h"
 
+#include <algorithm>
 #include <cmath>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +85,7 @@ struct scpp_hip_ctx
     std::vector<Span> spans;
     std::vector<hipEvent_t> pool;
     scpp_timing timing{};
+    hipEvent_t ev_base = nullptr; // time origin of the span intervals (recorded at the last timing reset)
     int last_active = 0;
     long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
     int stream_pools = 0;
@@ -168,14 +171,40 @@ struct Range
     hipStream_t stream;
 };
 Range fullRange(scpp_hip_ctx *c) { return Range{0, c->B, c->stream}; }
+// length of the union of [t0, t1) intervals (ms): the time during which at least one launch of a kernel family was in flight
+double unionLength(std::vector<std::pair<double, double>> &iv)
+{
+    std::sort(iv.begin(), iv.end());
+    double total = 0., lo = 0., hi = -1.;
+    for (const auto &x : iv)
+    {
+        if (hi < lo || x.first > hi)
+        {
+            if (hi >= lo)
+                total += hi - lo;
+            lo = x.first;
+            hi = x.second;
+        }
+        else if (x.second > hi)
+            hi = x.second;
+    }
+    if (hi >= lo)
+        total += hi - lo;
+    return total;
+}
 void collectTiming(scpp_hip_ctx *c)
 {
     (void)hipStreamSynchronize(c->stream);
+    // Launches of different slot pools run on different streams and overlap in time: the SUM of their spans (ms_socp) can
+    // exceed the wall clock.  ms_*_union is the length of the union of the spans on a common time axis (origin: ev_base) --
+    // the time the GPU spent with at least one launch of that family in flight, which is what a rate may be divided by.
+    std::vector<std::pair<double, double>> iv[2];
     for (auto &s : c->spans)
     {
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         (void)hipEventSynchronize(s.b);
         (void)hipEventElapsedTime(&ms, s.a, s.b);
+        const bool based = c->ev_base && hipEventElapsedTime(&t0, c->ev_base, s.a) == hipSuccess;
         if (s.kind == 0)
         {
             c->timing.ms_discretize += ms;
@@ -190,9 +219,18 @@ void collectTiming(scpp_hip_ctx *c)
         }
         else
             c->timing.ms_other += ms;
+        if (s.kind == 0 || s.kind == 1)
+        {
+            if (based)
+                iv[s.kind].emplace_back(double(t0), double(t0) + double(ms));
+            else
+                (s.kind == 0 ? c->timing.ms_discretize_union : c->timing.ms_socp_union) += ms; // no common axis: spans as they are
+        }
         c->pool.push_back(s.a);
         c->pool.push_back(s.b);
     }
+    c->timing.ms_discretize_union += unionLength(iv[0]);
+    c->timing.ms_socp_union += unionLength(iv[1]);
     c->spans.clear();
 }
 
@@ -529,6 +567,8 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
     }
     for (auto e : c->pool)
         (void)hipEventDestroy(e);
+    if (c->ev_base)
+        (void)hipEventDestroy(c->ev_base);
     if (c->ev_skew)
         (void)hipEventDestroy(c->ev_skew);
     if (c->ev_join)
@@ -1560,7 +1600,17 @@ int scpp_hip_get_timing(scpp_hip_ctx *c, scpp_timing *out, int reset)
     if (out)
         *out = c->timing;
     if (reset)
+    {
         c->timing = scpp_timing{};
+        // new time origin for the span intervals (all streams of the context are idle here: collectTiming waited for them)
+        if (!c->ev_base && hipEventCreate(&c->ev_base) != hipSuccess)
+            c->ev_base = nullptr;
+        if (c->ev_base)
+        {
+            (void)hipEventRecord(c->ev_base, c->stream);
+            (void)hipEventSynchronize(c->ev_base);
+        }
+    }
     return SCPP_OK;
 }
 

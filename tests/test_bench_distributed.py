@@ -20,11 +20,17 @@ def test_bench_world2_gloo_matches_single_process(model, emu_lib, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
            "--backend", "gloo", "--library", emu_lib, "--K", str(K), "--batch", str(B), "--max-iterations", str(maxit),
-           "--no-cpu-baseline", "--no-extras", "--dump", dump]
+           "--no-cpu-baseline", "--no-extras", "--dump", dump,
+           "--gather-chunk-mb", "0.0025"]  # 2.5 kB (two rows) per rank and collective: the 6 rows of a rank travel in 3 all-gathers
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warm
+    g = line["config"]["gather"]
+    assert g["collectives"] == 3 and g["rows_per_collective"] == 2 and g["gathered_equals_local_bitwise"] is True
+    assert g["bytes_per_rank_per_collective"] <= 2500
+    r_ = line["roofline"]
+    assert r_["kernel_time_s"] <= r_["timed_region_s"] * 1.001  # union of the launch spans, not their sum
     assert line["config"]["instances_timed"] == 2 * steps * B
     rows = np.load(dump)
     assert rows.shape == (2 * steps * B, K * 18 + 10)
@@ -47,3 +53,29 @@ def test_bench_world2_gloo_matches_single_process(model, emu_lib, tmp_path):
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * steps - conv) < 1e-6 * max(conv, 1) + 1e-9
     # full payload of SURVEY 8(e): X, U, sigma, ||nu||_1, iterations, status all travel in the row
     assert (got["instance"].reshape(world, steps * B) == np.arange(steps * B)[None, :]).all()
+
+
+def test_bench_force_gather_single_rank(model, emu_lib, tmp_path):
+    """--force-gather: ONE process creates a world-1 process group and runs the whole multi-GPU result path (view of the
+    library's rows -> staging tensor -> chunked all_gather_into_tensor) inside the timed region; the dumped gathered rows are,
+    bitwise, the rows of the plain single-process run.  (On the GPU box the same flag executes the RCCL branch:
+    tests/test_gpu_parity.py::test_bench_force_gather_runs_rccl_on_one_gpu.)"""
+    K, B, steps, maxit = 8, 3, 2, 4
+    outs = []
+    for extra, name in ((["--force-gather", "--gather-chunk-mb", "0.0025"], "g.npy"), ([], "p.npy")):
+        dump = str(tmp_path / name)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "0", "--backend", "gloo",
+               "--library", emu_lib, "--K", str(K), "--batch", str(B), "--max-iterations", str(maxit), "--no-cpu-baseline",
+               "--no-extras", "--dump", dump] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        outs.append((line, np.load(dump)))
+    (lg, rg), (lp, rp) = outs
+    assert lg["config"]["gather"]["collectives"] == 3 and lg["config"]["gather"]["gathered_equals_local_bitwise"] is True
+    assert lp["config"]["gather"] is None and lp["n_gpus"] == lg["n_gpus"] == 1
+    assert rg.shape == rp.shape == (steps * B, K * 18 + 10)
+    assert np.array_equal(rg.view(np.uint64), rp.view(np.uint64))

@@ -474,3 +474,36 @@ def test_sc_sim_monte_carlo_4096_loops_properties(model, hip_lib):
     for b in range(0, h, 97):
         assert (np.diff(r["X_sim"][b][:, 3]) < 0).all()
     a.ctx.close()
+
+
+def test_bench_force_gather_runs_rccl_on_one_gpu(hip_lib, tmp_path):
+    """bench.py's multi-GPU result path on real hardware with ONE rank: `--force-gather` creates a world-1
+    `nccl` (= RCCL) process group and runs, inside the timed region, torch.as_tensor(__cuda_array_interface__ view of the
+    library's hipMalloc'ed rows) -> torch-owned staging tensor -> all_gather_into_tensor in chunks (0.5 MB here: 8 collectives
+    for 512 rows).  bench.py itself asserts that the gathered rows equal the library's rows bitwise; the dump is compared with
+    a plain run of the same job as well."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    outs = []
+    for extra, name in ((["--force-gather", "--gather-chunk-mb", "0.5"], "g.npy"), ([], "p.npy")):
+        dump = str(tmp_path / name)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29751", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--batch", "256",
+               "--library", hip_lib, "--no-cpu-baseline", "--no-extras", "--dump", dump] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), np.load(dump)))
+    (lg, rg), (lp, rp) = outs
+    g = lg["config"]["gather"]
+    assert g["gathered_equals_local_bitwise"] is True and g["collectives"] == 8 and g["bytes_per_rank_per_collective"] <= 500_000
+    assert "nccl" in lg["config"]["parallelism"] and lp["config"]["gather"] is None
+    assert rg.shape == rp.shape == (512, 50 * 18 + 10)
+    assert np.array_equal(rg.view(np.uint64), rp.view(np.uint64))
+    print("force-gather on one GPU: %d RCCL all-gathers of <= %d B per rank, gathered == local bitwise; %.0f vs %.0f converged/s"
+          % (g["collectives"], g["bytes_per_rank_per_collective"], lg["value"], lp["value"]))
