@@ -274,6 +274,38 @@ int oracle_sc_set_tolerances(void *h, double feastol, double abstol, double relt
         return 0;
     });
 }
+// candidate point in the literal SC sub-problem linearised at (Xbar, Ubar, tbar), trajectories DIMENSIONAL (sc.hpp: checkPoint)
+// out[10]: eq_violation, min_lp_slack, min_cone_slack, cost, norm1_nu, lit_cost, lit_sigma, lit_exitflag, lit_iters, sum_delta
+int oracle_sc_check_point(void *h, const double *Xbar, const double *Ubar, double tbar, double w_trx, const double *Xc, const double *Uc,
+                          double tc, int solve_literal, double *out, double *Xlit, double *Ulit)
+{
+    try
+    {
+        return withAlg(h, [&](auto &a) {
+            const auto r = a.checkPoint(Xbar, Ubar, tbar, w_trx, Xc, Uc, tc, solve_literal != 0);
+            out[0] = r.eq_violation;
+            out[1] = r.min_lp_slack;
+            out[2] = r.min_cone_slack;
+            out[3] = r.cost;
+            out[4] = r.norm1_nu;
+            out[5] = r.lit_cost;
+            out[6] = r.lit_sigma;
+            out[7] = r.lit_exitflag;
+            out[8] = r.lit_iters;
+            out[9] = r.sum_delta;
+            if (Xlit && !r.Xlit.empty())
+                std::memcpy(Xlit, r.Xlit.data(), r.Xlit.size() * sizeof(double));
+            if (Ulit && !r.Ulit.empty())
+                std::memcpy(Ulit, r.Ulit.data(), r.Ulit.size() * sizeof(double));
+            return 0;
+        });
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_sc_check_point: %s\n", e.what());
+        return -2;
+    }
+}
 int oracle_sc_set_solver(void *h, int kind)
 {
     return withAlg(h, [&](auto &a) {
@@ -540,6 +572,16 @@ int oracle_scvx_set_tolerances(void *h, double feastol, double abstol, double re
     a.socp_settings.maxit = maxit;
     return 0;
 }
+// tolerances of the structured twin (defaults: feastol 1e-8, abstol / reltol 1e-7, maxit 60 = the device's)
+int oracle_scvx_set_twin_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
+{
+    auto &a = *static_cast<SCvxHandle *>(h)->alg;
+    a.structured_settings.feastol = feastol;
+    a.structured_settings.abstol = abstol;
+    a.structured_settings.reltol = reltol;
+    a.structured_settings.maxit = maxit;
+    return 0;
+}
 int oracle_scvx_verbose(void *h, int v)
 {
     auto &a = *static_cast<SCvxHandle *>(h)->alg;
@@ -611,6 +653,37 @@ int oracle_scvx_get_iterate(void *h, int idx, double *X, double *U, double *t)
     std::memcpy(U, td->U.data(), td->U.size() * sizeof(double));
     *t = td->t;
     return 0;
+}
+// candidate point in the literal sub-problem linearised at (Xbar, Ubar), all trajectories DIMENSIONAL (scvx.hpp: checkPoint).
+// out[10]: eq_violation, min_lp_slack, min_cone_slack, cost, norm1_nu, lit_cost, lit_norm1_nu, lit_exitflag, lit_iters, n
+int oracle_scvx_check_point(void *h, const double *Xbar, const double *Ubar, double radius, const double *Xc, const double *Uc,
+                            int solve_literal, double *out, double *Xlit, double *Ulit, int bar_nondim, int cand_nondim)
+{
+    try
+    {
+        auto &a = *static_cast<SCvxHandle *>(h)->alg;
+        const auto r = a.checkPoint(Xbar, Ubar, radius, Xc, Uc, solve_literal != 0, bar_nondim != 0, cand_nondim != 0);
+        out[0] = r.eq_violation;
+        out[1] = r.min_lp_slack;
+        out[2] = r.min_cone_slack;
+        out[3] = r.cost;
+        out[4] = r.norm1_nu;
+        out[5] = r.lit_cost;
+        out[6] = r.lit_norm1_nu;
+        out[7] = r.lit_exitflag;
+        out[8] = r.lit_iters;
+        out[9] = 0.;
+        if (Xlit && !r.Xlit.empty())
+            std::memcpy(Xlit, r.Xlit.data(), r.Xlit.size() * sizeof(double));
+        if (Ulit && !r.Ulit.empty())
+            std::memcpy(Ulit, r.Ulit.data(), r.Ulit.size() * sizeof(double));
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "oracle_scvx_check_point: %s\n", e.what());
+        return -2;
+    }
 }
 // per-solve rows: [norm1_nu, nonlinear_cost, actual_change, predicted_change, rho, trust_region(after), accepted, ipm_iters, exitflag]
 int oracle_scvx_get_info(void *h, double *rows, int max_rows)

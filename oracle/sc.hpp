@@ -8,6 +8,8 @@
 // Parity status: UNPINNED (the reference cannot be built or run here and ships no outputs); trajectory initialisation,
 // weight doubling and convergence logic are tested against the statements of the reference source they restate.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <functional>
 #include <type_traits>
@@ -372,6 +374,153 @@ class SCAlgorithm
             model->getNewModelParameters(td);
             model->redimensionalizeTrajectory(td);
         }
+    }
+
+    // ---- test support: one candidate point in the LITERAL (reference-shaped) SC sub-problem (cf. scvx.hpp: checkPoint) ----
+    // Problem: buildSCProblem + addApplicationConstraints linearised at the DIMENSIONAL trajectory (Xbar, Ubar, tbar) with the
+    // given trust-region weight (SCAlgorithm doubles it along the run, SCAlgorithm.cpp:112-115; <= 0: the configured one) for
+    // the model's current x_init, thrust_const as a cold solve() sets it.  Candidate (Xc, Uc, tc), dimensional: nu := dynamics
+    // defect, nu_bound := |nu|, norm1_nu := sum, delta_k := ||(x - xbar; u - ubar)||, delta_sigma := (sigma - sigmabar)^2 -- the
+    // cheapest completion -- then every row of the literal standard form is evaluated.
+    struct PointCheck
+    {
+        double eq_violation = 0., min_lp_slack = 0., min_cone_slack = 0., cost = 0., norm1_nu = 0., sum_delta = 0.;
+        double lit_cost = 0., lit_sigma = 0.;
+        int lit_exitflag = -99, lit_iters = 0;
+        std::vector<double> Xlit, Ulit;
+    };
+    PointCheck checkPoint(const double *Xbar, const double *Ubar, double tbar, double w_trx, const double *Xc, const double *Uc, double tc,
+                          bool solve_literal)
+    {
+        constexpr int NX = Model::NX, NU = Model::NU;
+        PointCheck out;
+        loadParameters();
+        if (w_trx > 0.)
+            weight_trust_region_trajectory = w_trx;
+        if (nondimensionalize)
+            model->nondimensionalize();
+        {
+            TrajectoryData init;
+            init.initialize(NX, NU, int(K), interpolate_input);
+            model->getInitializedTrajectory(init);
+            model->getNewModelParameters(init);
+        }
+        td.X.assign(Xbar, Xbar + size_t(td.K) * NX);
+        td.U.assign(Ubar, Ubar + size_t(td.nU) * NU);
+        td.t = tbar;
+        TrajectoryData cand = td;
+        cand.X.assign(Xc, Xc + size_t(td.K) * NX);
+        cand.U.assign(Uc, Uc + size_t(td.nU) * NU);
+        cand.t = tc;
+        if (nondimensionalize)
+        {
+            model->nondimensionalizeTrajectory(td);
+            model->nondimensionalizeTrajectory(cand);
+        }
+        multipleShooting(*model, td, dd);
+        SCVarIndex ix;
+        Socp socp = buildSCProblem<Model>(weight_time, weight_trust_region_time, weight_trust_region_trajectory, weight_virtual_control, td, dd, ix);
+        SCKeys key;
+        model->addApplicationConstraints(
+            socp, td.K, td.nU, [&](int i, int k) { return ix.vX(i, k); }, [&](int i, int k) { return ix.vU(i, k); }, key);
+        std::vector<double> x(size_t(socp.n), 0.);
+        for (int k = 0; k < td.K; k++)
+            for (int i = 0; i < NX; i++)
+                x[size_t(ix.vX(i, k))] = cand.x(k)[i];
+        for (int k = 0; k < td.nU; k++)
+            for (int i = 0; i < NU; i++)
+                x[size_t(ix.vU(i, k))] = cand.u(k)[i];
+        if (ix.sigma >= 0)
+        {
+            x[size_t(ix.sigma)] = cand.t;
+            x[size_t(ix.delta_sigma)] = (cand.t - td.t) * (cand.t - td.t);
+        }
+        double n1 = 0.;
+        for (int k = 0; k + 1 < td.K; k++)
+        {
+            const double *A = &dd.A[size_t(k) * NX * NX], *B = &dd.B[size_t(k) * NX * NU];
+            for (int i = 0; i < NX; i++)
+            {
+                double v = cand.x(k + 1)[i] - dd.z[size_t(k) * NX + i];
+                for (int j = 0; j < NX; j++)
+                    v -= A[i * NX + j] * cand.x(k)[j];
+                for (int j = 0; j < NU; j++)
+                    v -= B[i * NU + j] * cand.u(k)[j];
+                if (dd.interpolatedInput())
+                    for (int j = 0; j < NU; j++)
+                        v -= dd.C[size_t(k) * NX * NU + i * NU + j] * cand.u(k + 1)[j];
+                if (dd.variableTime())
+                    v -= dd.s[size_t(k) * NX + i] * cand.t;
+                x[size_t(ix.vNu(i, k))] = v;
+                x[size_t(ix.vNuB(i, k))] = std::fabs(v);
+                n1 += std::fabs(v);
+            }
+        }
+        x[size_t(ix.norm1_nu)] = n1;
+        out.norm1_nu = n1;
+        for (int k = 0; k < td.K; k++)
+        {
+            double d2 = 0.;
+            for (int i = 0; i < NX; i++)
+                d2 += (td.x(k)[i] - cand.x(k)[i]) * (td.x(k)[i] - cand.x(k)[i]);
+            if (dd.interpolatedInput() || k < td.K - 1)
+                for (int i = 0; i < NU; i++)
+                    d2 += (td.u(k)[i] - cand.u(k)[i]) * (td.u(k)[i] - cand.u(k)[i]);
+            x[size_t(ix.delta + k)] = std::sqrt(d2);
+            out.sum_delta += std::sqrt(d2);
+        }
+        auto rowValue = [&](const SocpRow &r) {
+            double v = 0.;
+            for (auto &t : r.t)
+                v += t.second * x[size_t(t.first)];
+            return v;
+        };
+        for (auto &r : socp.eq)
+            out.eq_violation = std::max(out.eq_violation, std::fabs(rowValue(r) - r.rhs));
+        out.min_lp_slack = 1e300;
+        for (auto &r : socp.lp)
+            out.min_lp_slack = std::min(out.min_lp_slack, r.rhs - rowValue(r));
+        out.min_cone_slack = 1e300;
+        for (auto &cn : socp.soc)
+        {
+            double s0 = cn[0].rhs - rowValue(cn[0]), nn = 0.;
+            for (size_t i = 1; i < cn.size(); i++)
+            {
+                const double si = cn[i].rhs - rowValue(cn[i]);
+                nn += si * si;
+            }
+            out.min_cone_slack = std::min(out.min_cone_slack, s0 - std::sqrt(nn));
+        }
+        for (int j = 0; j < socp.n; j++)
+            out.cost += socp.c[size_t(j)] * x[size_t(j)];
+        if (solve_literal)
+        {
+            SocpSolver solver(socp);
+            solver.opt = socp_settings;
+            SocpResult r = solver.solve();
+            out.lit_exitflag = r.exitflag;
+            out.lit_iters = r.iter;
+            if (r.exitflag == 0 || r.exitflag == 10)
+            {
+                out.lit_cost = r.pcost;
+                TrajectoryData sol = td;
+                for (int k = 0; k < td.K; k++)
+                    for (int i = 0; i < NX; i++)
+                        sol.x(k)[i] = r.x[size_t(ix.vX(i, k))];
+                for (int k = 0; k < td.nU; k++)
+                    for (int i = 0; i < NU; i++)
+                        sol.u(k)[i] = r.x[size_t(ix.vU(i, k))];
+                out.lit_sigma = ix.sigma >= 0 ? r.x[size_t(ix.sigma)] : td.t;
+                if (nondimensionalize)
+                    model->redimensionalizeTrajectory(sol);
+                out.Xlit = sol.X;
+                out.Ulit = sol.U;
+            }
+        }
+        if (nondimensionalize)
+            model->redimensionalize();
+        loadParameters(); // restores the configured trust-region weight
+        return out;
     }
 
     int last_dims[5] = {0, 0, 0, 0, 0};

@@ -6,6 +6,7 @@
 // No executable of the reference calls SCvxAlgorithm; it is compiled into libscpp.so and restated
 // here from its source.  Parity status: unpinned at the ECOS boundary like the SC path.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -378,6 +379,138 @@ class SCvxAlgorithm
             model->getNewModelParameters(td);
             model->redimensionalizeTrajectory(td);
         }
+    }
+
+    // ---- test support: one candidate point in the LITERAL (reference-shaped) sub-problem ----
+    // Builds buildSCvxProblem + addApplicationConstraints (SCvxProblem.cpp:6-71, rocketQuat.cpp:70-144) linearised at the given
+    // DIMENSIONAL trajectory (Xbar, Ubar) with trust radius `radius` for the model's current x_init -- exactly what
+    // SCvxAlgorithm::iterate hands to the solver in a cold solve() -- and evaluates a DIMENSIONAL candidate (Xc, Uc) in it:
+    // nu := the dynamics defect, nu_bound := |nu|, norm1_nu := sum |nu| (the cheapest completion), then every equality, LP row
+    // and second-order cone of the literal standard form.  With solve_literal the same problem is solved by the literal solver.
+    // Used by the parity tests to CHECK the statement "two solvers' inputs differ because the optimum is not unique": both
+    // points feasible in the same literal problem with the same objective.
+    struct PointCheck
+    {
+        double eq_violation = 0.;   // max |Ax - b| over the equality rows (dynamics rows are 0 by construction of nu)
+        double min_lp_slack = 0.;   // min over LP rows of (h - Gx); >= 0 <=> feasible
+        double min_cone_slack = 0.; // min over cones of s0 - ||s1||
+        double cost = 0.;           // c'x = weight_virtual_control * sum |nu|
+        double norm1_nu = 0.;
+        double lit_cost = 0., lit_norm1_nu = 0.;
+        int lit_exitflag = -99, lit_iters = 0;
+        std::vector<double> Xlit, Ulit; // dimensional optimum of the literal solver
+    };
+    // bar_nondim / cand_nondim: that trajectory is already in the solver's nondimensional units (e.g. an entry of all_td)
+    PointCheck checkPoint(const double *Xbar, const double *Ubar, double radius, const double *Xc, const double *Uc, bool solve_literal,
+                          bool bar_nondim = false, bool cand_nondim = false)
+    {
+        constexpr int NX = Model::NX, NU = Model::NU;
+        PointCheck out;
+        loadParameters();
+        if (nondimensionalize)
+            model->nondimensionalize();
+        {
+            // thrust_const of a cold solve(): refreshed once, from the initial trajectory (quirk F9(d), SCvxAlgorithm.cpp:181)
+            TrajectoryData init;
+            init.initialize(NX, NU, int(K), interpolate_input);
+            model->getInitializedTrajectory(init);
+            model->getNewModelParameters(init);
+            td.t = init.t;
+        }
+        td.X.assign(Xbar, Xbar + size_t(td.K) * NX);
+        td.U.assign(Ubar, Ubar + size_t(td.nU) * NU);
+        TrajectoryData cand = td;
+        cand.X.assign(Xc, Xc + size_t(td.K) * NX);
+        cand.U.assign(Uc, Uc + size_t(td.nU) * NU);
+        if (nondimensionalize && !bar_nondim)
+            model->nondimensionalizeTrajectory(td);
+        if (nondimensionalize && !cand_nondim)
+            model->nondimensionalizeTrajectory(cand);
+        multipleShooting(*model, td, dd);
+        const double keep_radius = trust_region;
+        trust_region = radius;
+        SCVarIndex ix;
+        Socp socp = buildSCvxProblem<Model>(trust_region, weight_virtual_control, td, dd, ix);
+        SCvxKeys key;
+        model->addApplicationConstraints(
+            socp, td.K, td.nU, [&](int i, int k) { return ix.vX(i, k); }, [&](int i, int k) { return ix.vU(i, k); }, key);
+        std::vector<double> x(size_t(socp.n), 0.);
+        for (int k = 0; k < td.K; k++)
+            for (int i = 0; i < NX; i++)
+                x[size_t(ix.vX(i, k))] = cand.x(k)[i];
+        for (int k = 0; k < td.nU; k++)
+            for (int i = 0; i < NU; i++)
+                x[size_t(ix.vU(i, k))] = cand.u(k)[i];
+        double n1 = 0.;
+        for (int k = 0; k + 1 < td.K; k++)
+        {
+            const double *A = &dd.A[size_t(k) * NX * NX], *B = &dd.B[size_t(k) * NX * NU], *C = &dd.C[size_t(k) * NX * NU];
+            for (int i = 0; i < NX; i++)
+            {
+                double v = cand.x(k + 1)[i] - dd.z[size_t(k) * NX + i];
+                for (int j = 0; j < NX; j++)
+                    v -= A[i * NX + j] * cand.x(k)[j];
+                for (int j = 0; j < NU; j++)
+                    v -= B[i * NU + j] * cand.u(k)[j] + (td.interpolatedInput() ? C[i * NU + j] * cand.u(k + 1)[j] : 0.);
+                x[size_t(ix.vNu(i, k))] = v;
+                x[size_t(ix.vNuB(i, k))] = std::fabs(v);
+                n1 += std::fabs(v);
+            }
+        }
+        x[size_t(ix.norm1_nu)] = n1;
+        out.norm1_nu = n1;
+        auto rowValue = [&](const SocpRow &r) {
+            double v = 0.;
+            for (auto &t : r.t)
+                v += t.second * x[size_t(t.first)];
+            return v;
+        };
+        for (auto &r : socp.eq)
+            out.eq_violation = std::max(out.eq_violation, std::fabs(rowValue(r) - r.rhs));
+        out.min_lp_slack = 1e300;
+        for (auto &r : socp.lp)
+            out.min_lp_slack = std::min(out.min_lp_slack, r.rhs - rowValue(r));
+        out.min_cone_slack = 1e300;
+        for (auto &cn : socp.soc)
+        {
+            double s0 = cn[0].rhs - rowValue(cn[0]), nn = 0.;
+            for (size_t i = 1; i < cn.size(); i++)
+            {
+                const double si = cn[i].rhs - rowValue(cn[i]);
+                nn += si * si;
+            }
+            out.min_cone_slack = std::min(out.min_cone_slack, s0 - std::sqrt(nn));
+        }
+        for (int j = 0; j < socp.n; j++)
+            out.cost += socp.c[size_t(j)] * x[size_t(j)];
+        if (solve_literal)
+        {
+            SocpSolver solver(socp);
+            solver.opt = socp_settings;
+            SocpResult r = solver.solve();
+            out.lit_exitflag = r.exitflag;
+            out.lit_iters = r.iter;
+            if (r.exitflag == 0 || r.exitflag == 10)
+            {
+                out.lit_cost = r.pcost;
+                out.lit_norm1_nu = r.x[size_t(ix.norm1_nu)];
+                TrajectoryData sol = td;
+                for (int k = 0; k < td.K; k++)
+                    for (int i = 0; i < NX; i++)
+                        sol.x(k)[i] = r.x[size_t(ix.vX(i, k))];
+                for (int k = 0; k < td.nU; k++)
+                    for (int i = 0; i < NU; i++)
+                        sol.u(k)[i] = r.x[size_t(ix.vU(i, k))];
+                if (nondimensionalize)
+                    model->redimensionalizeTrajectory(sol);
+                out.Xlit = sol.X;
+                out.Ulit = sol.U;
+            }
+        }
+        trust_region = keep_radius;
+        if (nondimensionalize)
+            model->redimensionalize();
+        return out;
     }
 
     int last_dims[5] = {0, 0, 0, 0, 0};

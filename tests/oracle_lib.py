@@ -236,6 +236,19 @@ class SC:
         lib().oracle_sc_get_scales(self.h, _p(out))
         return out
 
+    def check_point(self, Xbar, Ubar, tbar, Xc, Uc, tc, w_trx=0.0, solve_literal=True):
+        """A candidate (Xc, Uc, tc) in the LITERAL SC sub-problem linearised at (Xbar, Ubar, tbar) (all dimensional) for this
+        handle's x_init and trust-region weight w_trx (<= 0: SC.info's): row-by-row feasibility and the objective, next to the
+        literal solver's optimum of the same problem (oracle/sc.hpp: checkPoint)."""
+        Xbar, Ubar, Xc, Uc = (np.ascontiguousarray(a, dtype=np.float64) for a in (Xbar, Ubar, Xc, Uc))
+        out = np.zeros(10)
+        Xl, Ul = np.zeros_like(Xc), np.zeros_like(Uc)
+        rc = lib().oracle_sc_check_point(self.h, _p(Xbar), _p(Ubar), C.c_double(tbar), C.c_double(w_trx), _p(Xc), _p(Uc), C.c_double(tc),
+                                         int(solve_literal), _p(out), _p(Xl), _p(Ul))
+        assert rc == 0
+        return dict(eq_violation=out[0], min_lp_slack=out[1], min_cone_slack=out[2], cost=out[3], norm1_nu=out[4], lit_cost=out[5],
+                    lit_sigma=out[6], lit_exitflag=int(out[7]), lit_iters=int(out[8]), sum_delta=out[9], X_lit=Xl, U_lit=Ul)
+
 
 class SCvx:
     """Oracle SCvxAlgorithm handle for RocketQuat (oracle/scvx.hpp: SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:22-278)."""
@@ -257,6 +270,9 @@ class SCvx:
 
     def set_tolerances(self, feastol=1e-8, abstol=1e-8, reltol=1e-8, maxit=100):
         lib().oracle_scvx_set_tolerances(self.h, C.c_double(feastol), C.c_double(abstol), C.c_double(reltol), int(maxit))
+
+    def set_twin_tolerances(self, feastol=1e-8, abstol=1e-7, reltol=1e-7, maxit=60):
+        lib().oracle_scvx_set_twin_tolerances(self.h, C.c_double(feastol), C.c_double(abstol), C.c_double(reltol), int(maxit))
 
     def randomize(self, seed, instance):
         return lib().oracle_scvx_randomize(self.h, C.c_ulonglong(seed), C.c_ulonglong(instance))
@@ -285,6 +301,19 @@ class SCvx:
         rows = np.zeros((256, 9))
         n = lib().oracle_scvx_get_info(self.h, _p(rows), 256)
         return rows[:n]
+
+    def check_point(self, Xbar, Ubar, radius, Xc, Uc, solve_literal=True, bar_nondim=False, cand_nondim=False):
+        """A candidate (Xc, Uc) in the LITERAL sub-problem linearised at (Xbar, Ubar) (all dimensional) for this handle's
+        x_init: feasibility of every row of the reference-shaped standard form and the objective, next to the literal
+        solver's optimum of the same problem (oracle/scvx.hpp: checkPoint)."""
+        Xbar, Ubar, Xc, Uc = (np.ascontiguousarray(a, dtype=np.float64) for a in (Xbar, Ubar, Xc, Uc))
+        out = np.zeros(10)
+        Xl, Ul = np.zeros_like(Xc), np.zeros_like(Uc)
+        rc = lib().oracle_scvx_check_point(self.h, _p(Xbar), _p(Ubar), C.c_double(radius), _p(Xc), _p(Uc), int(solve_literal),
+                                           _p(out), _p(Xl), _p(Ul), int(bar_nondim), int(cand_nondim))
+        assert rc == 0
+        return dict(eq_violation=out[0], min_lp_slack=out[1], min_cone_slack=out[2], cost=out[3], norm1_nu=out[4],
+                    lit_cost=out[5], lit_norm1_nu=out[6], lit_exitflag=int(out[7]), lit_iters=int(out[8]), X_lit=Xl, U_lit=Ul)
 
 
 def sc_batch(K, seed, first, count, nthreads=1, solver=1, config_root=CONFIG_ROOT):

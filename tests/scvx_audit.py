@@ -1,0 +1,122 @@
+"""Literal-solver audit of the device's SCvx path (TEST INFRASTRUCTURE: uses the oracle).
+
+Why whole-run comparisons with an independent solver cannot be the parity test of the SCvx mode.  The accept / reject rule of
+SCvxAlgorithm (rho = dJ / dL against rho_0 = 0, SCvxAlgorithm.cpp:118-152) turns last-digit differences of a sub-problem optimum
+into different decision sequences: the oracle's two solvers (structured twin, literal sparse-KKT) part ways at the 2nd or 3rd
+solve on most instances and then visit different iterates (inputs differ by 1e-2 .. 1e-1 at the end, both runs converge).  The
+reference itself, with ECOS, would take a third path.  What CAN be pinned independently is every sub-problem the device
+actually solved:
+
+  for every ACCEPTED iterate j -> j+1 of the device run: build the reference-shaped (literal) sub-problem of
+  SCvxProblem.cpp:6-71 + rocketQuat.cpp:70-144 linearised at the device's iterate j with the radius the device used, and check
+  that the device's iterate j+1 is (i) feasible in it, row by row, to 1e-9, and (ii) as good as the literal solver's optimum of
+  the same problem (objective gap within the two solvers' termination tolerances).
+
+The accepted iterates are obtained without any extra ABI: the engine is deterministic, so a run capped at max_iterations = j
+ends exactly at iterate j of the full run (asserted: the capped runs' counters are prefixes of the full run's).
+A rejected candidate is never an iterate; the radius of the accepted solve of iteration j+1 is radius_j / alpha^(#rejections).
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def device_path(alg, x0, max_iterations):
+    """path[j] = dict(X, U, radius, solves, iters, converged) after j iterations, j = 0 .. (until every instance has ended);
+    path[0] is the initial trajectory (getInitializedTrajectory, redimensionalised) with the configured radius."""
+    path = []
+    keep = alg._max_iterations
+    try:
+        for j in range(0, max_iterations + 1):
+            alg._max_iterations = j
+            alg.solve(x0)
+            o = alg.getSolution()
+            assert (o["status"] == 0).all()
+            path.append(dict(X=o["X"].copy(), U=o["U"].copy(), radius=o["trust_region"].copy(), solves=o["solves"].copy(),
+                             iters=o["sc_iters"].copy(), converged=o["converged"].copy()))
+            if (o["converged"] == 1).all():
+                break
+    finally:
+        alg._max_iterations = keep
+    return path
+
+
+def audit_instance(oracle, K, seed, instance_id, path, b, alpha, lit_tol=1e-9):
+    """check_point of every accepted sub-problem of instance b (= randomised instance `instance_id` of `seed`)."""
+    s = oracle.SCvx(K=K)
+    s.randomize(seed, instance_id)
+    s.set_tolerances(lit_tol, lit_tol, lit_tol, 200)
+    rows = []
+    Xb, Ub = path[0]["X"][b], path[0]["U"][b]
+    r_prev, solves_prev = float(path[0]["radius"][b]), 0
+    for j, st in enumerate(path[1:]):
+        if st["iters"][b] <= j:  # the run had ended before this cap
+            break
+        n_rej = int(st["solves"][b] - solves_prev) - 1
+        assert n_rej >= 0
+        r_used = r_prev / alpha ** n_rej
+        c = s.check_point(Xb, Ub, r_used, st["X"][b], st["U"][b], True)
+        c["iteration"], c["radius"], c["rejections"] = j + 1, r_used, n_rej
+        ok = c["lit_exitflag"] in (0, 10)
+        c["relX"] = float(np.abs(c["X_lit"] - st["X"][b]).max() / np.abs(st["X"][b]).max()) if ok else None
+        c["relU"] = float(np.abs(c["U_lit"] - st["U"][b]).max() / np.abs(st["U"][b]).max()) if ok else None
+        del c["X_lit"], c["U_lit"]
+        rows.append(c)
+        Xb, Ub, r_prev, solves_prev = st["X"][b], st["U"][b], float(st["radius"][b]), int(st["solves"][b])
+    return rows
+
+
+def audit(oracle, K, seed, first, path, alpha, instances, threads=8, lit_tol=1e-9):
+    def one(b):
+        return audit_instance(oracle, K, seed, first + b, path, b, alpha, lit_tol=lit_tol)
+
+    with ThreadPoolExecutor(threads) as ex:
+        per = list(ex.map(one, instances))
+    rows = [r for p in per for r in p]
+    solved = [r for r in rows if r["lit_exitflag"] in (0, 10)]
+    gaps = np.array([(r["cost"] - r["lit_cost"]) / max(abs(r["lit_cost"]), 1e-12) for r in solved])
+    return dict(
+        rows=rows, n=len(rows), n_literal_solved=len(solved),
+        literal_flags={f: sum(r["lit_exitflag"] == f for r in rows) for f in sorted({r["lit_exitflag"] for r in rows})},
+        worst_eq=max(r["eq_violation"] for r in rows), worst_lp=min(r["min_lp_slack"] for r in rows),
+        worst_cone=min(r["min_cone_slack"] for r in rows),
+        gap_median=float(np.median(np.abs(gaps))), gap_max=float(np.abs(gaps).max()), gap_min_signed=float(gaps.min()),
+        relX_max=max(r["relX"] for r in solved), relU_max=max(r["relU"] for r in solved),
+        relU_median=float(np.median([r["relU"] for r in solved])),
+    )
+
+
+# ---- SC mode (SCAlgorithm): certificate for the LAST sub-problem of a device run ----
+def sc_device_iterate(alg, x0, j):
+    """(X, U, sigma, ...) of every instance after j SCAlgorithm iterations, redimensionalised (a run capped at
+    max_iterations = j: the device loop is deterministic, so this is iterate j of the full run)."""
+    import copy
+
+    opts = copy.copy(alg.opts)
+    opts.max_iterations = int(j)
+    alg.ctx.sc_setup(alg.model.sc_params(), opts, np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+    alg.ctx.sc_solve()
+    return alg.ctx.download()
+
+
+def sc_last_solve_certificate(handle, alg, x0_row, iters, w_trx=0.0, lit_tol=1e-9):
+    """The device's final iterate of one instance in the oracle's LITERAL SC sub-problem linearised at the device's previous
+    iterate: row-by-row feasibility, objective, and the literal solver's optimum of that same problem (oracle/sc.hpp: checkPoint).
+    `handle` is an oracle.SC whose x_init is x0_row."""
+    prev = sc_device_iterate(alg, x0_row, iters - 1)
+    last = sc_device_iterate(alg, x0_row, iters)
+    handle.set_tolerances(lit_tol, lit_tol, lit_tol, 200)
+    c = handle.check_point(prev["X"][0], prev["U"][0], float(prev["sigma"][0]), last["X"][0], last["U"][0], float(last["sigma"][0]),
+                           w_trx=w_trx)
+    if c["lit_exitflag"] in (0, 10):
+        c["relX"] = float(np.abs(c["X_lit"] - last["X"][0]).max() / np.abs(last["X"][0]).max())
+        c["relU"] = float(np.abs(c["U_lit"] - last["U"][0]).max() / np.abs(last["U"][0]).max())
+        c["gap"] = float((c["cost"] - c["lit_cost"]) / abs(c["lit_cost"]))
+    c["X"], c["U"], c["sigma"] = last["X"][0], last["U"][0], float(last["sigma"][0])
+    return c
+
+
+def assert_certificate(c, feas=1e-9, gap=1e-6):
+    """feasible in the literal problem and as good as its optimum: an eps-optimal point of the reference-shaped problem"""
+    assert c["eq_violation"] <= feas and c["min_lp_slack"] >= -feas and c["min_cone_slack"] >= -feas, c
+    assert c["lit_exitflag"] in (0, 10) and abs(c["gap"]) <= gap, c

@@ -239,3 +239,27 @@ def _zoh_case(oracle, lib, tol):
 
 def test_emu_discretize_zero_order_hold(oracle, emu_lib):
     _zoh_case(oracle, emu_lib, 1e-10)
+
+
+def test_emu_scvx_literal_audit_of_the_device_path(oracle, model, emu_lib):
+    """Every ACCEPTED sub-problem of the device's SCvx path, audited by the oracle's LITERAL (reference-shaped) formulation:
+    the device iterate j+1 is feasible, row by row, in the literal problem linearised at the device iterate j (<= 1e-9) and its
+    objective equals the literal solver's optimum within the solvers' termination tolerances (tests/scvx_audit.py; the GPU
+    counterpart at K = 50 is tests/test_gpu_parity.py::test_scvx_at_scale_parity_and_literal_audit).  Capped runs are prefixes
+    of the full run (determinism, which the audit's way of obtaining the iterates relies on)."""
+    import scvx_audit
+
+    K, B, maxit = 8, 3, 6
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    x0 = model.randomized_initial_states(B)
+    path = scvx_audit.device_path(alg, x0, maxit)
+    alg.solve(x0)
+    full = alg.getSolution()
+    for j, st in enumerate(path):
+        done = full["sc_iters"] <= j
+        assert np.array_equal(st["X"][done], full["X"][done]) and np.array_equal(st["solves"][done], full["solves"][done])
+    r = scvx_audit.audit(oracle, K, 20260927, 0, path, alg.opts.alpha, range(B), threads=3)
+    assert r["n"] == int(full["sc_iters"].sum()) and r["n_literal_solved"] >= r["n"] - 1
+    assert r["worst_eq"] <= 1e-9 and r["worst_lp"] >= -1e-9 and r["worst_cone"] >= -1e-9
+    assert r["gap_median"] <= 1e-6 and r["gap_max"] <= 5e-5 and r["gap_min_signed"] >= -1e-6
+    assert r["relX_max"] <= 1e-5
