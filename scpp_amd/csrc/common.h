@@ -121,6 +121,45 @@ __device__ __forceinline__ double readLane(double v, int src)
 }
 __device__ __forceinline__ bool anyLane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 #endif
+// ---- exchanges ACROSS the four rows of 16 lanes, still on the VALU data path (gfx950: v_permlane16_swap / v_permlane32_swap) ----
+// v_permlane16_swap vdst, src: rows 1 / 3 of vdst <-> rows 0 / 2 of src; v_permlane32_swap: lanes 32..63 of vdst <-> lanes 0..31 of
+// src.  With both operands holding the same value v the two results are "the even rows (lower half) everywhere" and "the odd rows
+// (upper half) everywhere", so two swaps broadcast any one row to all four:
+//   rowGroupBcast<GS>(v): every lane (g, i) receives v of lane (GS, i);
+//   rowGroupDiag(v):      every lane (g, i) receives v of lane (i & 3, i)  (the source row depends on the column: two selects).
+// Each replaces an LDS write -> wait -> read -> wait round trip of the inverse-factor eliminations (tile_engine.h).
+#ifdef SCPP_HIP_EMU
+template <int GS>
+inline double rowGroupBcast(double v) { const int l = threadIdx.x & 63; return __shfl(v, GS * 16 + (l & 15)); }
+inline double rowGroupDiag(double v) { const int l = threadIdx.x & 63; return __shfl(v, (l & 3) * 16 + (l & 15)); }
+#else
+template <int GS>
+__device__ __forceinline__ int rowGroupBcast32(int v)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(unsigned(v), unsigned(v), false, false); // a[0]: rows (0,0,2,2), a[1]: rows (1,1,3,3)
+    const unsigned t = (GS & 1) ? a[1] : a[0];
+    const auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false); // b[0]: lower half twice, b[1]: upper half twice
+    return int((GS & 2) ? b[1] : b[0]);
+}
+template <int GS>
+__device__ __forceinline__ double rowGroupBcast(double v)
+{
+    return __hiloint2double(rowGroupBcast32<GS>(__double2hiint(v)), rowGroupBcast32<GS>(__double2loint(v)));
+}
+__device__ __forceinline__ int rowGroupDiag32(int v, bool odd, bool upper)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(unsigned(v), unsigned(v), false, false);
+    const unsigned t = odd ? a[1] : a[0]; // rows (0|odd) of each half, for THIS lane's column
+    const auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+    return int(upper ? b[1] : b[0]);
+}
+__device__ __forceinline__ double rowGroupDiag(double v)
+{
+    const int i = threadIdx.x & 15;
+    const bool odd = i & 1, upper = i & 2;
+    return __hiloint2double(rowGroupDiag32(__double2hiint(v), odd, upper), rowGroupDiag32(__double2loint(v), odd, upper));
+}
+#endif
 // sum / max over the row of 16 lanes, result in every lane of the row
 __device__ __forceinline__ double rowSum16(double v)
 {

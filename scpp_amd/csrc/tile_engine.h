@@ -116,6 +116,9 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 #ifndef INVCHOL_UNROLL
 #define INVCHOL_UNROLL _Pragma("unroll")
 #endif
+#ifndef INVCHOL_PERMLANE
+#define INVCHOL_PERMLANE 1 // 1: pivot row / column exchanged by v_permlane16/32_swap ; 0: through 2 x 16 doubles of LDS
+#endif
 template <int n>
 INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
 {
@@ -142,6 +145,7 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         // it (and the multipliers m = A[row][j] / d, which come by row broadcast) are then structurally zero wherever the
         // elimination must not act, and no reader has to mask them (rows >= n of an n < 16 block are zero in column j anyway;
         // R[j][i] = 0 for i > j by construction).
+#if !INVCHOL_PERMLANE
         if (i == j)
         {
 #pragma unroll
@@ -155,11 +159,14 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         if (g == (j & 3))
             sh.rowR[b][i] = rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3];
         WAVE_SYNC();
+#endif
         // one batch of LDS reads (no control flow in between)
         double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
         const double floor_ = readLane(od, (j & 3) * 16 + j);
+#if !INVCHOL_PERMLANE
         const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
         const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
+#endif
         // column j below the pivot, for this lane's rows: lane (g, j) holds it -> row broadcast on the VALU data path
         double cr[4];
 #pragma unroll
@@ -169,6 +176,16 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
             if (4 * r + 3 > j)
                 cr[r] = rowBcast<j>((g + 4 * r > j) ? A.v[r] : 0.);
         }
+#if INVCHOL_PERMLANE
+        // No LDS in the elimination at all (gfx950 row swaps, common.h).  A[i][j] (= the pivot-row entry of column i, 0 for
+        // i <= j) is one of the column-j values the row broadcast just delivered: lane (i & 3, i) holds it as cr[i >> 2], and
+        // rowGroupDiag hands every lane of column i that lane's value.  R[j][i] lives in row group j & 3, register j >> 2.
+        // Bitwise the same operands as the LDS exchange (which remains available: -DINVCHOL_PERMLANE=0).
+        (void)b;
+        const int iq = i >> 2;
+        const double aj = rowGroupDiag(iq == 0 ? cr[0] : iq == 1 ? cr[1] : iq == 2 ? cr[2] : cr[3]);
+        const double rj = rowGroupBcast<(j & 3)>(rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3]);
+#endif
         d = fmax(d, floor_);
         const double p = fastRcp(d);
 #pragma unroll

@@ -500,27 +500,58 @@ def test_sc_sim_runs_to_the_stop_rule_like_the_oracle(oracle, hip_lib, tmp_path)
     a2.ctx.close()
 
 
-def test_sc_sim_monte_carlo_4096_loops_properties(model, hip_lib):
-    """configs[3] at its batch size: 4096 closed loops x 20 receding-horizon steps.  Size-independent properties: no solver
-    failure, the stop mask only ever shrinks, duplicated initial states give bitwise identical closed loops, and every loop's
-    plant state follows its plan (the first simulated step lands on the planned trajectory to discretisation accuracy)."""
-    B, steps = 4096, 20
+def test_sc_sim_monte_carlo_4096_loops_200_steps(oracle, model, hip_lib):
+    """BASELINE configs[3] AT SIZE: 4096 closed loops x 200 receding-horizon steps (SC_sim.cpp:28-66 per loop: warm-started
+    re-solve, plant step, stop rule), i.e. 819 200 warm-started SCAlgorithm solves and plant steps through the device.
+    Size-independent properties over the whole run: no solver failure in any loop at any step; nobody meets the stop rule (with
+    the shipped weights the re-planned final time drifts up, 12 s -> 15 .. 30 s, and the vehicle is still 250 .. 450 m up after
+    10 s: the oracle's loops say the same, DESIGN.md section 6); duplicated initial states give bitwise identical closed loops;
+    altitude decreases monotonically and the mass stays above the dry mass along every sampled loop.  Two loops are followed by
+    the oracle's restatement of the same driver for the first 100 steps (identical SC iteration counts per solve, plant states
+    within north_star's 1e-5)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    B, steps = 4096, 200
     a = scpp_amd.SCAlgorithm(model, K=50, batch_max=B, library=hip_lib).initialize()
-    x0 = model.randomized_initial_states(B, first=90_000)
+    first = 90_000
+    x0 = model.randomized_initial_states(B, first=first)
     x0[B // 2:] = x0[:B // 2]  # second half duplicates the first
+    t0 = time.time()
     r = scpp_amd.SCSim(a, time_step=0.05, max_steps=steps).run(x0)
+    t_dev = time.time() - t0
     assert not r["solver_failed"].any()
-    assert (r["steps"] == steps).all()  # nobody reaches the target within 1 s of a 12 s descent
+    assert (r["steps"] == steps).all() and not r["reached_end"].any()
     h = B // 2
-    for b in range(0, h, 97):
+    sample = range(0, h, 97)
+    for b in sample:
         assert np.array_equal(r["X_sim"][b], r["X_sim"][b + h]) and np.array_equal(r["U_sim"][b], r["U_sim"][b + h])
         assert np.array_equal(r["t_plan"][b], r["t_plan"][b + h])
-    # planned final time shrinks by about the elapsed time from solve to solve (free final time, receding horizon)
-    tp = np.array([r["t_plan"][b] for b in range(0, h, 97)])
-    assert (np.abs(np.diff(tp, axis=1) + 0.05) < 0.2).all()
-    # altitude decreases monotonically along every sampled closed loop (descent scenario)
-    for b in range(0, h, 97):
-        assert (np.diff(r["X_sim"][b][:, 3]) < 0).all()
+        assert (np.diff(r["X_sim"][b][:, 3]) < 0).all()        # descent
+        assert (r["X_sim"][b][:, 0] > 22000.0).all()           # above m_dry
+        assert (np.diff(r["X_sim"][b][:, 0]) < 0).all()        # burning fuel at every step
+        assert (r["t_plan"][b] > 5.0).all() and (r["t_plan"][b] < 60.0).all()
+    tp_end = np.array([r["t_plan"][b][-1] for b in range(h)])
+    alt_end = np.array([r["X_sim"][b][-1, 3] for b in range(h)])
+    n_oracle = 100
+
+    def ref(b):
+        sc = oracle.SC(oracle.ROCKETQUAT, K=50); sc.randomize(20260927, first + b); sc.set_solver(1)
+        return sc.sim(0.05, n_oracle)
+
+    t0 = time.time()
+    with ThreadPoolExecutor(2) as ex:
+        refs = list(ex.map(ref, (0, 1)))
+    worst = 0.0
+    for b, o in enumerate(refs):
+        assert o["steps"] == n_oracle and not o["solver_failed"]
+        assert list(o["sc_iters"]) == list(r["sc_iters"][b][:n_oracle])
+        dev = np.abs(o["X_sim"] - r["X_sim"][b][:n_oracle]).max() / np.abs(o["X_sim"]).max()
+        worst = max(worst, float(dev))
+    print("SC_sim at size: %d loops x %d steps in %.1f s (%.0f warm-started solves + plant steps per second); final planned time %.1f .. %.1f s, "
+          "final altitude %.0f .. %.0f m; two loops vs the oracle over %d steps: worst relative state deviation %.2e (oracle %.0f s)"
+          % (B, steps, t_dev, B * steps / t_dev, tp_end.min(), tp_end.max(), alt_end.min(), alt_end.max(), n_oracle, worst, time.time() - t0))
+    assert worst <= 1e-5
     a.ctx.close()
 
 
