@@ -56,6 +56,7 @@ extern "C"
 #define SCPP_E_HIP -2
 #define SCPP_E_UNSUPPORTED -3
 #define SCPP_E_STATE -4
+#define SCPP_STATUS_REJECTION_CAP -4 /* a per-instance STATUS (scpp_hip_download), not a return code */
 
     typedef struct scpp_hip_ctx scpp_hip_ctx;
 
@@ -171,13 +172,18 @@ extern "C"
        sc_iterate themselves, e.g. to record every iterate like getAllSolutions (SCAlgorithm.cpp:217-232) */
     int scpp_hip_sc_finish(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_socp_solve(scpp_hip_ctx *ctx);                 /* sub-problem only, on the current td/dd */
-    /* ---- SCvxAlgorithm boundary (RocketQuat): fixed final time, hard input trust region, rho-ratio radius update
+    /* ---- SCvxAlgorithm boundary: fixed final time, hard input trust region, rho-ratio radius update
        (scpp_core/src/SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:61-227).  Results through scpp_hip_download
        (sc_iters = SCvx iterations); per-instance radius, last nonlinear cost J, number of sub-problem solves and
        [rho, dJ, dL, code] of the last decision (code 0 rejected, 1 accepted, 2 first pass, 3 converged) through
        scpp_hip_scvx_download_state (any pointer may be NULL) ---- */
     int scpp_hip_scvx_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_scvx_opts *opts,
                             const double *x_init /* [B][14] dimensional */, int B, int warm_start);
+    /* the same for a Rocket2d context (the reference ships scpp_models/config/Rocket2D/SCvx.info, and SCvxAlgorithm is
+       model-generic: SCvxAlgorithm.cpp:46-59, constraints rocket2d.cpp:46-84): the SCvx mode of the solver instantiated for
+       Rocket2d's constraint table.  scvx_solve / download / scvx_download_state serve both models. */
+    int scpp_hip_scvx_setup_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_scvx_opts *opts,
+                                     const double *x_init /* [B][6] dimensional */, int B, int warm_start);
     int scpp_hip_scvx_solve(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_scvx_download_state(scpp_hip_ctx *ctx, double *trust_region, double *nonlinear_cost, int32_t *solves,
                                      double *last_decision /* [B][4] */);
@@ -197,10 +203,17 @@ extern "C"
     int scpp_hip_scvx_solve_stream(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_scvx_opts *opts,
                                    const double *x_init /* [N][14] dimensional */, int N, int slots, int pools,
                                    int *n_converged);
+    /* Rocket2d: rows of K*8 + 10 float64 (X [K][6], U [K][2], then the same ten scalars) */
+    int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_scvx_opts *opts,
+                                            const double *x_init /* [N][6] dimensional */, int N, int slots, int pools,
+                                            int *n_converged);
     int scpp_hip_stream_rows(scpp_hip_ctx *ctx, void **rows, int *row_doubles, int *n);
     int scpp_hip_stream_download(scpp_hip_ctx *ctx, double *rows /* [count][K*18+10] */, int first, int count);
     int scpp_hip_stream_info(scpp_hip_ctx *ctx, long long *rounds_enqueued, int *pools_used); /* diagnostics of the last job */
-    /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure */
+    /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure, SCPP_STATUS_REJECTION_CAP (-4):
+       SCvx only -- the instance used 64 x max_iterations sub-problem solves without leaving the reject / re-solve loop of
+       SCvxAlgorithm::iterate (SCvxAlgorithm.cpp:75-153 has no other exit; seen with the shipped Rocket2D SCvx.info, whose
+       trust radius collapses) and was retired; its trajectory is the last accepted iterate */
     int scpp_hip_download(scpp_hip_ctx *ctx, double *X, double *U, double *sigma, int32_t *sc_iters, double *nu_norm,
                           int32_t *converged, int32_t *status, int32_t *ipm_iters, double *sum_delta);
     int scpp_hip_download_socp_info(scpp_hip_ctx *ctx, double *info /* [B][32]: pcost,gap,pres,dres,iters,status,norm1_nu,sum_delta, then 24 profiling slots */);

@@ -526,30 +526,57 @@ int oracle_sc_batch(const char *config_root, int K, unsigned long long seed, lon
 } // extern "C"
 
 
-// ---- SCvx (RocketQuat) ----
+// ---- SCvx (any model; the structured twin exists for RocketQuat only) ----
 namespace
 {
-struct SCvxHandle
+struct SCvxHandleBase
 {
-    RocketQuat model;
-    std::unique_ptr<SCvxAlgorithm<RocketQuat>> alg;
-    SCvxHandle(const std::string &root, int K)
+    virtual ~SCvxHandleBase() {}
+    virtual SCvxAlgorithm<RocketQuat> *rq() { return nullptr; }
+    virtual SCvxAlgorithm<Rocket2d> *r2() { return nullptr; }
+};
+template <class M>
+struct SCvxHandleT : SCvxHandleBase
+{
+    M model;
+    std::unique_ptr<SCvxAlgorithm<M>> alg;
+    SCvxHandleT(const std::string &root, int K)
     {
-        const std::string folder = root + "/" + RocketQuat::modelName();
+        const std::string folder = root + "/" + M::modelName();
         model.loadParameters(folder);
-        alg.reset(new SCvxAlgorithm<RocketQuat>(&model, folder, K));
+        alg.reset(new SCvxAlgorithm<M>(&model, folder, K));
         alg->initialize();
     }
+    SCvxAlgorithm<RocketQuat> *rq() override;
+    SCvxAlgorithm<Rocket2d> *r2() override;
 };
+template <>
+SCvxAlgorithm<RocketQuat> *SCvxHandleT<RocketQuat>::rq() { return alg.get(); }
+template <>
+SCvxAlgorithm<Rocket2d> *SCvxHandleT<RocketQuat>::r2() { return nullptr; }
+template <>
+SCvxAlgorithm<RocketQuat> *SCvxHandleT<Rocket2d>::rq() { return nullptr; }
+template <>
+SCvxAlgorithm<Rocket2d> *SCvxHandleT<Rocket2d>::r2() { return alg.get(); }
+template <class F>
+auto withScvx(void *h, F f)
+{
+    SCvxHandleBase *b = static_cast<SCvxHandleBase *>(h);
+    if (b->rq())
+        return f(*b->rq());
+    return f(*b->r2());
+}
 } // namespace
 
 extern "C"
 {
-void *oracle_scvx_create(const char *config_root, int K_override)
+void *oracle_scvx_create_model(int model, const char *config_root, int K_override)
 {
     try
     {
-        return new SCvxHandle(config_root, K_override);
+        if (model == 0)
+            return static_cast<SCvxHandleBase *>(new SCvxHandleT<RocketQuat>(config_root, K_override));
+        return static_cast<SCvxHandleBase *>(new SCvxHandleT<Rocket2d>(config_root, K_override));
     }
     catch (const std::exception &e)
     {
@@ -557,66 +584,85 @@ void *oracle_scvx_create(const char *config_root, int K_override)
         return nullptr;
     }
 }
-void oracle_scvx_destroy(void *h) { delete static_cast<SCvxHandle *>(h); }
+void *oracle_scvx_create(const char *config_root, int K_override) { return oracle_scvx_create_model(0, config_root, K_override); }
+void oracle_scvx_destroy(void *h) { delete static_cast<SCvxHandleBase *>(h); }
 int oracle_scvx_set_solver(void *h, int kind)
 {
-    static_cast<SCvxHandle *>(h)->alg->solver_kind = kind;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.solver_kind = kind;
+        return 0;
+    });
 }
 int oracle_scvx_set_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    a.socp_settings.feastol = feastol;
-    a.socp_settings.abstol = abstol;
-    a.socp_settings.reltol = reltol;
-    a.socp_settings.maxit = maxit;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.socp_settings.feastol = feastol;
+        a.socp_settings.abstol = abstol;
+        a.socp_settings.reltol = reltol;
+        a.socp_settings.maxit = maxit;
+        return 0;
+    });
 }
 // tolerances of the structured twin (defaults: feastol 1e-8, abstol / reltol 1e-7, maxit 60 = the device's)
 int oracle_scvx_set_twin_tolerances(void *h, double feastol, double abstol, double reltol, int maxit)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    a.structured_settings.feastol = feastol;
-    a.structured_settings.abstol = abstol;
-    a.structured_settings.reltol = reltol;
-    a.structured_settings.maxit = maxit;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.structured_settings.feastol = feastol;
+        a.structured_settings.abstol = abstol;
+        a.structured_settings.reltol = reltol;
+        a.structured_settings.maxit = maxit;
+        return 0;
+    });
 }
 int oracle_scvx_verbose(void *h, int v)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    a.socp_settings.verbose = v != 0;
-    a.structured_settings.verbose = v != 0;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.socp_settings.verbose = v != 0;
+        a.structured_settings.verbose = v != 0;
+        return 0;
+    });
 }
 int oracle_scvx_set_reg(void *h, double dx, double deq, double dcone)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    a.socp_settings.delta_x = dx;
-    a.socp_settings.delta_eq = deq;
-    a.socp_settings.delta_cone = dcone;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.socp_settings.delta_x = dx;
+        a.socp_settings.delta_eq = deq;
+        a.socp_settings.delta_cone = dcone;
+        return 0;
+    });
 }
 int oracle_scvx_randomize(void *h, unsigned long long seed, unsigned long long instance)
 {
-    static_cast<SCvxHandle *>(h)->model.p.randomizeInitialState(seed, instance);
+    SCvxHandleBase *b = static_cast<SCvxHandleBase *>(h);
+    if (!b->rq())
+        return -1; // the randomisation recipe is RocketQuat's (rocketQuat.cpp:203-227)
+    b->rq()->model->p.randomizeInitialState(seed, instance);
     return 0;
+}
+int oracle_scvx_set_x_init(void *h, const double *x)
+{
+    return withScvx(h, [&](auto &a) {
+        for (size_t i = 0; i < sizeof(a.model->p.x_init) / sizeof(double); i++)
+            a.model->p.x_init[i] = x[i];
+        return 0;
+    });
 }
 int oracle_scvx_set_max_iterations(void *h, int n)
 {
-    static_cast<SCvxHandle *>(h)->alg->max_iterations_override = size_t(n);
-    static_cast<SCvxHandle *>(h)->alg->max_iterations = size_t(n);
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        a.max_iterations_override = size_t(n);
+        a.max_iterations = size_t(n);
+        return 0;
+    });
 }
 int oracle_scvx_solve(void *h, int warm_start)
 {
     try
     {
-        auto &a = *static_cast<SCvxHandle *>(h)->alg;
-        const size_t keep = a.max_iterations;
-        a.solve(warm_start != 0);
-        (void)keep;
-        return a.solver_failed ? -1 : 0;
+        return withScvx(h, [&](auto &a) {
+            a.solve(warm_start != 0);
+            return a.solver_failed ? -1 : 0;
+        });
     }
     catch (const std::exception &e)
     {
@@ -627,32 +673,34 @@ int oracle_scvx_solve(void *h, int warm_start)
 // meta: [K, nU, iterations, converged, n_all_td, n_info, solves, n, p, l, ncones, m]
 int oracle_scvx_meta(void *h, int *meta)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    meta[0] = a.td.K;
-    meta[1] = a.td.nU;
-    meta[2] = a.iterations;
-    meta[3] = a.converged;
-    meta[4] = int(a.all_td.size());
-    meta[5] = int(a.info.size());
-    meta[6] = a.solves;
-    for (int i = 0; i < 5; i++)
-        meta[7 + i] = a.last_dims[i];
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        meta[0] = a.td.K;
+        meta[1] = a.td.nU;
+        meta[2] = a.iterations;
+        meta[3] = a.converged;
+        meta[4] = int(a.all_td.size());
+        meta[5] = int(a.info.size());
+        meta[6] = a.solves;
+        for (int i = 0; i < 5; i++)
+            meta[7 + i] = a.last_dims[i];
+        return 0;
+    });
 }
 int oracle_scvx_get_iterate(void *h, int idx, double *X, double *U, double *t)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    const TrajectoryData *td = &a.td;
-    if (idx >= 0)
-    {
-        if (idx >= int(a.all_td.size()))
-            return -1;
-        td = &a.all_td[size_t(idx)];
-    }
-    std::memcpy(X, td->X.data(), td->X.size() * sizeof(double));
-    std::memcpy(U, td->U.data(), td->U.size() * sizeof(double));
-    *t = td->t;
-    return 0;
+    return withScvx(h, [&](auto &a) {
+        const TrajectoryData *td = &a.td;
+        if (idx >= 0)
+        {
+            if (idx >= int(a.all_td.size()))
+                return -1;
+            td = &a.all_td[size_t(idx)];
+        }
+        std::memcpy(X, td->X.data(), td->X.size() * sizeof(double));
+        std::memcpy(U, td->U.data(), td->U.size() * sizeof(double));
+        *t = td->t;
+        return 0;
+    });
 }
 // candidate point in the literal sub-problem linearised at (Xbar, Ubar), all trajectories DIMENSIONAL (scvx.hpp: checkPoint).
 // out[10]: eq_violation, min_lp_slack, min_cone_slack, cost, norm1_nu, lit_cost, lit_norm1_nu, lit_exitflag, lit_iters, n
@@ -661,23 +709,24 @@ int oracle_scvx_check_point(void *h, const double *Xbar, const double *Ubar, dou
 {
     try
     {
-        auto &a = *static_cast<SCvxHandle *>(h)->alg;
-        const auto r = a.checkPoint(Xbar, Ubar, radius, Xc, Uc, solve_literal != 0, bar_nondim != 0, cand_nondim != 0);
-        out[0] = r.eq_violation;
-        out[1] = r.min_lp_slack;
-        out[2] = r.min_cone_slack;
-        out[3] = r.cost;
-        out[4] = r.norm1_nu;
-        out[5] = r.lit_cost;
-        out[6] = r.lit_norm1_nu;
-        out[7] = r.lit_exitflag;
-        out[8] = r.lit_iters;
-        out[9] = 0.;
-        if (Xlit && !r.Xlit.empty())
-            std::memcpy(Xlit, r.Xlit.data(), r.Xlit.size() * sizeof(double));
-        if (Ulit && !r.Ulit.empty())
-            std::memcpy(Ulit, r.Ulit.data(), r.Ulit.size() * sizeof(double));
-        return 0;
+        return withScvx(h, [&](auto &a) {
+                    const auto r = a.checkPoint(Xbar, Ubar, radius, Xc, Uc, solve_literal != 0, bar_nondim != 0, cand_nondim != 0);
+            out[0] = r.eq_violation;
+            out[1] = r.min_lp_slack;
+            out[2] = r.min_cone_slack;
+            out[3] = r.cost;
+            out[4] = r.norm1_nu;
+            out[5] = r.lit_cost;
+            out[6] = r.lit_norm1_nu;
+            out[7] = r.lit_exitflag;
+            out[8] = r.lit_iters;
+            out[9] = 0.;
+            if (Xlit && !r.Xlit.empty())
+                std::memcpy(Xlit, r.Xlit.data(), r.Xlit.size() * sizeof(double));
+            if (Ulit && !r.Ulit.empty())
+                std::memcpy(Ulit, r.Ulit.data(), r.Ulit.size() * sizeof(double));
+            return 0;
+        });
     }
     catch (const std::exception &e)
     {
@@ -688,23 +737,24 @@ int oracle_scvx_check_point(void *h, const double *Xbar, const double *Ubar, dou
 // per-solve rows: [norm1_nu, nonlinear_cost, actual_change, predicted_change, rho, trust_region(after), accepted, ipm_iters, exitflag]
 int oracle_scvx_get_info(void *h, double *rows, int max_rows)
 {
-    auto &a = *static_cast<SCvxHandle *>(h)->alg;
-    const int n = std::min<int>(max_rows, int(a.info.size()));
-    for (int i = 0; i < n; i++)
-    {
-        const SCvxIterationInfo &f = a.info[size_t(i)];
-        double *r = rows + i * 9;
-        r[0] = f.norm1_nu;
-        r[1] = f.nonlinear_cost;
-        r[2] = f.actual_change;
-        r[3] = f.predicted_change;
-        r[4] = f.rho;
-        r[5] = f.trust_region;
-        r[6] = f.accepted;
-        r[7] = f.ipm_iters;
-        r[8] = f.exitflag;
-    }
-    return n;
+    return withScvx(h, [&](auto &a) {
+        const int n = std::min<int>(max_rows, int(a.info.size()));
+        for (int i = 0; i < n; i++)
+        {
+            const SCvxIterationInfo &f = a.info[size_t(i)];
+            double *r = rows + i * 9;
+            r[0] = f.norm1_nu;
+            r[1] = f.nonlinear_cost;
+            r[2] = f.actual_change;
+            r[3] = f.predicted_change;
+            r[4] = f.rho;
+            r[5] = f.trust_region;
+            r[6] = f.accepted;
+            r[7] = f.ipm_iters;
+            r[8] = f.exitflag;
+        }
+        return n;
+    });
 }
 }
 

@@ -244,9 +244,10 @@ class Context:
 
     # ---- SCvx boundary ----
     def scvx_setup(self, model_params, scvx_opts, x_init, warm_start=False):
-        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         self.B = x_init.shape[0]
-        _chk(self.lib.scpp_hip_scvx_setup(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(self.B), int(warm_start)), "scvx_setup")
+        fn = self.lib.scpp_hip_scvx_setup if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_scvx_setup_rocket2d
+        _chk(fn(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(self.B), int(warm_start)), "scvx_setup")
 
     def scvx_solve(self):
         n = C.c_int(0)
@@ -264,12 +265,13 @@ class Context:
                       "ipm_iters", "instance")
 
     def scvx_solve_stream(self, model_params, scvx_opts, x_init, slots=0, pools=0):
-        """SCvxAlgorithm::solve of every row of x_init [N][14] through `slots` resident slots. Returns #converged."""
-        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, 14)
+        """SCvxAlgorithm::solve of every row of x_init [N][nx] through `slots` resident slots. Returns #converged."""
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         n = C.c_int(0)
         self._stream_N = x_init.shape[0]
-        _chk(self.lib.scpp_hip_scvx_solve_stream(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(x_init.shape[0]),
-                                                 int(slots), int(pools), C.byref(n)), "scvx_solve_stream")
+        fn = self.lib.scpp_hip_scvx_solve_stream if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_scvx_solve_stream_rocket2d
+        _chk(fn(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(x_init.shape[0]), int(slots), int(pools), C.byref(n)),
+             "scvx_solve_stream")
         return n.value
 
     def stream_rows_device(self):
@@ -279,15 +281,15 @@ class Context:
         return ptr.value, rd.value, n.value
 
     def stream_download_rows(self, first=0, count=None):
-        """raw result rows [count][K*18 + 10] of the last streaming job (the all-gather payload)"""
+        """raw result rows [count][K*(nx+nu) + 10] of the last streaming job (the all-gather payload)"""
         count = self._stream_N - first if count is None else count
-        rowd = self.K * 18 + len(self.STREAM_SCALARS)
+        rowd = self.K * (self.nx + self.nu) + len(self.STREAM_SCALARS)
         rows = np.zeros((count, rowd))
         _chk(self.lib.scpp_hip_stream_download(self.h, _p(rows), int(first), int(count)), "stream_download")
         return rows
 
     def stream_download(self, first=0, count=None):
-        return self.unpack_stream_rows(self.stream_download_rows(first, count), self.K)
+        return self.unpack_stream_rows(self.stream_download_rows(first, count), self.K, self.nx, self.nu)
 
     def stream_rounds(self):
         """rounds the host enqueued for the last streaming job and the number of slot pools it used"""
@@ -296,11 +298,11 @@ class Context:
         return {"rounds": r.value, "pools": p.value}
 
     @classmethod
-    def unpack_stream_rows(cls, rows, K):
+    def unpack_stream_rows(cls, rows, K, nx=14, nu=4):
         n = rows.shape[0]
-        out = dict(X=rows[:, :K * 14].reshape(n, K, 14), U=rows[:, K * 14:K * 18].reshape(n, K, 4))
+        out = dict(X=rows[:, :K * nx].reshape(n, K, nx), U=rows[:, K * nx:K * (nx + nu)].reshape(n, K, nu))
         for j, name in enumerate(cls.STREAM_SCALARS):
-            col = rows[:, K * 18 + j]
+            col = rows[:, K * (nx + nu) + j]
             out[name] = col if name in ("sigma", "nu_norm", "nonlinear_cost", "trust_region") else col.astype(np.int32)
         return out
 

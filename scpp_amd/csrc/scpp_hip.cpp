@@ -909,15 +909,12 @@ SCvxBuffers scvxBuffers(scpp_hip_ctx *c)
 }
 } // namespace
 
-int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
-                        int B, int warm_start)
+namespace
 {
-    DeviceGuard guard(c);
-    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
-        return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKETQUAT)
-        return SCPP_E_UNSUPPORTED;
-    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
+// what SCvx set-up does for every model: buffers, options, the SC-style options the shared set-up kernels read
+int scvxSetupCommon(scpp_hip_ctx *c, const scpp_scvx_opts *so, const double *x_init, int B, int warm_start)
+{
+    if (so->K != c->K || !so->interpolate_input)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->scvx_ready || B != c->B))
         return SCPP_E_STATE;
@@ -927,8 +924,8 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
     {
         const size_t Bm = size_t(c->Bmax), K = size_t(c->K);
         int rc = 0;
-        rc |= devAlloc(&c->vx_Xold, Bm * K * 14);
-        rc |= devAlloc(&c->vx_Uold, Bm * K * 4);
+        rc |= devAlloc(&c->vx_Xold, Bm * K * size_t(c->nx));
+        rc |= devAlloc(&c->vx_Uold, Bm * K * size_t(c->nu));
         rc |= devAlloc(&c->vx_tr, Bm);
         rc |= devAlloc(&c->vx_last, Bm);
         rc |= devAlloc(&c->vx_cost, Bm);
@@ -940,7 +937,6 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
             return SCPP_E_HIP;
     }
     c->B = B;
-    c->mp = *mp;
     c->scvx = *so;
     // the trajectory / parameter set-up is the SC one (same model code); SCvx specifics are applied on top
     scpp_sc_opts sc{};
@@ -957,19 +953,52 @@ int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const
     sc.delta_tol = 0.;
     c->sc = sc;
     c->mode = SCPP_MODE_FOH;
-    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * 14 * sizeof(double), c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * size_t(c->nx) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
     if (!warm_start)
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
-    SCBuffers b = scBuffers(c);
-    const unsigned grid = unsigned((B + 63) / 64);
-    hipLaunchKernelGGL(sc_setup_kernel, dim3(grid), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
-    hipLaunchKernelGGL(scvx_setup_kernel, dim3(grid), dim3(64), 0, c->stream, b, scvxBuffers(c), c->scvx, mp->final_time, warm_start);
+    return SCPP_OK;
+}
+int scvxSetupDone(scpp_hip_ctx *c, double final_time, int B, int warm_start)
+{
+    hipLaunchKernelGGL(scvx_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), scvxBuffers(c), c->scvx, final_time,
+                       warm_start);
     c->sc_ready = false; // the SC entry points must not be mixed with an SCvx set-up
     c->scvx_ready = true;
     c->par_from_ip = true;
     c->last_active = B;
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
+}
+} // namespace
+
+int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                        int B, int warm_start)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKETQUAT || mp->enable_roll_control)
+        return SCPP_E_UNSUPPORTED;
+    if (int rc = scvxSetupCommon(c, so, x_init, B, warm_start))
+        return rc;
+    c->mp = *mp;
+    hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), c->mp, c->sc, warm_start);
+    return scvxSetupDone(c, mp->final_time, B, warm_start);
+}
+
+int scpp_hip_scvx_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                                 int B, int warm_start)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKET2D)
+        return SCPP_E_UNSUPPORTED;
+    if (int rc = scvxSetupCommon(c, so, x_init, B, warm_start))
+        return rc;
+    c->mp2 = *mp;
+    hipLaunchKernelGGL(sc_setup_r2d_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), c->mp2, c->sc, warm_start);
+    return scvxSetupDone(c, mp->final_time, B, warm_start);
 }
 
 namespace
@@ -1004,7 +1033,10 @@ int scvxRound(scpp_hip_ctx *c, Range r)
         return rc;
     const SCBuffers b = scBuffersRange(c, r);
     const SCvxBuffers v = scvxBuffersRange(c, r);
-    hipLaunchKernelGGL((scvx_cost_update_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
+    if (c->model == SCPP_MODEL_ROCKETQUAT)
+        hipLaunchKernelGGL((scvx_cost_update_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
+    else
+        hipLaunchKernelGGL((scvx_cost_update_kernel<Rocket2dModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 
@@ -1042,7 +1074,8 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
         return rc;
     if (int rc = ensurePools(c, 1))
         return rc;
-    const long max_rounds = long(c->scvx.max_iterations) * 64;
+    // an instance is retired at the cap (scvxDecide); max_iterations <= 0: no iteration at all (the initial trajectory comes back)
+    const long max_rounds = c->scvx.max_iterations > 0 ? long(c->scvx.max_iterations) * SCVX_SOLVE_CAP + 8 : 0;
     // One stream (measured: the two-stream skewed pipeline of scpp_hip_sc_solve loses here, rounds late in the run have few
     // active instances and are latency-bound either way).  The host does not wait for a round before enqueueing the next:
     // the active count is read back asynchronously every POLL rounds and looked at one poll later, so the device never
@@ -1070,7 +1103,12 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
         }
     }
     if (c->scvx.nondimensionalize)
-        hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
+    {
+        if (c->model == SCPP_MODEL_ROCKETQUAT)
+            hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
+        else
+            hipLaunchKernelGGL(sc_redim_r2d_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
+    }
     CHECK_HIP(hipStreamSynchronize(c->stream));
     {
         int n = 0;
@@ -1092,22 +1130,29 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
 }
 
 // ---------------------------------------------------------------- SCvx streaming engine (continuous batching)
-int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
-                               int N, int slots, int pools, int *n_converged)
+extern "C++"
 {
-    DeviceGuard guard(c);
-    if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
-        return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKETQUAT)
-        return SCPP_E_UNSUPPORTED;
-    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
-        return SCPP_E_UNSUPPORTED;
+namespace
+{
+int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x, int B)
+{
+    return scpp_hip_scvx_setup(c, mp, so, x, B, 0);
+}
+int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x, int B)
+{
+    return scpp_hip_scvx_setup_rocket2d(c, mp, so, x, B, 0);
+}
+template <class T>
+int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_scvx_opts *so, const double *x_init, int N, int slots,
+                    int pools, int *n_converged)
+{
+    constexpr int NX = T::NX, NU = T::NU;
     const int S = slots > 0 ? (slots < N ? slots : N) : (c->Bmax < N ? c->Bmax : N);
     // the engine's per-slot state is the batch state of scvx_setup: set it up on the first S instances' worth of slots
     // WITHOUT starting them (every slot starts empty and is filled by the first refill)
-    if (int rc = scpp_hip_scvx_setup(c, mp, so, x_init, S, 0))
+    if (int rc = scvxSetupFor(c, mp, so, x_init, S))
         return rc;
-    const size_t K = size_t(c->K), rowd = size_t(streamRowDoubles(c->K, 14, 4));
+    const size_t K = size_t(c->K), rowd = size_t(streamRowDoubles(c->K, NX, NU));
     if (c->q_cap < size_t(N))
     {
         if (c->q_xinit)
@@ -1117,7 +1162,7 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
         c->q_xinit = c->q_rows = nullptr;
         c->q_cap = 0;
         int a = 0;
-        a |= devAlloc(&c->q_xinit, size_t(N) * 14);
+        a |= devAlloc(&c->q_xinit, size_t(N) * NX);
         a |= devAlloc(&c->q_rows, size_t(N) * rowd);
         if (a)
             return SCPP_E_HIP;
@@ -1133,7 +1178,7 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     }
     (void)K;
     c->q_N = N;
-    CHECK_HIP(hipMemcpyAsync(c->q_xinit, x_init, size_t(N) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->q_xinit, x_init, size_t(N) * NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHECK_HIP(hipMemsetAsync(c->q_counters, 0, 4 * sizeof(int), c->stream));
     CHECK_HIP(hipMemsetAsync(c->q_slot_inst, 0xFF, size_t(c->Bmax) * sizeof(int), c->stream)); // -1: empty
     CHECK_HIP(hipMemsetAsync(c->active, 0, size_t(c->Bmax) * sizeof(int), c->stream));
@@ -1183,7 +1228,7 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     q.nconv = c->q_counters + 2;
     scpp_sc_opts sc = c->sc; // as built by scvx_setup
     // an instance needs at most max_iterations accepted + ~log2 rejected solves each; the queue drains in ceil(N/S) waves
-    const long per_instance = long(so->max_iterations) * 64;
+    const long per_instance = long(so->max_iterations) * SCVX_SOLVE_CAP + 8; // an instance is retired at the cap (scvxDecide)
     const long max_rounds = per_instance * ((N + S - 1) / S + 1);
     constexpr int POLL = 4;
     bool pending = false;
@@ -1210,7 +1255,7 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
             StreamQueue qp = q;
             qp.slot_inst = c->q_slot_inst + r.first;
             qp.warm = c->ipm_warm + r.first;
-            hipLaunchKernelGGL(scvx_stream_refill_kernel, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, qp, *mp, sc, *so);
+            hipLaunchKernelGGL((scvx_stream_refill_kernel<T>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, qp, *mp, sc, *so);
             if (int rc = scvxRound(c, r))
                 return fail(rc);
         }
@@ -1256,6 +1301,30 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
         return fail(SCPP_E_STATE);
     return SCPP_OK;
 }
+} // namespace
+} // extern "C++"
+
+int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                               int N, int slots, int pools, int *n_converged)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKETQUAT || mp->enable_roll_control)
+        return SCPP_E_UNSUPPORTED;
+    return scvxSolveStream<RefillRocketQuat>(c, mp, so, x_init, N, slots, pools, n_converged);
+}
+
+int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                                        int N, int slots, int pools, int *n_converged)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
+        return SCPP_E_ARG;
+    if (c->model != SCPP_MODEL_ROCKET2D)
+        return SCPP_E_UNSUPPORTED;
+    return scvxSolveStream<RefillRocket2d>(c, mp, so, x_init, N, slots, pools, n_converged);
+}
 
 int scpp_hip_stream_rows(scpp_hip_ctx *c, void **rows, int *row_doubles, int *n)
 {
@@ -1267,7 +1336,7 @@ int scpp_hip_stream_rows(scpp_hip_ctx *c, void **rows, int *row_doubles, int *n)
     if (rows)
         *rows = c->q_rows;
     if (row_doubles)
-        *row_doubles = streamRowDoubles(c->K, 14, 4);
+        *row_doubles = streamRowDoubles(c->K, c->nx, c->nu);
     if (n)
         *n = c->q_N;
     return SCPP_OK;
@@ -1291,7 +1360,7 @@ int scpp_hip_stream_download(scpp_hip_ctx *c, double *rows, int first, int count
         return SCPP_E_ARG;
     if (!c->q_rows || first + count > c->q_N)
         return SCPP_E_STATE;
-    const size_t rowd = size_t(streamRowDoubles(c->K, 14, 4));
+    const size_t rowd = size_t(streamRowDoubles(c->K, c->nx, c->nu));
     CHECK_HIP(hipStreamSynchronize(c->stream));
     CHECK_HIP(hipMemcpy(rows, c->q_rows + size_t(first) * rowd, size_t(count) * rowd * sizeof(double), hipMemcpyDeviceToHost));
     return SCPP_OK;

@@ -15,6 +15,8 @@
 namespace scpp
 {
 
+constexpr int SCVX_SOLVE_CAP = 64; // sub-problem solves per configured iteration before an instance is retired (see scvxDecide)
+
 struct SCvxBuffers
 {
     double *Xold, *Uold;       // candidate backup (td = old_td on rejection); filled by ipm_kernel before it overwrites X / U
@@ -107,6 +109,15 @@ __device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const
                 restore = 1; // td = old_td ; re-solve without re-discretising
                 v.needs_disc[i] = 0;
                 code = 0.;
+                // The reference's `while (true)` (SCvxAlgorithm.cpp:75-153) has no exit but acceptance.  With the shipped Rocket2D
+                // SCvx.info (SI units, radius 5) the radius collapses and some start states are rejected over and over (the
+                // candidate creeps, dJ stays < 0): a batched engine cannot spin with them, so an instance is retired with
+                // status SCPP_STATUS_REJECTION_CAP once it has used SCVX_SOLVE_CAP x max_iterations sub-problem solves (build-defined).
+                if (v.solves[i] >= SCVX_SOLVE_CAP * so.max_iterations)
+                {
+                    b.status[i] = SCPP_STATUS_REJECTION_CAP;
+                    b.active[i] = 0;
+                }
             }
             else
             {
@@ -225,7 +236,7 @@ __global__ void __launch_bounds__(WAVE) scvx_cost_update_kernel(SCBuffers b, SCv
 }
 
 // ---------------------------------------------------------------- streaming engine
-// result row of one instance (doubles): X [K][14], U [K][4] (dimensional), then the scalars below
+// result row of one instance (doubles): X [K][nx], U [K][nu] (dimensional), then the scalars below
 enum StreamRow
 {
     SR_SIGMA = 0,
@@ -245,7 +256,7 @@ __host__ __device__ inline int streamRowDoubles(int K, int nx, int nu) { return 
 struct StreamQueue
 {
     int N;                 // instances in the job
-    const double *x_init;  // [N][14] dimensional initial states
+    const double *x_init;  // [N][nx] dimensional initial states
     double *rows;          // [N][streamRowDoubles]
     int *head;             // next instance id to hand out
     int *done;             // instances whose row has been written
@@ -254,12 +265,40 @@ struct StreamQueue
     int *warm;             // [B] interior-point warm-start flag of the slot
 };
 
+// What the refill kernel needs to know about a model: its C-ABI parameter struct, the cold start of one instance and the
+// factors that redimensionalise a result row.
+struct RefillRocketQuat
+{
+    using Params = scpp_rocketquat_params;
+    static constexpr int NX = 14, NU = 4;
+    static __device__ void coldStart(const SCBuffers &b, const Params &mp, const scpp_sc_opts &sc, long slot, const double *xi, int lane)
+    {
+        scSetupOne(b, mp, sc, 0, slot, xi, lane, WAVE);
+    }
+    static __device__ double rx(int j, double ms, double rs) { return redimX(j, ms, rs); }
+    static __device__ double ru(int j, double ms, double rs) { return redimU(j, ms, rs); }
+};
+struct RefillRocket2d
+{
+    using Params = scpp_rocket2d_params;
+    static constexpr int NX = 6, NU = 2;
+    static __device__ void coldStart(const SCBuffers &b, const Params &mp, const scpp_sc_opts &sc, long slot, const double *xi, int lane)
+    {
+        if (lane == 0)
+            scSetupOneR2d(b, mp, sc, 0, slot, xi);
+    }
+    static __device__ double rx(int j, double, double rs) { return j < 4 ? rs : 1.; }        // rocket2d.cpp:108-118
+    static __device__ double ru(int j, double ms, double rs) { return j == 1 ? ms * rs : 1.; }
+};
+
 // One wavefront per slot, at the top of every round: harvest a terminated instance (redimensionalised row -> rows[inst]),
-// then pull the next instance id off the queue and run its cold start (scSetupOne + scvxSetupOne spread over the lanes).
-__global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, SCvxBuffers v, StreamQueue q, scpp_rocketquat_params mp,
+// then pull the next instance id off the queue and run its cold start (the model's set-up + scvxSetupOne).
+template <class T>
+__global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, SCvxBuffers v, StreamQueue q, typename T::Params mp,
                                                                    scpp_sc_opts sc, scpp_scvx_opts so)
 {
     using namespace ipm;
+    constexpr int NX = T::NX, NU = T::NU;
     const long slot = blockIdx.x;
     if (slot >= b.B || b.active[slot] != 0)
         return;
@@ -269,14 +308,14 @@ __global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, S
     {
         const double *ip = b.ip + slot * IP_N;
         const double ms = so.nondimensionalize ? ip[IP_MSCALE] : 1., rs = so.nondimensionalize ? ip[IP_RSCALE] : 1.;
-        double *row = q.rows + size_t(inst) * streamRowDoubles(K, 14, 4);
-        for (int e = lane; e < K * 14; e += WAVE)
-            row[e] = b.X[slot * K * 14 + e] * redimX(e % 14, ms, rs);
-        for (int e = lane; e < K * 4; e += WAVE)
-            row[K * 14 + e] = b.U[slot * K * 4 + e] * redimU(e % 4, ms, rs);
+        double *row = q.rows + size_t(inst) * streamRowDoubles(K, NX, NU);
+        for (int e = lane; e < K * NX; e += WAVE)
+            row[e] = b.X[slot * K * NX + e] * T::rx(e % NX, ms, rs);
+        for (int e = lane; e < K * NU; e += WAVE)
+            row[K * NX + e] = b.U[slot * K * NU + e] * T::ru(e % NU, ms, rs);
         if (lane == 0)
         {
-            double *s = row + K * 18;
+            double *s = row + K * (NX + NU);
             s[SR_SIGMA] = b.sigma[slot];
             s[SR_NU] = b.norm1_nu[slot];
             s[SR_COST] = v.last_cost[slot];
@@ -306,8 +345,8 @@ __global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, S
     next = __shfl(next, 0);
     if (next >= 0)
     {
-        const double *xi = q.x_init + size_t(next) * 14;
-        scSetupOne(b, mp, sc, 0, slot, xi, lane, WAVE);
+        const double *xi = q.x_init + size_t(next) * NX;
+        T::coldStart(b, mp, sc, slot, xi, lane);
         if (lane == 0)
         {
             scvxSetupOne(b, v, so, mp.final_time, 0, slot);

@@ -117,7 +117,9 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 #define INVCHOL_UNROLL _Pragma("unroll")
 #endif
 #ifndef INVCHOL_PERMLANE
-#define INVCHOL_PERMLANE 1 // 1: pivot row / column exchanged by v_permlane16/32_swap ; 0: through 2 x 16 doubles of LDS
+#define INVCHOL_PERMLANE 0 // 0: pivot row / column exchanged through 2 x 16 doubles of LDS ; 1: by v_permlane16/32_swap (no LDS at all;
+                           // measured on MI355X, round 3: 3930 vs 4046 converged/s -- 8 swaps + their hazard s_nops per step issue more than the
+                           // LDS round trip costs, the eliminations are not LDS-latency bound)
 #endif
 template <int n>
 INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)

@@ -23,7 +23,7 @@ class Rocket2d
 public:
     static constexpr int state_dim = 6, input_dim = 2, param_dim = 6;
     static constexpr int model_id = SCPP_MODEL_ROCKET2D;
-    static constexpr bool has_scvx = false; // the reference ships no SCvx.info for this model
+    static constexpr bool has_scvx = true; // scpp_models/config/Rocket2D/SCvx.info
     using state_vector_t = std::array<double, 6>;
     using input_vector_t = std::array<double, 2>;
     using param_vector_t = std::array<double, 6>;

@@ -331,7 +331,13 @@ private:
     {
         return scpp_hip_scvx_setup(ctx, &m.p.abi, &opts, x, B, warm ? 1 : 0);
     }
-    int scvxSetup(const scpp::models::Rocket2d &, const double *, int, bool) { return SCPP_E_UNSUPPORTED; }
+    int scvxSetup(const scpp::models::Rocket2d &m, const double *x, int B, bool warm)
+    {
+        if (!m.p.constrain_initial_final)
+            return SCPP_E_UNSUPPORTED; // model.info:55-56: "enable for SC and disable for MPC/LQR"
+        const scpp_rocket2d_params a = m.abi();
+        return scpp_hip_scvx_setup_rocket2d(ctx, &a, &opts, x, B, warm ? 1 : 0);
+    }
     int batch_max, device, K_override;
     scpp_hip_ctx *ctx = nullptr;
     trajectory_data_t td;

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from ._lib import MODEL_ROCKETQUAT, Context, SCvxOpts
+from ._lib import Context, SCvxOpts
 from .parameter_server import ParameterServer
 
 
@@ -38,17 +38,18 @@ class SCvxAlgorithm:
 
     def initialize(self):
         """SCvxAlgorithm::initialize (SCvxAlgorithm.cpp:46-59): allocates the device context."""
-        self.ctx = Context(MODEL_ROCKETQUAT, self.opts.K, self.batch_max, self.device, self.library)
+        self.ctx = Context(self.model.model_id, self.opts.K, self.batch_max, self.device, self.library)
         return self
 
     def solve(self, x_init=None, warm_start=False):
-        """SCvxAlgorithm::solve for every row of x_init [B][14] (dimensional). Returns #converged."""
+        """SCvxAlgorithm::solve for every row of x_init [B][state_dim] (dimensional). Returns #converged.  Model-generic like
+        the reference's SCvxAlgorithm (SCvxAlgorithm.cpp:46-59): RocketQuat and Rocket2D (scpp_models/config/Rocket2D/SCvx.info)."""
         if x_init is None:
             x_init = self.model.x_init[None, :]
         x_init = np.atleast_2d(np.asarray(x_init, dtype=np.float64))
         if not warm_start:
             self.opts = load_scvx_opts(self.model.getParameterFolder(), self.opts.K, self._max_iterations)
-        self.ctx.scvx_setup(self.model.p, self.opts, x_init, warm_start=warm_start)
+        self.ctx.scvx_setup(self.model.sc_params(), self.opts, x_init, warm_start=warm_start)
         return self.ctx.scvx_solve()
 
     def solveStream(self, x_init, slots=0, pools=0):
@@ -56,7 +57,7 @@ class SCvxAlgorithm:
         finished slots are refilled from the queue on the device.  Returns #converged; results via getStreamSolution()."""
         x_init = np.atleast_2d(np.asarray(x_init, dtype=np.float64))
         self.opts = load_scvx_opts(self.model.getParameterFolder(), self.opts.K, self._max_iterations)
-        return self.ctx.scvx_solve_stream(self.model.p, self.opts, x_init, slots=slots, pools=pools)
+        return self.ctx.scvx_solve_stream(self.model.sc_params(), self.opts, x_init, slots=slots, pools=pools)
 
     def getStreamSolution(self, first=0, count=None):
         return self.ctx.stream_download(first, count)

@@ -253,12 +253,17 @@ class SC:
 class SCvx:
     """Oracle SCvxAlgorithm handle for RocketQuat (oracle/scvx.hpp: SCvxProblem.cpp:6-71, SCvxAlgorithm.cpp:22-278)."""
 
-    def __init__(self, K=0, config_root=CONFIG_ROOT):
-        lib().oracle_scvx_create.restype = C.c_void_p
-        self.h = lib().oracle_scvx_create(config_root.encode(), int(K))
+    def __init__(self, K=0, config_root=CONFIG_ROOT, model=ROCKETQUAT):
+        lib().oracle_scvx_create_model.restype = C.c_void_p
+        self.model = model
+        self.h = lib().oracle_scvx_create_model(int(model), config_root.encode(), int(K))
         if not self.h:
             raise RuntimeError("oracle_scvx_create failed")
         self.h = C.c_void_p(self.h)
+
+    def set_x_init(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().oracle_scvx_set_x_init(self.h, _p(x))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -291,8 +296,9 @@ class SCvx:
 
     def iterate(self, idx=-1):
         m = self.meta()
-        X = np.zeros((m["K"], 14))
-        U = np.zeros((m["nU"], 4))
+        nx, nu, _ = dims(self.model)
+        X = np.zeros((m["K"], nx))
+        U = np.zeros((m["nU"], nu))
         t = C.c_double(0)
         assert lib().oracle_scvx_get_iterate(self.h, int(idx), _p(X), _p(U), C.byref(t)) == 0
         return X, U, t.value

@@ -42,10 +42,16 @@ def device_path(alg, x0, max_iterations):
 
 
 def audit_instance(oracle, K, seed, instance_id, path, b, alpha, lit_tol=1e-9):
-    """check_point of every accepted sub-problem of instance b (= randomised instance `instance_id` of `seed`)."""
+    """check_point of every accepted sub-problem of instance b (= randomised RocketQuat instance `instance_id` of `seed`)."""
     s = oracle.SCvx(K=K)
     s.randomize(seed, instance_id)
     s.set_tolerances(lit_tol, lit_tol, lit_tol, 200)
+    return audit_rows(s, path, b, alpha)
+
+
+def audit_rows(s, path, b, alpha):
+    """check_point of every accepted sub-problem of instance b of `path` with the oracle handle `s` (any model; its x_init must
+    be instance b's)."""
     rows = []
     Xb, Ub = path[0]["X"][b], path[0]["U"][b]
     r_prev, solves_prev = float(path[0]["radius"][b]), 0

@@ -263,3 +263,88 @@ def test_emu_scvx_literal_audit_of_the_device_path(oracle, model, emu_lib):
     assert r["worst_eq"] <= 1e-9 and r["worst_lp"] >= -1e-9 and r["worst_cone"] >= -1e-9
     assert r["gap_median"] <= 1e-6 and r["gap_max"] <= 5e-5 and r["gap_min_signed"] >= -1e-6
     assert r["relX_max"] <= 1e-5
+
+
+def _rocket2d_scvx_case(oracle, lib, K, tmp_path, maxit=None):
+    """Rocket2D under SCvx (the reference ships scpp_models/config/Rocket2D/SCvx.info; SCvxAlgorithm is model-generic,
+    SCvxAlgorithm.cpp:46-59): the SCvx mode of the device solver instantiated for Rocket2d's constraint table
+    (scpp_hip_scvx_setup_rocket2d / _solve_stream_rocket2d).  Checker: the oracle's LITERAL run (there is no structured twin for
+    this model).  Two configurations: the shipped one (SI units, trust radius 5 on [rad, N]: neither run converges, the radius
+    collapses -- both sides must say so, and every accepted device iterate must be feasible and eps-optimal in the literal
+    sub-problem) and the same file with `nondimensionalize true`, which converges: there device and literal run take the same
+    decisions and end at the same trajectory."""
+    import os
+    import shutil
+
+    import scvx_audit
+
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    p = cfg / "Rocket2D" / "SCvx.info"
+    p.write_text(p.read_text().replace("nondimensionalize                   false", "nondimensionalize                   true"))
+    out = {}
+    for name, root in (("nondimensionalised", str(cfg)), ("shipped", None)):
+        m2 = scpp_amd.Rocket2D(root).loadParameters() if root else scpp_amd.Rocket2D().loadParameters()
+        alg = scpp_amd.SCvxAlgorithm(m2, K=K, batch_max=4, library=lib, max_iterations=maxit if name == "shipped" else None).initialize()
+        x0 = np.tile(m2.x_init, (2, 1))
+        x0[1:] = m2.randomized_initial_states(1, first=1)
+        n = alg.solve(x0)
+        o = alg.getSolution()
+        assert (o["status"] == 0).all() and n == int(o["converged"].sum())
+        s = oracle.SCvx(K=K, model=oracle.ROCKET2D, config_root=root or oracle.CONFIG_ROOT); s.set_solver(0)
+        if name == "shipped" and maxit:
+            s.set_max_iterations(maxit)
+        assert s.solve() == 0
+        mm = s.meta()
+        X, U, _ = s.iterate(-1)
+        assert o["converged"][0] == mm["converged"]
+        if name == "nondimensionalised":
+            # same decisions; the trajectories themselves agree only as far as the sub-problems determine them (the states are
+            # outside SCvx's trust region: equal objective, X apart by up to 1e-2 at K = 8, by 1e-9 at K = 12) -> audited below
+            assert mm["converged"] == 1 and o["sc_iters"][0] == mm["iterations"] and o["solves"][0] == mm["solves"]
+        else:
+            assert mm["converged"] == 0 and o["sc_iters"][0] == mm["iterations"] == int(alg.opts.max_iterations)
+            assert o["trust_region"][0] < (1e-6 if maxit is None else 5.0)  # the radius collapses on the device as in the oracle
+        # the streaming engine hands out the same instances and computes the same rows
+        ns = alg.solveStream(x0, slots=1, pools=1)
+        so = alg.getStreamSolution()
+        assert ns == n and (so["instance"] == np.arange(2)).all()
+        for key in ("X", "U", "sigma", "nu_norm", "trust_region", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+            assert np.array_equal(so[key], o[key]), (name, key)
+        out[name] = (alg, x0, o, s)
+    # literal audit of every accepted sub-problem of the nominal instance, both configurations
+    res = {}
+    for name, root in (("nondimensionalised", str(cfg)), ("shipped", None)):
+        alg, x0, o, _ = out[name]
+        path = scvx_audit.device_path(alg, x0[:1], int(alg.opts.max_iterations))
+        s = oracle.SCvx(K=K, model=oracle.ROCKET2D, config_root=root or oracle.CONFIG_ROOT); s.set_tolerances(1e-9, 1e-9, 1e-9, 200)
+        rows = scvx_audit.audit_rows(s, path, 0, alg.opts.alpha)
+        solved = [r for r in rows if r["lit_exitflag"] in (0, 10)]
+        assert len(rows) == int(o["sc_iters"][0]) and len(solved) >= len(rows) - 1
+        scale = 1.0 if name == "nondimensionalised" else 1e5  # SI units: thrust ~ 2e5 N, positions ~ 800 m
+        assert max(r["eq_violation"] for r in rows) <= 1e-9 * scale
+        assert min(r["min_lp_slack"] for r in rows) >= -1e-9 * scale and min(r["min_cone_slack"] for r in rows) >= -1e-9 * scale
+        gaps = np.array([(r["cost"] - r["lit_cost"]) / abs(r["lit_cost"]) for r in solved])
+        assert np.abs(gaps).max() <= 5e-5 and gaps.min() >= -1e-6
+        res[name] = dict(n=len(rows), gap_max=float(np.abs(gaps).max()), relU_max=max(r["relU"] for r in solved), relX_max=max(r["relX"] for r in solved))
+        alg.ctx.close()
+    return res
+
+
+def test_emu_rocket2d_scvx(oracle, emu_lib, tmp_path):
+    _rocket2d_scvx_case(oracle, emu_lib, 8, tmp_path, maxit=5)  # (the GPU test runs the shipped K = 30 / 20 iterations)
+
+
+def test_emu_scvx_rejection_loop_cap(emu_lib):
+    """SCvxAlgorithm::iterate's `while (true)` leaves only through an accepted candidate (SCvxAlgorithm.cpp:75-153).  With the
+    shipped Rocket2D SCvx.info (radius 5 in SI units) some start states never get there once the radius has collapsed; the
+    batched engine retires such an instance after 64 x max_iterations sub-problem solves with status SCPP_STATUS_REJECTION_CAP
+    (-4) instead of spinning, keeps its last accepted iterate, and the streaming engine still hands back every row."""
+    m2 = scpp_amd.Rocket2D().loadParameters()
+    x0 = m2.randomized_initial_states(2, first=1)
+    alg = scpp_amd.SCvxAlgorithm(m2, K=8, batch_max=2, library=emu_lib, max_iterations=1).initialize()
+    n = alg.solveStream(x0, slots=2, pools=1)
+    o = alg.getStreamSolution()
+    assert (o["instance"] == np.arange(2)).all() and n == 0
+    assert (o["solves"] <= 64 * 1 + 1).all() and (o["status"] <= 0).all()
+    alg.ctx.close()
