@@ -50,6 +50,7 @@ enum InstPar
     // delta_k is the constant trust_region, the state rows of the trust cone are zero padding, S = 0 decouples sigma
     IP_SCVX = 52,
     IP_TR = 53,
+    IP_FIXEDT = 54, // != 0: SCAlgorithm with free_final_time false (SCProblem.cpp:33-35,78-100): sigma is not a variable
     IP_N = 56
 };
 

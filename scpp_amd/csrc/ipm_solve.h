@@ -2276,8 +2276,8 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
             for (int i = 0; i < NU; i++)
                 Uo[i] = L::UINV.v[i] >= 0 ? double(st[fW + (L::UINV.v[i] >= 0 ? L::UINV.v[i] : 0)]) : 0.;
         }
-        if (lane == 0 && c.ip[IP_SCVX] == 0.)
-            t.sigma[inst] = sig; // SCvx: fixed final time (the sigma block is a decoupled dummy)
+        if (lane == 0 && c.ip[IP_SCVX] == 0. && c.ip[IP_FIXEDT] == 0.)
+            t.sigma[inst] = sig; // SCvx / SC with free_final_time false: fixed final time (the sigma block is a decoupled dummy)
     }
     if (lane == 0)
     {

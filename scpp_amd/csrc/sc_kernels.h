@@ -68,10 +68,14 @@ __device__ inline void scSetupOne(const SCBuffers &b, const scpp_rocketquat_para
         ip[IP_TMAX] = T_max;
         ip[IP_GIM] = tan(mp.gimbal_max);
         ip[IP_MDRY] = xf[0];
-        ip[IP_WT] = so.weight_time;
-        ip[IP_WTRT] = so.weight_trust_region_time;
+        // free_final_time false (SCProblem.cpp:33-35,78-100): no sigma / delta_sigma in the reference's problem.  Here sigma stays
+        // in the structure as a DECOUPLED dummy block (dS/dsigma = 0 from the fixed-time discretisation, unit weights), exactly
+        // as in SCvx mode, and the solver does not write it back: the final time stays at its configured value.
+        ip[IP_WT] = so.free_final_time ? so.weight_time : 1.;
+        ip[IP_WTRT] = so.free_final_time ? so.weight_trust_region_time : 1.;
         ip[IP_WTRX] = so.weight_trust_region_trajectory;
         ip[IP_WVC] = so.weight_virtual_control;
+        ip[IP_FIXEDT] = so.free_final_time ? 0. : 1.;
         ip[IP_PAR + 0] = mp.alpha_m * r_scale;
         for (int j = 0; j < 3; j++)
         {
@@ -215,10 +219,11 @@ __device__ inline void scSetupOneR2d(const SCBuffers &b, const scpp_rocket2d_par
     ip[IP_TMIN] = T_min;
     ip[IP_TMAX] = T_max;
     ip[IP_GIM] = mp.gimbal_max;
-    ip[IP_WT] = so.weight_time;
-    ip[IP_WTRT] = so.weight_trust_region_time;
+    ip[IP_WT] = so.free_final_time ? so.weight_time : 1.; // fixed final time: decoupled dummy sigma block (see scSetupOne)
+    ip[IP_WTRT] = so.free_final_time ? so.weight_trust_region_time : 1.;
     ip[IP_WTRX] = so.weight_trust_region_trajectory;
     ip[IP_WVC] = so.weight_virtual_control;
+    ip[IP_FIXEDT] = so.free_final_time ? 0. : 1.;
     ip[IP_PAR + 0] = mp.m / m_scale;
     ip[IP_PAR + 1] = mp.J_B / (m_scale * r_scale * r_scale);
     ip[IP_PAR + 2] = mp.g_I[0] / r_scale;

@@ -701,8 +701,8 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKETQUAT)
         return SCPP_E_UNSUPPORTED;
-    /* the device solver implements the configuration SC_oneshot/SC_sim run for RocketQuat */
-    if (so->K != c->K || !so->free_final_time || !so->interpolate_input || mp->enable_roll_control)
+    /* first-order hold, roll control off (the configuration SC_oneshot / SC_sim run for RocketQuat); free or fixed final time */
+    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
@@ -711,7 +711,9 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     c->B = B;
     c->mp = *mp;
     c->sc = *so;
-    c->mode = SCPP_MODE_FOH | SCPP_MODE_VT;
+    c->mode = SCPP_MODE_FOH | (so->free_final_time ? SCPP_MODE_VT : 0);
+    if (!so->free_final_time) // fixed final time (SCProblem.cpp:33-35): dS/dsigma = 0, the discretisation does not write it
+        CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (!warm_start || c->scvx_ready) // cold SC solve (or a context last used in SCvx mode): cold interior-point start
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
@@ -732,8 +734,8 @@ int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, 
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKET2D)
         return SCPP_E_UNSUPPORTED;
-    /* the configuration SC_oneshot runs for Rocket2d: free final time, first-order hold (config/Rocket2D/SC.info) */
-    if (so->K != c->K || !so->free_final_time || !so->interpolate_input)
+    /* first-order hold (config/Rocket2D/SC.info); free or fixed final time */
+    if (so->K != c->K || !so->interpolate_input)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
@@ -742,7 +744,9 @@ int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, 
     c->B = B;
     c->mp2 = *mp;
     c->sc = *so;
-    c->mode = SCPP_MODE_FOH | SCPP_MODE_VT;
+    c->mode = SCPP_MODE_FOH | (so->free_final_time ? SCPP_MODE_VT : 0);
+    if (!so->free_final_time)
+        CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (!warm_start)
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));

@@ -290,7 +290,7 @@ def _rocket2d_scvx_case(oracle, lib, K, tmp_path, maxit=None):
         x0[1:] = m2.randomized_initial_states(1, first=1)
         n = alg.solve(x0)
         o = alg.getSolution()
-        assert (o["status"] == 0).all() and n == int(o["converged"].sum())
+        assert np.isin(o["status"], (0, -4)).all() and o["status"][0] == 0 and n == int(o["converged"].sum())  # -4: rejection-loop cap
         s = oracle.SCvx(K=K, model=oracle.ROCKET2D, config_root=root or oracle.CONFIG_ROOT); s.set_solver(0)
         if name == "shipped" and maxit:
             s.set_max_iterations(maxit)
@@ -348,3 +348,51 @@ def test_emu_scvx_rejection_loop_cap(emu_lib):
     assert (o["instance"] == np.arange(2)).all() and n == 0
     assert (o["solves"] <= 64 * 1 + 1).all() and (o["status"] <= 0).all()
     alg.ctx.close()
+
+
+def _sc_fixed_final_time_case(oracle, lib, tmp_path, KQ, K2):
+    """SCAlgorithm with `free_final_time false` (SCProblem.cpp:33-35,78-100, SCAlgorithm.cpp:25: no sigma / delta_sigma, fixed-time
+    discretisation), both models, against the oracle's LITERAL run of the same configuration: same iteration count and verdict,
+    final time untouched, states within 1e-5; inputs within 1e-5 or certified on the last sub-problem (feasible in the literal
+    problem, objective equal to its optimum: tests/scvx_audit.py)."""
+    import os
+    import re
+    import shutil
+
+    import scvx_audit
+
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    for mname in ("RocketQuat", "Rocket2D"):
+        p = cfg / mname / "SC.info"
+        p.write_text(re.sub(r"free_final_time(\s+)true", r"free_final_time\1false", p.read_text()))
+    res = {}
+    for name, M, OM, K in (("RocketQuat", scpp_amd.RocketQuat, oracle.ROCKETQUAT, KQ), ("Rocket2D", scpp_amd.Rocket2D, oracle.ROCKET2D, K2)):
+        m = M(str(cfg)).loadParameters()
+        alg = scpp_amd.SCAlgorithm(m, K=K, batch_max=1, library=lib).initialize()
+        assert alg.opts.free_final_time == 0
+        x0 = np.atleast_2d(m.x_init)
+        alg.solve(x0)
+        o = alg.getSolution()
+        s = oracle.SC(OM, K=K, config_root=str(cfg)); s.set_solver(0)
+        assert s.solve() == 0
+        mm, inf = s.meta(), s.info()
+        X, U, t = s.solution()
+        assert o["status"][0] == 0 and o["sc_iters"][0] == mm["iterations"] and o["converged"][0] == mm["converged"]
+        assert o["sigma"][0] == t == m.p.final_time  # the final time is not a variable
+        relX = np.abs(o["X"][0] - X).max() / np.abs(X).max()
+        relU = np.abs(o["U"][0] - U).max() / np.abs(U).max()
+        # (||nu||_1 of two independent 15-iteration runs: a derived scalar, 5e-5 apart on the emulator; the certificate below pins
+        #  the last sub-problem's objective, which contains it, to 1e-6)
+        assert relX <= 1e-5 and abs(o["nu_norm"][0] - inf[-1, 0]) <= 2e-4 * max(inf[-1, 0], 1e-3)
+        if relU > 1e-5:
+            doublings = int((inf[:-1, 0] < alg.opts.nu_tol).sum())
+            c = scvx_audit.sc_last_solve_certificate(s, alg, x0[0], int(o["sc_iters"][0]), w_trx=alg.opts.weight_trust_region_trajectory * 2.0 ** doublings)
+            scvx_audit.assert_certificate(c)
+        res[name] = (float(relX), float(relU))
+        alg.ctx.close()
+    return res
+
+
+def test_emu_sc_fixed_final_time(oracle, emu_lib, tmp_path):
+    _sc_fixed_final_time_case(oracle, emu_lib, tmp_path, 10, 12)

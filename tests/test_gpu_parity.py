@@ -693,3 +693,11 @@ def test_rocket2d_scvx_on_gpu(oracle, hip_lib, tmp_path):
     r = _rocket2d_scvx_case(oracle, hip_lib, 30, tmp_path)
     print("Rocket2D SCvx, K=30: " + "; ".join("%s: %d accepted sub-problems audited, objective gap <= %.1e, vs the literal optimum rel dX <= %.1e, "
                                              "rel dU <= %.1e" % (k, v["n"], v["gap_max"], v["relX_max"], v["relU_max"]) for k, v in r.items()))
+
+
+def test_sc_fixed_final_time_on_gpu(oracle, hip_lib, tmp_path):
+    """`free_final_time false` in the SC solver at the BASELINE horizons, both models."""
+    from test_emu_kernels import _sc_fixed_final_time_case
+
+    r = _sc_fixed_final_time_case(oracle, hip_lib, tmp_path, 50, 30)
+    print("SC with fixed final time vs the literal run: " + ", ".join("%s rel dX %.1e rel dU %.1e" % (k, v[0], v[1]) for k, v in r.items()))
