@@ -141,10 +141,32 @@ struct Rocket2dSC
     };
 };
 
+// Zero-order-hold variant of a table (SCProblem.cpp:37-59,116-120 with td.interpolatedInput() == false: K-1 inputs).  The stage
+// structure keeps an input slot at every node; at the LAST node the inputs do not exist -- they are pinned (to 0, which is
+// also what the device stores in U[K-1]) so that every cone / LP row on them drops out and the trust-region cone of that node
+// carries its state part only -- and the table's final-input equalities (`v_U.cols() - 1`) act on node K-2.  C = 0 in the
+// dynamics (the zero-order-hold discretisation writes no C).
+template <class P>
+struct ZeroOrderHold : P
+{
+    static constexpr bool ZOH = true;
+};
+template <class P, class = void>
+struct IsZoh
+{
+    static constexpr bool value = false;
+};
+template <class P>
+struct IsZoh<P, decltype(void(P::ZOH))>
+{
+    static constexpr bool value = P::ZOH;
+};
+
 // ---------------- quantities derived from a table (all constexpr) ----------------
 template <class P>
 struct Derived
 {
+    static constexpr bool ZOH = IsZoh<P>::value;
     static constexpr int NVU = P::NXV + P::NUV; // used stage variables; the rest of the tile is identity padding
     static_assert(NVU <= NV, "a node's free states + inputs must fit one 16-wide MFMA tile");
     static_assert(P::NCONE <= MAXCONES && P::NLP <= MAXLP, "table too large");
@@ -225,9 +247,13 @@ struct Derived
     }
     static constexpr Arr16 XINV = mkXinv(), UINV = mkUinv(), CONE_OFF = mkConeOff(), CONE_DIM = mkConeDim();
     // presolved (constant) stage variables at node k
+    static constexpr unsigned INPUT_MASK = ((1u << NVU) - 1u) & ~((1u << P::NXV) - 1u);
+    // what the table pins at the last node (first-order hold) / at the last node and the last INPUT node K-2 (zero-order hold)
+    static constexpr unsigned FIX_LAST = ZOH ? ((P::FIXED_LAST & ~INPUT_MASK) | INPUT_MASK) : P::FIXED_LAST;
+    static constexpr unsigned FIX_PRE = ZOH ? (P::FIXED_LAST & INPUT_MASK) : 0u;
     __host__ __device__ static constexpr unsigned fixedMask(int k, int K)
     {
-        return PAD_MASK | (k == 0 ? P::FIXED_FIRST : 0u) | (k == K - 1 ? P::FIXED_LAST : 0u);
+        return PAD_MASK | (k == 0 ? P::FIXED_FIRST : 0u) | (k == K - 1 ? FIX_LAST : 0u) | (k == K - 2 ? FIX_PRE : 0u);
     }
     static constexpr bool rowFree(const Row &r, unsigned fm)
     {
@@ -254,11 +280,16 @@ struct Derived
                 a |= 1u << (NCONES + l);
         return a;
     }
-    static constexpr unsigned ACT_FIRST = activeFor(PAD_MASK | P::FIXED_FIRST), ACT_LAST = activeFor(PAD_MASK | P::FIXED_LAST),
-                              ACT_MID = activeFor(PAD_MASK), ACT_BOTH = activeFor(PAD_MASK | P::FIXED_FIRST | P::FIXED_LAST);
+    static constexpr unsigned ACT_FIRST = activeFor(PAD_MASK | P::FIXED_FIRST), ACT_LAST = activeFor(PAD_MASK | FIX_LAST),
+                              ACT_MID = activeFor(PAD_MASK), ACT_BOTH = activeFor(PAD_MASK | P::FIXED_FIRST | FIX_LAST),
+                              ACT_PRE = activeFor(PAD_MASK | FIX_PRE), ACT_FIRST_PRE = activeFor(PAD_MASK | P::FIXED_FIRST | FIX_PRE);
     __host__ __device__ static constexpr unsigned activeMask(int k, int K)
     {
-        return (k == 0 && k == K - 1) ? ACT_BOTH : k == 0 ? ACT_FIRST : k == K - 1 ? ACT_LAST : ACT_MID;
+        return (k == 0 && k == K - 1) ? ACT_BOTH
+               : k == 0               ? (K == 2 ? ACT_FIRST_PRE : ACT_FIRST)
+               : k == K - 1           ? ACT_LAST
+               : k == K - 2           ? ACT_PRE
+                                      : ACT_MID;
     }
     // number of active cone-program rows "D" (degree of the product cone) contributed by node k: one per cone, one per LP row
     static constexpr int popcount(unsigned v)

@@ -842,13 +842,16 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
         for (int j = 0; j < 3; j++)
             st[L::F_UHAT + j] = uhat[size_t(k) * 3 + j];
         // presolved variables (the table's equalTo rows): x_init at the first node, x_final components / zero inputs at the last
+        // (zero-order hold: final-input equalities at node K-2, and the non-existent inputs of node K-1 pinned to 0)
 #pragma unroll
         for (int j = 0; j < L::NVU; j++)
         {
             if (k == 0 && (P::FIXED_FIRST & (1u << j)))
                 st[L::F_W + j] = j < P::NXV ? ip[IP_XINIT + P::XMAP[j < P::NXV ? j : 0]] : 0.;
-            if (k == K - 1 && (P::FIXED_LAST & (1u << j)))
+            if (k == K - 1 && (L::FIX_LAST & (1u << j)))
                 st[L::F_W + j] = j < P::NXV ? ip[IP_XFINAL + P::XMAP[j < P::NXV ? j : 0]] : 0.;
+            if (k == K - 2 && (L::FIX_PRE & (1u << j)))
+                st[L::F_W + j] = 0.;
         }
         Dcount += __builtin_popcount(v.act);
         // identity scalings

@@ -138,6 +138,8 @@ __device__ inline void scSetupOne(const SCBuffers &b, const scpp_rocketquat_para
                 u[j] /= m_scale * r_scale;
             u[3] /= m_scale * r_scale * r_scale;
         }
+        if (!so.interpolate_input && k == K - 1) // zero-order hold: K-1 inputs (trajectoryData.hpp:27-32); the slot of node K-1 is unused
+            u[0] = u[1] = u[2] = u[3] = 0.;
         // updateProblemParameters: thrust_const from the trajectory bound at solve() start
         double *uh = b.uhat + (i * K + k) * 3;
         if (mp.exact_minimum_thrust)
@@ -251,6 +253,8 @@ __device__ inline void scSetupOneR2d(const SCBuffers &b, const scpp_rocket2d_par
                 x[j] /= r_scale;
             u[1] /= m_scale * r_scale;
         }
+        if (!so.interpolate_input && k == K - 1) // zero-order hold: the input slot of node K-1 is unused
+            u[0] = u[1] = 0.;
         double *uh = b.uhat + (i * K + k) * 3; // no linearised-thrust row in this model's table
         uh[0] = 0.;
         uh[1] = 0.;

@@ -369,10 +369,15 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     const bool timed = spanBegin(c, 1, ninst, r.stream);
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
     // one instantiation of the solver per model table (csrc/constraint_table.h)
-    if (rq)
+    const bool zoh = !(c->mode & SCPP_MODE_FOH); // zero-order hold: the table's ZeroOrderHold variant (same record layout)
+    if (rq && !zoh)
         hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
-    else
+    else if (rq)
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+    else if (!zoh)
         hipLaunchKernelGGL(ipm::ipm_kernel<ipm::Rocket2dSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+    else
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::Rocket2dSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
     spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
@@ -701,8 +706,9 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKETQUAT)
         return SCPP_E_UNSUPPORTED;
-    /* first-order hold, roll control off (the configuration SC_oneshot / SC_sim run for RocketQuat); free or fixed final time */
-    if (so->K != c->K || !so->interpolate_input || mp->enable_roll_control)
+    /* roll control off (the configuration SC_oneshot / SC_sim run for RocketQuat); first-order or zero-order hold, free or fixed
+       final time (SCProblem.cpp:33-59,78-100,116-120) */
+    if (so->K != c->K || mp->enable_roll_control)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
@@ -711,9 +717,11 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     c->B = B;
     c->mp = *mp;
     c->sc = *so;
-    c->mode = SCPP_MODE_FOH | (so->free_final_time ? SCPP_MODE_VT : 0);
+    c->mode = (so->interpolate_input ? SCPP_MODE_FOH : 0) | (so->free_final_time ? SCPP_MODE_VT : 0);
     if (!so->free_final_time) // fixed final time (SCProblem.cpp:33-35): dS/dsigma = 0, the discretisation does not write it
         CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
+    if (!so->interpolate_input) // zero-order hold: no C in the dynamics (discretizationData.hpp:56-59)
+        CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * size_t(c->nu) * sizeof(double), c->stream));
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (!warm_start || c->scvx_ready) // cold SC solve (or a context last used in SCvx mode): cold interior-point start
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
@@ -734,8 +742,8 @@ int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, 
         return SCPP_E_ARG;
     if (c->model != SCPP_MODEL_ROCKET2D)
         return SCPP_E_UNSUPPORTED;
-    /* first-order hold (config/Rocket2D/SC.info); free or fixed final time */
-    if (so->K != c->K || !so->interpolate_input)
+    /* first-order or zero-order hold, free or fixed final time */
+    if (so->K != c->K)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
@@ -744,9 +752,11 @@ int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, 
     c->B = B;
     c->mp2 = *mp;
     c->sc = *so;
-    c->mode = SCPP_MODE_FOH | (so->free_final_time ? SCPP_MODE_VT : 0);
+    c->mode = (so->interpolate_input ? SCPP_MODE_FOH : 0) | (so->free_final_time ? SCPP_MODE_VT : 0);
     if (!so->free_final_time)
         CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
+    if (!so->interpolate_input)
+        CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * size_t(c->nu) * sizeof(double), c->stream));
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (!warm_start)
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));

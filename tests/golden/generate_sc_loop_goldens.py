@@ -9,7 +9,7 @@ max_iterations) is driven with scipy's trust-constr on the NLP restatement of ge
 library, no scpp_amd -- at K = 5 and at the reference's shipped K = 15, and ||nu||_1, sum(delta), sigma, delta_sigma and the
 objective of every iteration are recorded in rocketquat_sc_loop_K{5,15}.npz.
 
-  python tests/golden/generate_sc_loop_goldens.py 5 15        (K = 15: ~680 variables per sub-problem, tens of minutes)
+  python tests/golden/generate_sc_loop_goldens.py 5 15:6      (K = 15: ~680 variables per sub-problem, tens of minutes each)
 """
 import os
 import sys
@@ -25,18 +25,42 @@ NU_TOL, DELTA_TOL, MAX_ITERATIONS = 1e-5, 1e-3, 15  # SC.info:8-16
 WEIGHTS = dict(t=1.0, trt=1.0, trx=50.0, vc=1000.0)
 
 
-def run(K):
+def solve_subproblem(pb):
+    """SubProblem.solve of generate_subproblem_goldens.py without its finite-difference check of the cone gradients: from the
+    second SC iteration on the start point IS the trust-region centre, where ||w|| is not differentiable (the check is done at
+    the smooth start of iteration 1 by the K = 5 sub-problem goldens)."""
+    from scipy.optimize import minimize
+
+    cons = [{"type": "eq", "fun": pb.eq, "jac": pb.eq_jac}, {"type": "ineq", "fun": pb.ineq, "jac": pb.ineq_jac}]
+    opts = dict(maxiter=4000, gtol=1e-11, xtol=1e-14, barrier_tol=1e-11, initial_barrier_parameter=0.1)
+    r = minimize(pb.cost, pb.start(), jac=pb.cost_grad, method="trust-constr", constraints=cons, options=opts)
+    r2 = minimize(pb.cost, r.x, jac=pb.cost_grad, method="trust-constr", constraints=cons,
+                  options=dict(opts, initial_barrier_parameter=1e-6, initial_tr_radius=1e-2))
+    print("  trust-constr: pass 0 %d iterations obj %.12f viol %.1e ; pass 1 %d iterations obj %.12f viol %.1e"
+          % (r.nit, r.fun, r.constr_violation, r2.nit, r2.fun, r2.constr_violation), flush=True)
+    return (r2.x, r2) if r2.constr_violation <= max(r.constr_violation, 1e-9) and abs(r2.fun - r.fun) < 1e-4 else (r.x, r)
+
+
+def save(K, rec, sc, converged, max_iterations):
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(K=K, iterations=len(rec["sigma"]), converged=int(converged), x_init=sc["x_init"], m_scale=sc["m_scale"], r_scale=sc["r_scale"],
+               max_iterations_run=max_iterations)
+    np.savez(os.path.join(HERE, "rocketquat_sc_loop_K%d.npz" % K), **out)
+    return out
+
+
+def run(K, max_iterations=MAX_ITERATIONS):
     G.K = K  # the restatement reads its horizon from the module global
     sc = G.scenario()
     Xb, Ub, sb = G.initial_trajectory(sc)
     w = dict(WEIGHTS)
     rec = dict(norm1_nu=[], sum_delta=[], sigma=[], delta_sigma=[], objective=[], weight_trx=[], constr_violation=[], X=[], U=[])
     converged = False
-    for it in range(1, MAX_ITERATIONS + 1):
+    for it in range(1, max_iterations + 1):
         t0 = time.time()
         dd = G.discretize(sc, Xb, Ub, sb, True)
         pb = G.SubProblem(sc, Xb, Ub, sb, dd, "sc", dict(w))
-        v, r = pb.solve()
+        v, r = solve_subproblem(pb)
         X, U, P, M, D, sig, dsg = pb.split(v)
         n1, sd = float((P + M).sum()), float(D.sum())
         rec["norm1_nu"].append(n1); rec["sum_delta"].append(sd); rec["sigma"].append(float(sig)); rec["delta_sigma"].append(float(dsg))
@@ -48,13 +72,16 @@ def run(K):
             w["trx"] *= 2.0  # SCAlgorithm.cpp:112-115
         if sd < DELTA_TOL and n1 < NU_TOL:  # SCAlgorithm.cpp:131
             converged = True
+            save(K, rec, sc, converged, max_iterations)
             break
-    out = {k: np.array(v) for k, v in rec.items()}
-    out.update(K=K, iterations=len(rec["sigma"]), converged=int(converged), x_init=sc["x_init"], m_scale=sc["m_scale"], r_scale=sc["r_scale"])
-    np.savez(os.path.join(HERE, "rocketquat_sc_loop_K%d.npz" % K), **out)
+        save(K, rec, sc, converged, max_iterations)  # (after every iteration: a K = 15 iteration takes tens of minutes)
+    out = save(K, rec, sc, converged, max_iterations)
     print("written rocketquat_sc_loop_K%d.npz: %d iterations, converged %d" % (K, out["iterations"], int(converged)))
 
 
 if __name__ == "__main__":
-    for k in [int(a) for a in sys.argv[1:]] or [5]:
-        run(k)
+    # arguments: K or K:iterations (a K = 15 sub-problem has ~680 variables and takes trust-constr tens of minutes: the record
+    # of the first iterations already shows the stall, ||nu||_1 and sigma settle to 1e-6 by iteration 4-5)
+    for a in sys.argv[1:] or ["5"]:
+        k, _, n = a.partition(":")
+        run(int(k), int(n) if n else MAX_ITERATIONS)

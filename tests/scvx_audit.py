@@ -112,11 +112,12 @@ def sc_last_solve_certificate(handle, alg, x0_row, iters, w_trx=0.0, lit_tol=1e-
     prev = sc_device_iterate(alg, x0_row, iters - 1)
     last = sc_device_iterate(alg, x0_row, iters)
     handle.set_tolerances(lit_tol, lit_tol, lit_tol, 200)
-    c = handle.check_point(prev["X"][0], prev["U"][0], float(prev["sigma"][0]), last["X"][0], last["U"][0], float(last["sigma"][0]),
-                           w_trx=w_trx)
+    nU = handle.meta()["nU"]  # K inputs (first-order hold) or K-1 (zero-order hold: the device's slot K-1 is unused)
+    Up, Ul = np.ascontiguousarray(prev["U"][0][:nU]), np.ascontiguousarray(last["U"][0][:nU])
+    c = handle.check_point(prev["X"][0], Up, float(prev["sigma"][0]), last["X"][0], Ul, float(last["sigma"][0]), w_trx=w_trx)
     if c["lit_exitflag"] in (0, 10):
         c["relX"] = float(np.abs(c["X_lit"] - last["X"][0]).max() / np.abs(last["X"][0]).max())
-        c["relU"] = float(np.abs(c["U_lit"] - last["U"][0]).max() / np.abs(last["U"][0]).max())
+        c["relU"] = float(np.abs(c["U_lit"] - Ul).max() / np.abs(Ul).max())
         c["gap"] = float((c["cost"] - c["lit_cost"]) / abs(c["lit_cost"]))
     c["X"], c["U"], c["sigma"] = last["X"][0], last["U"][0], float(last["sigma"][0])
     return c

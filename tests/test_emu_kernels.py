@@ -350,27 +350,32 @@ def test_emu_scvx_rejection_loop_cap(emu_lib):
     alg.ctx.close()
 
 
-def _sc_fixed_final_time_case(oracle, lib, tmp_path, KQ, K2):
-    """SCAlgorithm with `free_final_time false` (SCProblem.cpp:33-35,78-100, SCAlgorithm.cpp:25: no sigma / delta_sigma, fixed-time
-    discretisation), both models, against the oracle's LITERAL run of the same configuration: same iteration count and verdict,
-    final time untouched, states within 1e-5; inputs within 1e-5 or certified on the last sub-problem (feasible in the literal
-    problem, objective equal to its optimum: tests/scvx_audit.py)."""
+def _sc_variant_case(oracle, lib, tmp_path, KQ, K2, variant):
+    """The SC sub-problem variants buildSCProblem handles beside the shipped one, both models, against the
+    oracle's LITERAL run of the same configuration:
+      "fixed_time": `free_final_time false` (SCProblem.cpp:33-35,78-100, SCAlgorithm.cpp:25: no sigma / delta_sigma, fixed-time
+                    discretisation; on the device sigma stays in the structure as a decoupled dummy block);
+      "zoh":        `interpolate_input false` (SCProblem.cpp:37-59,116-120: K-1 inputs, no C, the last node's trust region has
+                    its state part only; on the device the ZeroOrderHold variant of the constraint table).
+    Same iteration count and verdict, final time equal (fixed) or within 1e-5 (free), states within 1e-5; inputs within 1e-5 or
+    certified on the last sub-problem (feasible in the literal problem, objective equal to its optimum: tests/scvx_audit.py)."""
     import os
     import re
     import shutil
 
     import scvx_audit
 
+    key = {"fixed_time": "free_final_time", "zoh": "interpolate_input"}[variant]
     cfg = tmp_path / "config"
     shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
     for mname in ("RocketQuat", "Rocket2D"):
         p = cfg / mname / "SC.info"
-        p.write_text(re.sub(r"free_final_time(\s+)true", r"free_final_time\1false", p.read_text()))
+        p.write_text(re.sub(key + r"(\s+)true", key + r"\1false", p.read_text()))
     res = {}
     for name, M, OM, K in (("RocketQuat", scpp_amd.RocketQuat, oracle.ROCKETQUAT, KQ), ("Rocket2D", scpp_amd.Rocket2D, oracle.ROCKET2D, K2)):
         m = M(str(cfg)).loadParameters()
         alg = scpp_amd.SCAlgorithm(m, K=K, batch_max=1, library=lib).initialize()
-        assert alg.opts.free_final_time == 0
+        assert getattr(alg.opts, key) == 0
         x0 = np.atleast_2d(m.x_init)
         alg.solve(x0)
         o = alg.getSolution()
@@ -378,12 +383,17 @@ def _sc_fixed_final_time_case(oracle, lib, tmp_path, KQ, K2):
         assert s.solve() == 0
         mm, inf = s.meta(), s.info()
         X, U, t = s.solution()
+        nU = U.shape[0]
+        assert nU == (K - 1 if variant == "zoh" else K) and (variant != "zoh" or not o["U"][0][K - 1].any())
         assert o["status"][0] == 0 and o["sc_iters"][0] == mm["iterations"] and o["converged"][0] == mm["converged"]
-        assert o["sigma"][0] == t == m.p.final_time  # the final time is not a variable
+        if variant == "fixed_time":
+            assert o["sigma"][0] == t == m.p.final_time  # the final time is not a variable
+        else:
+            assert abs(o["sigma"][0] - t) <= 1e-5 * t
         relX = np.abs(o["X"][0] - X).max() / np.abs(X).max()
-        relU = np.abs(o["U"][0] - U).max() / np.abs(U).max()
-        # (||nu||_1 of two independent 15-iteration runs: a derived scalar, 5e-5 apart on the emulator; the certificate below pins
-        #  the last sub-problem's objective, which contains it, to 1e-6)
+        relU = np.abs(o["U"][0][:nU] - U).max() / np.abs(U).max()
+        # (||nu||_1 of two independent 15-iteration runs: a derived scalar, up to 5e-5 apart on the emulator; the certificate below
+        #  pins the last sub-problem's objective, which contains it, to 1e-6)
         assert relX <= 1e-5 and abs(o["nu_norm"][0] - inf[-1, 0]) <= 2e-4 * max(inf[-1, 0], 1e-3)
         if relU > 1e-5:
             doublings = int((inf[:-1, 0] < alg.opts.nu_tol).sum())
@@ -395,4 +405,8 @@ def _sc_fixed_final_time_case(oracle, lib, tmp_path, KQ, K2):
 
 
 def test_emu_sc_fixed_final_time(oracle, emu_lib, tmp_path):
-    _sc_fixed_final_time_case(oracle, emu_lib, tmp_path, 10, 12)
+    _sc_variant_case(oracle, emu_lib, tmp_path, 10, 12, "fixed_time")
+
+
+def test_emu_sc_zero_order_hold(oracle, emu_lib, tmp_path):
+    _sc_variant_case(oracle, emu_lib, tmp_path, 10, 12, "zoh")

@@ -695,9 +695,11 @@ def test_rocket2d_scvx_on_gpu(oracle, hip_lib, tmp_path):
                                              "rel dU <= %.1e" % (k, v["n"], v["gap_max"], v["relX_max"], v["relU_max"]) for k, v in r.items()))
 
 
-def test_sc_fixed_final_time_on_gpu(oracle, hip_lib, tmp_path):
-    """`free_final_time false` in the SC solver at the BASELINE horizons, both models."""
-    from test_emu_kernels import _sc_fixed_final_time_case
+def test_sc_variants_on_gpu(oracle, hip_lib, tmp_path):
+    """`free_final_time false` and zero-order-hold inputs in the SC solver at the BASELINE horizons,
+    both models, against the oracle's literal runs."""
+    from test_emu_kernels import _sc_variant_case
 
-    r = _sc_fixed_final_time_case(oracle, hip_lib, tmp_path, 50, 30)
-    print("SC with fixed final time vs the literal run: " + ", ".join("%s rel dX %.1e rel dU %.1e" % (k, v[0], v[1]) for k, v in r.items()))
+    for variant in ("fixed_time", "zoh"):
+        r = _sc_variant_case(oracle, hip_lib, tmp_path / variant, 50, 30, variant)
+        print("SC variant %s vs the literal run: " % variant + ", ".join("%s rel dX %.1e rel dU %.1e" % (k, v[0], v[1]) for k, v in r.items()))
