@@ -122,6 +122,7 @@ SYMBOLS = [
     "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
     "scpp_hip_mpc_sim_download",
     "scpp_hip_scvx_solve_stream", "scpp_hip_stream_rows", "scpp_hip_stream_download", "scpp_hip_stream_info",
+    "scpp_hip_scvx_setup_rocket2d", "scpp_hip_scvx_solve_stream_rocket2d",
 ]
 
 

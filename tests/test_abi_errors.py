@@ -56,9 +56,10 @@ def test_state_and_argument_errors(raw, model):
     # warm start without a previous solve
     assert raw.scpp_hip_sc_setup(h, C.byref(model.p), C.byref(opts), xp, 4, 1) == E_STATE
     # configurations the device solver does not implement are refused, not silently mis-solved
-    bad = scpp_amd.load_sc_opts(model.getParameterFolder(), 8)
-    bad.free_final_time = 0
-    assert raw.scpp_hip_sc_setup(h, C.byref(model.p), C.byref(bad), xp, 4, 0) == E_UNSUPPORTED
+    # (free_final_time false and zero-order hold are implemented since round 3; roll control is not: 18 stage variables)
+    rollp = type(model.p).from_buffer_copy(model.p)
+    rollp.enable_roll_control = 1
+    assert raw.scpp_hip_sc_setup(h, C.byref(rollp), C.byref(opts), xp, 4, 0) == E_UNSUPPORTED
     bad = scpp_amd.load_sc_opts(model.getParameterFolder(), 9)  # K differs from the context's
     assert raw.scpp_hip_sc_setup(h, C.byref(model.p), C.byref(bad), xp, 4, 0) == E_UNSUPPORTED
     # a good setup, then a mask of the wrong length
