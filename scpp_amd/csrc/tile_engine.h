@@ -116,9 +116,6 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 #ifndef INVCHOL_UNROLL
 #define INVCHOL_UNROLL _Pragma("unroll")
 #endif
-#ifndef INVCHOL_MAXFIRST
-#define INVCHOL_MAXFIRST 0
-#endif
 #ifndef INVCHOL_PERMLANE
 #define INVCHOL_PERMLANE 0 // 0: pivot row / column exchanged through 2 x 16 doubles of LDS ; 1: by v_permlane16/32_swap (no LDS at all;
                            // measured on MI355X, round 3: 3930 vs 4046 converged/s -- 8 swaps + their hazard s_nops per step issue more than the
@@ -166,15 +163,10 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         WAVE_SYNC();
 #endif
         // one batch of LDS reads (no control flow in between)
-#if INVCHOL_MAXFIRST
-        // pivot and its floor live in the SAME lane ((j & 3), j): take the maximum there and broadcast one value -- two readlanes
-        // and the two canonicalising v_max of the wave-uniform fmax less per step, bitwise the same pivot
-        const double dj = rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3];
-        double d = readLane(fmax(dj, od), (j & 3) * 16 + j);
-#else
+        // (taking the maximum in the pivot's own lane before ONE broadcast -- two readlanes and two canonicalising v_max less per
+        //  step, bitwise the same pivot -- was measured in round 3: 3915 vs 3923 converged/s, no difference; not kept)
         double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
         const double floor_ = readLane(od, (j & 3) * 16 + j);
-#endif
 #if !INVCHOL_PERMLANE
         const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
         const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
@@ -198,9 +190,7 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         const double aj = rowGroupDiag(iq == 0 ? cr[0] : iq == 1 ? cr[1] : iq == 2 ? cr[2] : cr[3]);
         const double rj = rowGroupBcast<(j & 3)>(rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3]);
 #endif
-#if !INVCHOL_MAXFIRST
         d = fmax(d, floor_);
-#endif
         const double p = fastRcp(d);
 #pragma unroll
         for (int r = 0; r < 4; r++)
