@@ -161,3 +161,32 @@ def test_mpc_sim_matches_oracle_closed_loop(oracle, host_emu, tmp_path):
     # the shipped model.info (constrain_initial_final true) is refused, as its own comment demands for MPC
     r = subprocess.run([os.path.join(host_emu, "mpc_sim_emu"), "--keep-constraint", "--config", CONFIG], capture_output=True, text=True)
     assert r.returncode == 1 and "constrain_initial_final" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_rccl_all_gather_on_gpu(model, hip_lib):
+    """The torch-free multi-GPU driver (host/scvx_multi_gpu.cpp: one process, one context + one RCCL communicator per device,
+    ncclAllGather of the device-resident result rows in chunks) on the one GPU of the test box: 96 SCvx instances through 32
+    slots, gathered with 3 collectives; the executable itself checks gathered == shard rows bitwise (exit code), and its
+    converged count / checksum must equal the Python front end's streaming run of the same instances."""
+    import re
+
+    import __graft_entry__ as g
+    import scpp_amd
+
+    g.build_host()
+    exe = os.path.join(HOST, "scvx_multi_gpu")
+    N = 96
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "--batch", str(N), "--gpus", "1", "--slots", "32", "--chunk-mb", "0.25", "--config", CONFIG], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bitwise: yes" in r.stdout and "3 collective(s)" in r.stdout, r.stdout
+    conv = int(re.search(r"converged (\d+) \(engine counters (\d+)\)", r.stdout).group(1))
+    cs = float(re.search(r"checksum X (\S+)", r.stdout).group(1))
+    alg = scpp_amd.SCvxAlgorithm(model, K=50, batch_max=32, library=hip_lib).initialize()
+    n = alg.solveStream(model.randomized_initial_states(N), slots=32)
+    o = alg.getStreamSolution()
+    assert n == conv and abs(float(o["X"].sum()) - cs) <= 1e-9 * abs(cs)
+    alg.ctx.close()
+    print(r.stdout.strip().replace("\n", " | "))
