@@ -75,7 +75,9 @@ public:
         ps.loadScalar("K", opts.K);
         ps.loadScalar("nondimensionalize", nd);
         ps.loadScalar("weight_time", opts.weight_time);
-        ps.loadScalar("weight_trust_region_time", opts.weight_trust_region_time);
+        opts.weight_trust_region_time = 0.;
+        if (fft) // SCAlgorithm.cpp:42-45: only read (and only present) for a free final time
+            ps.loadScalar("weight_trust_region_time", opts.weight_trust_region_time);
         ps.loadScalar("weight_trust_region_trajectory", opts.weight_trust_region_trajectory);
         ps.loadScalar("weight_virtual_control", opts.weight_virtual_control);
         ps.loadScalar("nu_tol", opts.nu_tol);
@@ -179,13 +181,14 @@ private:
         for (int b = 0; b < B; b++)
         {
             trajectory_data_t &t = out.td[size_t(b)];
-            t.initialize(K, true);
+            t.initialize(K, opts.interpolate_input != 0); // zero-order hold: K - 1 inputs (trajectoryData.hpp:27-32); device slot K-1 unused
             for (size_t k = 0; k < K; k++)
             {
                 for (size_t j = 0; j < NX; j++)
                     t.X[k][j] = X[(size_t(b) * K + k) * NX + j];
-                for (size_t j = 0; j < NU; j++)
-                    t.U[k][j] = U[(size_t(b) * K + k) * NU + j];
+                if (k < t.U.size())
+                    for (size_t j = 0; j < NU; j++)
+                        t.U[k][j] = U[(size_t(b) * K + k) * NU + j];
             }
             t.t = sigma[size_t(b)];
         }
@@ -198,7 +201,10 @@ private:
         trajectory_data_t t = r.td[0];
         if (redimensionalize && opts.nondimensionalize)
             for (size_t k = 0; k < t.X.size(); k++)
-                Model::redimensionalize(t.X[k], t.U[k], scale_m, scale_r);
+            {
+                Model::input_vector_t none{}; // zero-order hold: no input at the last node
+                Model::redimensionalize(t.X[k], k < t.U.size() ? t.U[k] : none, scale_m, scale_r);
+            }
         return t;
     }
 

@@ -49,6 +49,35 @@ def test_sc_oneshot_writes_reference_output_tree(oracle, host_emu, tmp_path):
         assert abs(tf - t) <= 2e-5 * abs(t)
 
 
+def test_sc_oneshot_zero_order_hold_and_fixed_time_configuration(oracle, host_emu, tmp_path):
+    """A configuration with `interpolate_input false` and `free_final_time false` (and no weight_trust_region_time entry, which
+    the reference only reads for a free final time, SCAlgorithm.cpp:42-45) through the C++ front end: U.txt has K - 1 rows
+    (trajectoryData.hpp:27-32), t.txt keeps the configured final time, the trajectory is the oracle's literal run."""
+    import re
+    import shutil
+
+    K = 8
+    cfg = tmp_path / "config"
+    shutil.copytree(CONFIG, cfg)
+    p = cfg / "RocketQuat" / "SC.info"
+    txt = re.sub(r"interpolate_input(\s+)true", r"interpolate_input\1false", p.read_text())
+    txt = re.sub(r"free_final_time(\s+)true", r"free_final_time\1false", txt)
+    txt = "\n".join(l for l in txt.splitlines() if not l.startswith("weight_trust_region_time"))
+    p.write_text(txt + "\n")
+    subprocess.check_output([os.path.join(host_emu, "sc_oneshot_emu"), "--K", str(K), "--config", str(cfg), "--out", str(tmp_path)], text=True)
+    run = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SC" / "*"))[0]
+    last = max(int(os.path.basename(d)) for d in glob.glob(os.path.join(run, "*")))
+    Xf, Uf = _read(os.path.join(run, str(last), "X.txt")), _read(os.path.join(run, str(last), "U.txt"))
+    assert Xf.shape == (K, 14) and Uf.shape == (K - 1, 4)
+    assert float(open(os.path.join(run, str(last), "t.txt")).read()) == 12.0
+    sc = oracle.SC(oracle.ROCKETQUAT, K=K, config_root=str(cfg)); sc.set_solver(0)
+    assert sc.solve() == 0
+    X, U, t = sc.solution()
+    assert U.shape == (K - 1, 4) and t == 12.0
+    assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
+    assert np.allclose(Uf, U, rtol=1e-3, atol=1e-3 * np.abs(U).max())  # CSV: 6 significant digits; two independent 15-iteration runs
+
+
 def test_sc_oneshot_batch_and_sc_sim(oracle, host_emu, tmp_path):
     K = 8
     out = subprocess.check_output([os.path.join(host_emu, "sc_oneshot_emu"), "--K", str(K), "--batch", "3", "--config", CONFIG, "--out", str(tmp_path)], text=True)
