@@ -25,20 +25,68 @@ NU_TOL, DELTA_TOL, MAX_ITERATIONS = 1e-5, 1e-3, 15  # SC.info:8-16
 WEIGHTS = dict(t=1.0, trt=1.0, trx=50.0, vc=1000.0)
 
 
-def solve_subproblem(pb):
-    """SubProblem.solve of generate_subproblem_goldens.py without its finite-difference check of the cone gradients: from the
-    second SC iteration on the start point IS the trust-region centre, where ||w|| is not differentiable (the check is done at
-    the smooth start of iteration 1 by the K = 5 sub-problem goldens)."""
-    from scipy.optimize import minimize
+def lagrangian_hessian(pb):
+    """v, multipliers -> sum_i lambda_i Hessian(c_i)(v) for the inequality rows of SubProblem.ineq (sparse).  The linear rows have
+    none; a cone row c = t - sqrt(sum_j w_j^2 + eps^2) with affine w_j = const + a_j'v has
+        Hessian = -( sum_j a_j a_j' / n  -  g g' / n^3 ),  g = sum_j w_j a_j,  n = sqrt(sum w_j^2 + eps^2);
+    the delta_sigma row c = v[idx] - f^2 has -2 a_f a_f'.  With exact second derivatives trust-constr is a Newton interior-point
+    method (its default, a quasi-Newton estimate of this matrix, needs thousands of iterations at K = 15 and stalls at the
+    non-smooth trust-region centres of the later SC iterations)."""
+    import scipy.sparse as sp
 
-    cons = [{"type": "eq", "fun": pb.eq, "jac": pb.eq_jac}, {"type": "ineq", "fun": pb.ineq, "jac": pb.ineq_jac}]
-    opts = dict(maxiter=4000, gtol=1e-11, xtol=1e-14, barrier_tol=1e-11, initial_barrier_parameter=0.1)
-    r = minimize(pb.cost, pb.start(), jac=pb.cost_grad, method="trust-constr", constraints=cons, options=opts)
-    r2 = minimize(pb.cost, r.x, jac=pb.cost_grad, method="trust-constr", constraints=cons,
+    lin, soc = pb._forms()
+    n_lin = len(lin)
+
+    def hess(v, lam):
+        rows, cols, vals = [], [], []
+        for c, (t, ws) in enumerate(soc):
+            l = lam[n_lin + c]
+            if l == 0.0:
+                continue
+            wv = [pb._val(w, v) for w in ws]
+            nrm = np.sqrt(sum(x * x for x in wv) + pb.EPS ** 2)
+            g = {}
+            for w, x in zip(ws, wv):
+                for i, cf in w[1]:
+                    g[i] = g.get(i, 0.0) + x * cf
+                    for i2, cf2 in w[1]:
+                        rows.append(i); cols.append(i2); vals.append(-l * cf * cf2 / nrm)
+            gi = list(g.items())
+            for i, a in gi:
+                for i2, b in gi:
+                    rows.append(i); cols.append(i2); vals.append(l * a * b / nrm ** 3)
+        if pb.mode == "sc":
+            idx, f = pb._dsg_row
+            l = lam[n_lin + len(soc)]
+            for i, cf in f[1]:
+                for i2, cf2 in f[1]:
+                    rows.append(i); cols.append(i2); vals.append(-2.0 * l * cf * cf2)
+        return sp.csr_matrix((vals, (rows, cols)), shape=(pb.n, pb.n))
+
+    return hess
+
+
+def solve_subproblem(pb):
+    """The sub-problem by scipy trust-constr with sparse Jacobians and the exact Hessian of the Lagrangian (the objective is
+    linear), cold from SubProblem.start(), then once more from its own solution with the barrier restarted: the objective must
+    not move.  (SubProblem.solve of generate_subproblem_goldens.py -- dense Jacobians, quasi-Newton Hessian -- reaches the same K = 5
+    optimum, 96.48277, in minutes; it does not scale to K = 15.)"""
+    import scipy.sparse as sp
+    from scipy.optimize import LinearConstraint, NonlinearConstraint, minimize
+
+    Je = sp.csr_matrix(pb.eq_jac(np.zeros(pb.n)))
+    be = -pb.eq(np.zeros(pb.n))
+    cons = [LinearConstraint(Je, be, be),
+            NonlinearConstraint(pb.ineq, 0.0, np.inf, jac=lambda v: sp.csr_matrix(pb.ineq_jac(v)), hess=lagrangian_hessian(pb))]
+    zero_h = lambda v: sp.csr_matrix((pb.n, pb.n))
+    # iteration caps: K = 5 needs ~3000 iterations for its first (cold) sub-problem; K = 15 (679 variables) tens of thousands
+    opts = dict(maxiter=3000 if pb.n < 400 else 80000, gtol=1e-10, xtol=1e-14, barrier_tol=1e-11, initial_barrier_parameter=0.1)
+    r = minimize(pb.cost, pb.start(), jac=pb.cost_grad, hess=zero_h, method="trust-constr", constraints=cons, options=opts)
+    r2 = minimize(pb.cost, r.x, jac=pb.cost_grad, hess=zero_h, method="trust-constr", constraints=cons,
                   options=dict(opts, initial_barrier_parameter=1e-6, initial_tr_radius=1e-2))
     print("  trust-constr: pass 0 %d iterations obj %.12f viol %.1e ; pass 1 %d iterations obj %.12f viol %.1e"
           % (r.nit, r.fun, r.constr_violation, r2.nit, r2.fun, r2.constr_violation), flush=True)
-    return (r2.x, r2) if r2.constr_violation <= max(r.constr_violation, 1e-9) and abs(r2.fun - r.fun) < 1e-4 else (r.x, r)
+    return (r2.x, r2) if r2.constr_violation <= max(r.constr_violation, 1e-9) and r2.fun <= r.fun + 1e-6 * abs(r.fun) else (r.x, r)
 
 
 def save(K, rec, sc, converged, max_iterations):
