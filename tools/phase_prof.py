@@ -19,7 +19,7 @@ info = alg.ctx.socp_info()
 names = ["init", "residuals", "scalings", "  factorFused(in 5)", "rhs(t,bx)+kktPrep", "sweeps+kktFinish", "dz/ds/step", "update", "prepareFactor", "  bwdSweeps(in 5)", "  fwdSweep(in 5)", "kernel_total"]
 it = info[:, 4].mean()
 p = info[:, 8:20].mean(axis=0)
-print(f"B={B} mean ipm iters {it:.1f}; cycles are 100 MHz s_memtime ticks? (raw counts)")
+print(f"B={B} mean ipm iters {it:.1f}; counts are clock64() ticks = s_memtime, the shader clock (4096 instances = two generations of 2048 resident wavefronts in the 45.2 ms launch: 39.9 M ticks per wavefront lifetime of ~22.6 ms, i.e. ~1.77 GHz under this load)")
 for n, v in zip(names, p):
     if n != "-":
         print(f"  {n:14s} total {v:14.0f}   per-iter {v / it:12.0f}   share {100 * v / p[11]:5.1f}%")
