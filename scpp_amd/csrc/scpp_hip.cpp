@@ -397,6 +397,63 @@ int ensureWorkspace(scpp_hip_ctx *c)
     return devAlloc(&c->ws, size_t(c->Bmax) * per) ? SCPP_E_HIP : 0;
 }
 
+// ---- create-time self-test of the tile engine on the device the context is created on ----
+// One wavefront: a known SPD 16 x 16 tile (diagonally dominant, entries from a fixed recurrence) goes through the matrix-core
+// product, the inverse-Cholesky elimination (LDS exchange, DPP row broadcasts, v_readlane, hardware reciprocal + Newton) and
+// the LDS transpose -- everything the sweeps of ipm_kernel are built from -- and || Li A Li' - I ||_max comes back.  It is a
+// check of the toolchain + device combination the library is running on (DESIGN.md 4.2 "Toolchain hazard"), run once per
+// process and device; it does not replace the GPU parity suite (the two miscompilations seen so far sat in argument handling of
+// the big kernel, not in the tile engine).
+__global__ void __launch_bounds__(WAVE) tile_selftest_kernel(double *out)
+{
+    using namespace ipm;
+    __shared__ TileShared sh;
+    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+    Tile A;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = g + 4 * r;
+        const double off = 0.5 / double(1 + (row > i ? row - i : i - row)) * (((row + i) & 1) ? -1. : 1.);
+        A.v[r] = row == i ? 4. + 0.25 * row : off; // symmetric, strictly diagonally dominant
+    }
+    const Tile Li = invCholFactor<16>(A, sh, lane);
+    const Tile Lit = transposeTile(Li, sh, lane);
+    // Li A Li' = mm(Lit, mm(A, Lit)) with mm(X, Y) = X'Y and A symmetric
+    const Tile R = mm(Lit, mm(A, Lit));
+    double err = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const double e = fabs(R.v[r] - ((g + 4 * r == i) ? 1. : 0.));
+        err = e > err ? e : err;
+    }
+    err = wave_max(err);
+    if (lane == 0)
+        out[0] = err;
+}
+int tileSelfTest(int device)
+{
+    static std::vector<int> done; // devices that passed in this process
+    for (int d : done)
+        if (d == device)
+            return SCPP_OK;
+    double *d_out = nullptr, h = -1.;
+    if (hipMalloc(reinterpret_cast<void **>(&d_out), sizeof(double)) != hipSuccess)
+        return SCPP_E_HIP;
+    hipLaunchKernelGGL(tile_selftest_kernel, dim3(1), dim3(WAVE), 0, nullptr, d_out);
+    const bool ok = hipMemcpy(&h, d_out, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_out);
+    if (!ok || !(h >= 0. && h < 1e-12))
+    {
+        std::fprintf(stderr, "scpp_hip: tile-engine self-test FAILED on device %d (|Li A Li' - I|_max = %g): this build / device must not be used (%s)\n",
+                     device, h, scpp_hip_version());
+        return SCPP_E_HIP;
+    }
+    done.push_back(device);
+    return SCPP_OK;
+}
+
 int countActive(scpp_hip_ctx *c, int *n)
 {
     hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, c->stream, c->B, (const int *)c->active, c->counter);
@@ -471,6 +528,8 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
                 (void)hipSetDevice(d);
         }
     } restore{prev_device == device_id ? -1 : prev_device};
+    if (int rc = tileSelfTest(device_id))
+        return rc;
     scpp_hip_ctx *c = new (std::nothrow) scpp_hip_ctx;
     if (!c)
         return SCPP_E_HIP;
