@@ -241,6 +241,33 @@ def test_emu_discretize_zero_order_hold(oracle, emu_lib):
     _zoh_case(oracle, emu_lib, 1e-10)
 
 
+def _dd_variant_goldens_case(lib, tol):
+    """discretize_kernel's three other instantiations against the DOP853 goldens of generate_dd_variant_goldens.py (no oracle in
+    between): <FOH, fixed> -- the discretisation of the headline SCvx mode --, <ZOH, VT>, <ZOH, fixed>."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "rocketquat_dd_variants_K15.npz"))
+    K = 15
+    for name, foh, vt in (("foh_fixed", True, False), ("zoh_vt", False, True), ("zoh_fixed", False, False)):
+        ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K, 2, library=lib)
+        ctx.set_flow_params(np.tile(g["par"], (2, 1)))
+        U = g["U"] if foh else g["U"][:K - 1]
+        ctx.upload_traj(np.tile(g["X"], (2, 1, 1)), np.tile(U, (2, 1, 1)), np.full(2, float(g["t"])))
+        ctx.discretize((scpp_amd.MODE_FOH if foh else 0) | (scpp_amd.MODE_VT if vt else 0))
+        out = ctx.download_dd()
+        for n, a in zip("ABCSZ", out):
+            o = g[f"{name}_{n}"]
+            if n == "S" and not vt:
+                continue  # not written for a fixed final time (the SC / SCvx set-up zeroes it)
+            for b in range(2):
+                assert np.abs(a[b] - o).max() <= tol * max(1.0, np.abs(o).max()), (name, n)
+        ctx.close()
+
+
+def test_emu_discretize_variants_match_dop853_goldens(emu_lib):
+    _dd_variant_goldens_case(emu_lib, 1e-9)
+
+
 def test_emu_scvx_literal_audit_of_the_device_path(oracle, model, emu_lib):
     """Every ACCEPTED sub-problem of the device's SCvx path, audited by the oracle's LITERAL (reference-shaped) formulation:
     the device iterate j+1 is feasible, row by row, in the literal problem linearised at the device iterate j (<= 1e-9) and its

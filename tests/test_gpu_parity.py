@@ -454,6 +454,13 @@ def test_discretize_zero_order_hold_on_gpu(oracle, hip_lib):
     _zoh_case(oracle, hip_lib, 1e-9)
 
 
+def test_discretize_variants_match_dop853_goldens_on_gpu(hip_lib):
+    """<FOH, fixed> (the headline SCvx mode's discretisation), <ZOH, VT>, <ZOH, fixed> against goldens generated without the oracle"""
+    from test_emu_kernels import _dd_variant_goldens_case
+
+    _dd_variant_goldens_case(hip_lib, 1e-9)
+
+
 def test_sc_sim_runs_to_the_stop_rule_like_the_oracle(oracle, hip_lib, tmp_path):
     """Receding-horizon loops driven until the reference's own stop rule fires (||x - x_final|| < 0.02 or planned time
     < 0.25 s, SC_sim.cpp:57), against the oracle's driver.  With the shipped 12 s scenario the closed loop never gets there

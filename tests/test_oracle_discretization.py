@@ -38,3 +38,19 @@ def test_variants_fixed_time_consistency(oracle):
     assert np.abs(A1 - A2).max() < 1e-12
     assert np.abs(B1 - B2).max() < 1e-9 * np.abs(B1).max()
     assert np.abs(Z2 - (Z1 + S1 * t)).max() < 1e-11
+
+
+@pytest.mark.parametrize("name,foh,vt", [("foh_fixed", True, False), ("zoh_vt", False, True), ("zoh_fixed", False, False)])
+def test_dd_variants_match_dop853_goldens(oracle, name, foh, vt):
+    """The three other variants of multipleShootingImplementation<FOH, VT> (discretization.cpp:42-55) -- first-order hold with a
+    fixed final time is what SCvx (the headline mode) and SC with free_final_time false discretise with -- against DOP853 goldens
+    generated without the oracle (tests/golden/generate_dd_variant_goldens.py)."""
+    g = np.load(os.path.join(GOLDEN, "rocketquat_dd_variants_K15.npz"))
+    U = g["U"] if foh else g["U"][:-1]
+    out = oracle.discretize(0, g["par"], g["X"], U, float(g["t"]), foh=foh, vt=vt)
+    for n, a in zip("ABCSZ", out):
+        o = g[f"{name}_{n}"]
+        if (n == "C" and not foh) or (n == "S" and not vt):
+            assert not o.any() and (a.size == 0 or not a.any()), n  # empty in the reference (discretizationData.hpp:56-65)
+            continue
+        assert np.abs(a - o).max() <= 1e-10 * max(1.0, np.abs(o).max()), (name, n)
