@@ -374,7 +374,7 @@ def main():
         ipm_iters0 = float(out["ipm_iters"].sum())
         socp_flops = ipm_iters0 * FLOP_PER_IPM_ITER + total * FLOP_PER_SOCP_INIT
         launches = max(tm["n_socp"], 1)
-        # kernel time = length of the UNION of the launches' hipEvent spans on a common time axis (launches of the two slot pools
+        # kernel time = length of the UNION of the launches' hipEvent spans on a common time axis (launches of the slot pools
         # overlap in time: the plain sum of spans exceeds the wall clock).  By construction <= the timed region; asserted.
         span_sum_s = tm["ms_socp"] * 1e-3
         socp_s = tm.get("ms_socp_union", 0.0) * 1e-3 or span_sum_s

@@ -1259,14 +1259,16 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     // pools: disjoint slot ranges, each on its own stream, all pulling from the one queue.  Their rounds drift apart, so the
     // memory-bound interior-point kernel of one pool overlaps the ALU/LDS-bound discretisation of another without any of
     // the explicit skewing scpp_hip_sc_solve needs.
-    // pools == 0 (and no SCPP_STREAM_POOLS): heuristic -- two pools once each of them still fills the chip (>= 2048 slots
-    // = 2048 resident wavefronts), one below that.  An explicit request (argument or environment) is honoured as given and
-    // only clamped to the slot count (a pool has at least one slot) and to 8.
+    // pools == 0 (and no SCPP_STREAM_POOLS): heuristic -- every pool should still fill the chip on its own (>= 2048 slots = 2048
+    // resident wavefronts): three pools from 6144 slots on, two from 4096, one below.  Measured at 8192 slots, same box,
+    // alternating runs (profiles/r03_ab_pools.json): 2 pools 4035, 3 pools 4140 (+2.6 %), 4 pools 3722 converged/s -- with three,
+    // a pool's launch (2731 wavefronts) is 1 1/3 generations of resident wavefronts and its tail overlaps two other pools' kernels.
+    // An explicit request (argument or environment) is honoured as given and only clamped to the slot count and to 8.
     int P = pools;
     if (const char *e = std::getenv("SCPP_STREAM_POOLS"))
         P = std::atoi(e) > 0 ? std::atoi(e) : P;
     if (P <= 0)
-        P = S >= 4096 ? 2 : 1;
+        P = S >= 6144 ? 3 : (S >= 4096 ? 2 : 1);
     if (P > S)
         P = S;
     if (P > 8)
