@@ -191,8 +191,8 @@ extern "C"
        independent instances pushed through `slots` (<= batch_max; 0: batch_max) resident problem slots.  Instances need very
        different numbers of sub-problem solves (accepted + rejected candidates, SCvxAlgorithm.cpp:132-138); a slot whose
        loop has terminated is refilled from the queue at the next round, so the device stays full until the queue is empty.
-       `pools` slot ranges run on their own HIP streams: 0 = heuristic (3 pools from 6144 slots on, 2 from 4096, 1 below: a pool
-       should still fill the chip); an explicit value (or the SCPP_STREAM_POOLS environment variable, which overrides it) is honoured
+       `pools` slot ranges run on their own HIP streams: 0 = heuristic (pools of about 1365 slots = 2/3 of the wavefronts the chip
+       holds: 6 pools at 8192 slots, 3 at 4096, 1 below 2731; measured); an explicit value (or the SCPP_STREAM_POOLS environment variable, which overrides it) is honoured
        and only clamped to the slot count and to 8; scpp_hip_stream_info reports the number used.  A failed job (any return code != 0) has joined all pool streams and invalidated its rows:
        scpp_hip_stream_rows / _download then return SCPP_E_STATE.  Every instance computes exactly what
        scpp_hip_scvx_setup + scpp_hip_scvx_solve compute for it (bitwise), whatever slot it lands in.

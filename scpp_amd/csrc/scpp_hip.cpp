@@ -1259,16 +1259,18 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     // pools: disjoint slot ranges, each on its own stream, all pulling from the one queue.  Their rounds drift apart, so the
     // memory-bound interior-point kernel of one pool overlaps the ALU/LDS-bound discretisation of another without any of
     // the explicit skewing scpp_hip_sc_solve needs.
-    // pools == 0 (and no SCPP_STREAM_POOLS): heuristic -- every pool should still fill the chip on its own (>= 2048 slots = 2048
-    // resident wavefronts): three pools from 6144 slots on, two from 4096, one below.  Measured at 8192 slots, same box,
-    // alternating runs (profiles/r03_ab_pools.json): 2 pools 4035, 3 pools 4140 (+2.6 %), 4 pools 3722 converged/s -- with three,
-    // a pool's launch (2731 wavefronts) is 1 1/3 generations of resident wavefronts and its tail overlaps two other pools' kernels.
+    // pools == 0 (and no SCPP_STREAM_POOLS): heuristic -- pools of about 2/3 of the 2048 wavefronts the chip holds (1365 slots), so
+    // that one and a half ipm_kernel launches are resident at any time and a launch's tail (instances that need more
+    // interior-point iterations) is covered by the next pool's kernels: measured on MI355X, same box, alternating runs
+    // (profiles/r03_ab_pools.json), 8192 slots: 2 pools 4035, 3 pools 4140 / 4017, 4 pools 3722, 5 pools 3914, 6 pools 4070 / 4117,
+    // 7 pools 4022, 8 pools 3482 converged/s (second figures: another box); 4096 slots: 1 pool 3365, 2 pools 3918, 3 pools 4158.
+    // Pool sizes that divide the resident capacity exactly (2048, 1024) are the bad ones.  Below 2731 slots: one pool.
     // An explicit request (argument or environment) is honoured as given and only clamped to the slot count and to 8.
     int P = pools;
     if (const char *e = std::getenv("SCPP_STREAM_POOLS"))
         P = std::atoi(e) > 0 ? std::atoi(e) : P;
     if (P <= 0)
-        P = S >= 6144 ? 3 : (S >= 4096 ? 2 : 1);
+        P = S >= 2731 ? int((double(S) + 682.) / 1365.34) : 1;
     if (P > S)
         P = S;
     if (P > 8)
