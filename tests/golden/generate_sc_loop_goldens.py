@@ -12,8 +12,8 @@ objective of every iteration are recorded in rocketquat_sc_loop_K{5,15}.npz.
   python tests/golden/generate_sc_loop_goldens.py 5
 K = 15 (the reference's shipped horizon, 679 variables per sub-problem) was attempted with the same script (`15:6`): trust-constr did
 not reach the optimum of even the FIRST sub-problem within 80 000 iterations / 30 minutes (objective 189.3, ||nu||_1 0.083, against
-155.2 / 0.0494 found by both oracle solvers and by the device -- a LOWER objective at a feasible point, checked by the literal
-checkPoint), so no K = 15 record is committed; the tests skip K = 15 when the file is absent.  The K = 5 record shows the mechanism
+154.58 / 0.0494 found by both oracle solvers and by the device: a LOWER objective at a point that is feasible in the literal
+problem, oracle/sc.hpp: checkPoint), so no K = 15 record is committed; the tests skip K = 15 when the file is absent.  The K = 5 record shows the mechanism
 of the stall (exact trust-region penalty: the iterate stops moving while ||nu||_1 stays two orders of magnitude above nu_tol).
 """
 import os
