@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -434,7 +435,9 @@ __global__ void __launch_bounds__(WAVE) tile_selftest_kernel(double *out)
 }
 int tileSelfTest(int device)
 {
+    static std::mutex mtx; // contexts of different devices are created from different host threads (host/sc_oneshot --gpus N)
     static std::vector<int> done; // devices that passed in this process
+    std::lock_guard<std::mutex> lock(mtx);
     for (int d : done)
         if (d == device)
             return SCPP_OK;
