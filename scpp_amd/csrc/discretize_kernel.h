@@ -42,6 +42,11 @@ __device__ inline void forEachStage(F &&f)
     forEachStageImpl(f, std::make_integer_sequence<int, RK_S>{});
 }
 
+// fixed RKF78 steps per segment: the reference's integrate_adaptive(stepper, ode, V, 0., dt, dt / 5.) with an uncontrolled
+// stepper takes exactly 5 (discretizationImplementation.hpp:141,154)
+#ifndef DISC_STEPS
+#define DISC_STEPS 5
+#endif
 #ifndef DISC_WAVES_PER_SIMD
 #define DISC_WAVES_PER_SIMD 2
 #endif
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
     constexpr int UHP = NUAUX + 1 + NU;           // per stage time: input-only sub-expressions, t / dt, u(t)
-    __shared__ double uh[5 * RK_S * UHP];
+    __shared__ double uh[DISC_STEPS * RK_S * UHP];
 #define DISC_TABLE_ROWS 1
     // Jacobian entries as a lane-parallel table (Model::JacobianTable): one output per lane per pass instead of one divergent
     // `case` per row; W holds the operands, the partial sums and the outputs [J | f]
@@ -155,8 +160,8 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     {
         // the input is a known function of time: u(t) at each of the 5 x 13 stage times and what the rows need of it alone
         // (|T|, 1/|T| for RocketQuat) are computed once here, one stage time per lane
-        const double hh = dt / 5.;
-        for (int e = lane; e < 5 * RK_S; e += WAVE)
+        const double hh = dt / double(DISC_STEPS);
+        for (int e = lane; e < DISC_STEPS * RK_S; e += WAVE)
         {
             const double tse = double(e / RK_S) * hh + RK_C[e % RK_S] * hh;
             const double fre = FOH ? tse / dt : 0.;
@@ -235,13 +240,13 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 
     double kk[RK_S][EPL];
-    const double h = dt / 5.;
+    const double h = dt / double(DISC_STEPS);
 #ifdef DISC_PROFILE
     long long tA = 0, tB = 0, tC = 0;
     const long long tk0 = clock64();
 #endif
 
-    for (int step = 0; step < 5; step++)
+    for (int step = 0; step < DISC_STEPS; step++)
     {
         const double t0 = double(step) * h;
         // The 13 stages are instantiated with a COMPILE-TIME stage index: the tableau entries become
