@@ -39,7 +39,8 @@ FLOP_PER_IPM_ITER = 2.0e6        # one Mehrotra iteration of one instance: 1 fac
 FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border (cold start: once per instance)
 IPM_ALGO_BYTES_PER_SOLVE = 131712 + 7208 + 7200  # read dd + td, write X, U: what one sub-problem solve must move
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
-DISC_FLOP_PER_INSTANCE = 5.9e7    # 49 seg x 65 RHS x ~18.6 kflop
+DISC_FLOP_PER_RHS = 18.6e3        # one evaluation of the augmented right-hand side (J V on the matrix core + flow map + Jacobian rows)
+DISC_MAX_STEP = 12.0 / (14.0 * 5.0)  # csrc/discretize_kernel.h: n = clamp(ceil(segment seconds / this), 1, 5) RKF78 steps per segment
 PEAK_FP64_TFLOPS = 78.6           # MI355X FP64 vector == FP64 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
 
@@ -400,6 +401,10 @@ def main():
         limiting = ("hbm traffic of the workspace (measured bytes): %.0f GB/s = %.1f %% of peak, against %.1f %% of the FP64 matrix peak"
                     % (measured_gbs, 100 * hbm_frac, 100 * mfma_frac)) if (hbm_frac is not None and hbm_frac > mfma_frac) else "fp64 mfma"
         disc_s = tm.get("ms_discretize_union", 0.0) * 1e-3 or tm["ms_discretize"] * 1e-3
+        # flops the kernel EXECUTES: 13 stages x n steps per segment (the reference's scheme is n = 5 whatever K: 5.9e7 flop at K = 50)
+        import math
+        disc_steps = min(5, max(1, math.ceil(float(model.p.final_time) / (K - 1) / DISC_MAX_STEP)))
+        DISC_FLOP_PER_INSTANCE = (K - 1) * 13 * disc_steps * DISC_FLOP_PER_RHS
         # discretize launches are masked (needs_disc): instances that re-solve after a rejection skip it, so count solves
         line = {
             "metric": "converged SCvx trajectories/sec (RocketQuat, K=50) at 1/2/4/8 MI355X",
@@ -474,7 +479,10 @@ def main():
                     "fp64_TFLOPs": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 if disc_s > 0 else None,
                     "fp64_frac": (g_iters / world) * DISC_FLOP_PER_INSTANCE / disc_s / 1e12 / PEAK_FP64_TFLOPS if disc_s > 0 else None,
                     "hbm_GBs": (g_iters / world) * DISC_BYTES_PER_INSTANCE / disc_s / 1e9 if disc_s > 0 else None,
-                    "bound": "fp64-alu (450 flop/B: HBM is not the binding roof, SURVEY §8(d))",
+                    "rkf78_steps_per_segment": disc_steps,
+                    "flop_per_instance_call": DISC_FLOP_PER_INSTANCE,
+                    "flop_per_instance_call_reference_scheme": (K - 1) * 65 * DISC_FLOP_PER_RHS,
+                    "bound": "fp64-alu (170 .. 450 flop/B: HBM is not the binding roof, SURVEY §8(d))",
                 },
             },
         }

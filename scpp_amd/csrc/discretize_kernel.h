@@ -42,11 +42,23 @@ __device__ inline void forEachStage(F &&f)
     forEachStageImpl(f, std::make_integer_sequence<int, RK_S>{});
 }
 
-// fixed RKF78 steps per segment: the reference's integrate_adaptive(stepper, ode, V, 0., dt, dt / 5.) with an uncontrolled
-// stepper takes exactly 5 (discretizationImplementation.hpp:141,154)
+// RKF78 steps per segment.  The reference takes exactly 5 whatever the segment length (integrate_adaptive(stepper, ode, V, 0., dt,
+// dt / 5.) with an uncontrolled stepper, discretizationImplementation.hpp:141,154): at its own shipped RocketQuat configuration
+// (K = 15, 12 s) that is a step of 0.171 s and leaves ~1e-13 relative in A .. z.  At K = 50 the same 5 steps are 0.049 s long -- an
+// order-8 scheme then integrates to round-off four times over.  The kernel therefore takes
+//      n = clamp(ceil(segment length / DISC_MAX_STEP), 1, DISC_STEPS_MAX)     (wave-uniform, per instance and call)
+// steps: never more than the reference's 5, and never a step longer than the reference's own at the configuration it ships --
+// K = 50, 12 s: 2 steps of 0.122 s, A .. z within 1e-13 of the 5-step result (measured: 3 steps 3.5e-15, 2 steps 1.0e-13, 1 step
+// 2.4e-11; K = 15: 5 steps as the reference); test-enforced against the DOP853 goldens at 1e-9 like before, and against the 5-step
+// kernel at 1e-11.  40 % of the stage evaluations at K = 50: discretize_kernel 4.2 -> 1.9 ms per launch, headline +4.2 % (same box).
+// -DDISC_STEPS=n pins the count (n = 5: the reference's scheme literally).
 #ifndef DISC_STEPS
-#define DISC_STEPS 5
+#define DISC_STEPS 0
 #endif
+#ifndef DISC_MAX_STEP
+#define DISC_MAX_STEP (12. / (14. * 5.)) // seconds: shipped RocketQuat SC.info (K = 15) on the 12 s scenario, 5 steps per segment
+#endif
+constexpr int DISC_STEPS_MAX = 5;
 #ifndef DISC_WAVES_PER_SIMD
 #define DISC_WAVES_PER_SIMD 2
 #endif
@@ -96,7 +108,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
     constexpr int UHP = NUAUX + 1 + NU;           // per stage time: input-only sub-expressions, t / dt, u(t)
-    __shared__ double uh[DISC_STEPS * RK_S * UHP];
+    __shared__ double uh[DISC_STEPS_MAX * RK_S * UHP];
 #define DISC_TABLE_ROWS 1
     // Jacobian entries as a lane-parallel table (Model::JacobianTable): one output per lane per pass instead of one divergent
     // `case` per row; W holds the operands, the partial sums and the outputs [J | f]
@@ -125,6 +137,15 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     const double sg = sigma[inst];
     const double dt = VT ? 1. / double(K - 1) : sg / double(K - 1);
     const double tscale = VT ? sg : 1.;
+    // steps of this segment (see DISC_STEPS above); the segment lasts sg / (K - 1) seconds in both time parametrisations
+    int nsteps = DISC_STEPS;
+    if (DISC_STEPS <= 0)
+    {
+        const double seg_seconds = fabs(sg) / double(K - 1);
+        nsteps = int(ceil(seg_seconds / DISC_MAX_STEP));
+        nsteps = nsteps < 1 ? 1 : (nsteps > DISC_STEPS_MAX ? DISC_STEPS_MAX : nsteps);
+    }
+    nsteps = uniformInt(nsteps);
     double p[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++)
@@ -158,10 +179,10 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 #ifndef DISC_AD_JACOBIAN
     {
-        // the input is a known function of time: u(t) at each of the 5 x 13 stage times and what the rows need of it alone
+        // the input is a known function of time: u(t) at each of the nsteps x 13 stage times and what the rows need of it alone
         // (|T|, 1/|T| for RocketQuat) are computed once here, one stage time per lane
-        const double hh = dt / double(DISC_STEPS);
-        for (int e = lane; e < DISC_STEPS * RK_S; e += WAVE)
+        const double hh = dt / double(nsteps);
+        for (int e = lane; e < nsteps * RK_S; e += WAVE)
         {
             const double tse = double(e / RK_S) * hh + RK_C[e % RK_S] * hh;
             const double fre = FOH ? tse / dt : 0.;
@@ -240,13 +261,13 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     }
 
     double kk[RK_S][EPL];
-    const double h = dt / double(DISC_STEPS);
+    const double h = dt / double(nsteps);
 #ifdef DISC_PROFILE
     long long tA = 0, tB = 0, tC = 0;
     const long long tk0 = clock64();
 #endif
 
-    for (int step = 0; step < DISC_STEPS; step++)
+    for (int step = 0; step < nsteps; step++)
     {
         const double t0 = double(step) * h;
         // The 13 stages are instantiated with a COMPILE-TIME stage index: the tableau entries become

@@ -440,3 +440,31 @@ def test_emu_sc_fixed_final_time(oracle, emu_lib, tmp_path):
 
 def test_emu_sc_zero_order_hold(oracle, emu_lib, tmp_path):
     _sc_variant_case(oracle, emu_lib, tmp_path, 10, 12, "zoh")
+
+
+def _adaptive_steps_case(oracle, model, lib, tol):
+    """discretize_kernel takes n = clamp(ceil(segment seconds / 0.171 s), 1, 5) RKF78 steps per segment (never more than the
+    reference's 5, never a longer step than the reference's own at its shipped K = 15 / 12 s configuration): 2 steps at K = 50.
+    Checked where it matters -- LATE iterates of SCvx runs (non-trivial attitude and thrust profiles), fixed-time first-order hold
+    like the headline mode -- against the oracle's 5-step integration of the reference's Phi^-1 formulation."""
+    worst = 0.0
+    for K, b in ((50, 0), (50, 3), (30, 2)):
+        s = oracle.SCvx(K=K); s.randomize(20260927, b); s.set_solver(1)
+        assert s.solve() == 0
+        X, U, t = s.iterate(s.meta()["n_all_td"] - 2)  # nondimensional late iterate
+        par = model.flow_params(model.randomized_initial_states(1, first=b)[0])
+        ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K, 1, library=lib)
+        ctx.set_flow_params(par[None]); ctx.upload_traj(X[None], U[None], [t]); ctx.discretize(scpp_amd.MODE_FOH)
+        out = ctx.download_dd()
+        ctx.close()
+        ref = oracle.discretize(0, par, X, U, t, foh=True, vt=False)
+        for n, a, o in zip("ABCSZ", out, ref):
+            if n == "S":
+                continue
+            worst = max(worst, float(np.abs(a[0] - o).max() / max(1.0, np.abs(o).max())))
+    assert worst <= tol, worst
+    return worst
+
+
+def test_emu_discretize_adaptive_step_count_matches_the_five_step_oracle(oracle, model, emu_lib):
+    _adaptive_steps_case(oracle, model, emu_lib, 1e-11)

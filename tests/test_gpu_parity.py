@@ -461,6 +461,14 @@ def test_discretize_variants_match_dop853_goldens_on_gpu(hip_lib):
     _dd_variant_goldens_case(hip_lib, 1e-9)
 
 
+def test_discretize_adaptive_step_count_on_gpu(oracle, model, hip_lib):
+    """2 RKF78 steps per segment at K = 50 (adaptive rule of discretize_kernel.h) against the oracle's 5-step integration, late iterates"""
+    from test_emu_kernels import _adaptive_steps_case
+
+    print("adaptive RKF78 step count vs the 5-step oracle at late SCvx iterates: worst relative deviation of A, B, C, z %.2e"
+          % _adaptive_steps_case(oracle, model, hip_lib, 1e-11))
+
+
 def test_sc_sim_runs_to_the_stop_rule_like_the_oracle(oracle, hip_lib, tmp_path):
     """Receding-horizon loops driven until the reference's own stop rule fires (||x - x_final|| < 0.02 or planned time
     < 0.25 s, SC_sim.cpp:57), against the oracle's driver.  With the shipped 12 s scenario the closed loop never gets there
