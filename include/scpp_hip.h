@@ -151,6 +151,11 @@ extern "C"
        (discretization.cpp:42-55, discretizationImplementation.hpp:96-101); dd.C reads back as zeros */
     int scpp_hip_upload_traj_zoh(scpp_hip_ctx *ctx, const double *X, const double *U, const double *sigma, int B);
     int scpp_hip_discretize(scpp_hip_ctx *ctx, int mode);
+    /* RKF78 steps per shooting segment for every later discretisation of this context (the open-loop call above, the SC / SCvx /
+       MPC loops).  5 = the reference's fixed count (scpp_core/include/discretizationImplementation.hpp:141,154), literally; 0
+       (default) = n = clamp(ceil(segment seconds / 0.1714 s), 1, 5): never more steps than the reference, never a longer step than
+       the reference's own at the K = 15 it ships; at K = 50 that is 2 steps, 1e-13 from the 5-step result */
+    int scpp_hip_set_discretization_steps(scpp_hip_ctx *ctx, int steps);
     int scpp_hip_download_dd(scpp_hip_ctx *ctx, double *A, double *B, double *C, double *S, double *Z);
     int scpp_hip_simulate(scpp_hip_ctx *ctx, const double *dt /* [B] */, const double *u0, const double *u1,
                           double *x /* [B][nx] in/out */, int B);

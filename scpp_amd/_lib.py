@@ -116,7 +116,7 @@ _lib_path = None
 
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj", "scpp_hip_upload_traj_zoh",
-    "scpp_hip_discretize", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
+    "scpp_hip_discretize", "scpp_hip_set_discretization_steps", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
     "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
@@ -200,6 +200,10 @@ class Context:
         else:
             assert U.shape[1] == self.K
             _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
+
+    def set_discretization_steps(self, steps):
+        """RKF78 steps per segment: 5 = the reference's fixed count, 0 = the adaptive rule (default); include/scpp_hip.h"""
+        _chk(self.lib.scpp_hip_set_discretization_steps(self.h, int(steps)), "set_discretization_steps")
 
     def discretize(self, mode=MODE_FOH | MODE_VT):
         _chk(self.lib.scpp_hip_discretize(self.h, int(mode)), "discretize")

@@ -51,7 +51,8 @@ __device__ inline void forEachStage(F &&f)
 // K = 50, 12 s: 2 steps of 0.122 s, A .. z within 1e-13 of the 5-step result (measured: 3 steps 3.5e-15, 2 steps 1.0e-13, 1 step
 // 2.4e-11; K = 15: 5 steps as the reference); test-enforced against the DOP853 goldens at 1e-9 like before, and against the 5-step
 // kernel at 1e-11.  40 % of the stage evaluations at K = 50: discretize_kernel 4.2 -> 1.9 ms per launch, headline +4.2 % (same box).
-// -DDISC_STEPS=n pins the count (n = 5: the reference's scheme literally).
+// scpp_hip_set_discretization_steps(ctx, n) pins the count at run time (n = 5: the reference's scheme literally; 0 = this rule);
+// -DDISC_STEPS=n pins it at compile time.
 #ifndef DISC_STEPS
 #define DISC_STEPS 0
 #endif
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
                       const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
                       const int *__restrict__ active,
                       double *__restrict__ Aout, double *__restrict__ Bout, double *__restrict__ Cout,
-                      double *__restrict__ Sout, double *__restrict__ Zout)
+                      double *__restrict__ Sout, double *__restrict__ Zout, int steps_opt)
 {
     using L = DiscLayout<Model, FOH, VT>;
     constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
@@ -138,8 +139,8 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     const double dt = VT ? 1. / double(K - 1) : sg / double(K - 1);
     const double tscale = VT ? sg : 1.;
     // steps of this segment (see DISC_STEPS above); the segment lasts sg / (K - 1) seconds in both time parametrisations
-    int nsteps = DISC_STEPS;
-    if (DISC_STEPS <= 0)
+    int nsteps = DISC_STEPS > 0 ? DISC_STEPS : steps_opt; // scpp_hip_set_discretization_steps: 0 = the rule, 1 .. 5 = pinned
+    if (nsteps <= 0)
     {
         const double seg_seconds = fabs(sg) / double(K - 1);
         nsteps = int(ceil(seg_seconds / DISC_MAX_STEP));

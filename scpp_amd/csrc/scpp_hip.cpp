@@ -90,6 +90,7 @@ struct scpp_hip_ctx
     int last_active = 0;
     long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
     int stream_pools = 0;
+    int disc_steps = 0; // RKF78 steps per segment: 0 = discretize_kernel.h's rule, 1 .. 5 pinned
 };
 
 namespace
@@ -254,16 +255,16 @@ int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par0, int stride, 
     const bool timed = spanBegin(c, 0, ninst, r.stream);
     if (mode == (SCPP_MODE_FOH | SCPP_MODE_VT))
         hipLaunchKernelGGL((discretize_kernel<Model, true, true>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
-                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z, c->disc_steps);
     else if (mode == SCPP_MODE_FOH)
         hipLaunchKernelGGL((discretize_kernel<Model, true, false>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
-                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z, c->disc_steps);
     else if (mode == SCPP_MODE_VT)
         hipLaunchKernelGGL((discretize_kernel<Model, false, true>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
-                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z, c->disc_steps);
     else
         hipLaunchKernelGGL((discretize_kernel<Model, false, false>), dim3(grid), dim3(WAVE), 0, v.stream, B, K, v.X, v.U,
-                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z);
+                           v.sigma, par, stride, active, v.A, v.Bm, v.C, v.S, v.Z, c->disc_steps);
     spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
@@ -748,6 +749,14 @@ int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const
                            (const int *)nullptr);
     CHECK_HIP(hipMemcpyAsync(x, c->sim_x, size_t(B) * c->nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHECK_HIP(hipStreamSynchronize(c->stream));
+    return SCPP_OK;
+}
+
+int scpp_hip_set_discretization_steps(scpp_hip_ctx *c, int steps)
+{
+    if (!c || steps < 0 || steps > DISC_STEPS_MAX) // 0 = the adaptive rule, 1 .. 5 pinned
+        return SCPP_E_ARG;
+    c->disc_steps = steps;
     return SCPP_OK;
 }
 

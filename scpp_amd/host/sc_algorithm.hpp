@@ -95,6 +95,13 @@ public:
         check(scpp_hip_create(&ctx, device, Model::model_id, opts.K, batch_max, 0), "scpp_hip_create");
         td.initialize(size_t(opts.K), opts.interpolate_input != 0);
     }
+    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154), 0 = the
+    // engine's rule (default; include/scpp_hip.h).  Call after initialize().
+    void setDiscretizationSteps(int steps)
+    {
+        if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
+            throw std::invalid_argument("setDiscretizationSteps: 0 (adaptive) or 1 .. 5");
+    }
 
     // ---- the reference's single-problem interface (instance = model->p.x_init) ----
     void solve(bool warm_start = false)
@@ -269,6 +276,13 @@ public:
         const int rc = scpp_hip_create(&ctx, device, Model::model_id, opts.K, batch_max, 0);
         if (rc != SCPP_OK)
             throw std::runtime_error("scpp_hip_create failed with code " + std::to_string(rc));
+    }
+    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154), 0 = the
+    // engine's rule (default; include/scpp_hip.h).  Call after initialize().
+    void setDiscretizationSteps(int steps)
+    {
+        if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
+            throw std::invalid_argument("setDiscretizationSteps: 0 (adaptive) or 1 .. 5");
     }
     void solve(bool warm_start = false)
     {

@@ -447,7 +447,7 @@ def _adaptive_steps_case(oracle, model, lib, tol):
     reference's 5, never a longer step than the reference's own at its shipped K = 15 / 12 s configuration): 2 steps at K = 50.
     Checked where it matters -- LATE iterates of SCvx runs (non-trivial attitude and thrust profiles), fixed-time first-order hold
     like the headline mode -- against the oracle's 5-step integration of the reference's Phi^-1 formulation."""
-    worst = 0.0
+    worst = worst5 = 0.0
     for K, b in ((50, 0), (50, 3), (30, 2)):
         s = oracle.SCvx(K=K); s.randomize(20260927, b); s.set_solver(1)
         assert s.solve() == 0
@@ -456,13 +456,22 @@ def _adaptive_steps_case(oracle, model, lib, tol):
         ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K, 1, library=lib)
         ctx.set_flow_params(par[None]); ctx.upload_traj(X[None], U[None], [t]); ctx.discretize(scpp_amd.MODE_FOH)
         out = ctx.download_dd()
+        # scpp_hip_set_discretization_steps: 5 = the reference's count literally (tighter against the oracle), out of range refused
+        ctx.set_discretization_steps(5); ctx.discretize(scpp_amd.MODE_FOH)
+        out5 = ctx.download_dd()
+        if K == 30:
+            with pytest.raises(scpp_amd.ScppHipError):
+                ctx.set_discretization_steps(6)
+            ctx.set_discretization_steps(0); ctx.discretize(scpp_amd.MODE_FOH)
+            assert all(np.array_equal(a, b) for n, a, b in zip("ABCSZ", out, ctx.download_dd()) if n != "S")
         ctx.close()
         ref = oracle.discretize(0, par, X, U, t, foh=True, vt=False)
-        for n, a, o in zip("ABCSZ", out, ref):
+        for n, a, a5, o in zip("ABCSZ", out, out5, ref):
             if n == "S":
                 continue
             worst = max(worst, float(np.abs(a[0] - o).max() / max(1.0, np.abs(o).max())))
-    assert worst <= tol, worst
+            worst5 = max(worst5, float(np.abs(a5[0] - o).max() / max(1.0, np.abs(o).max())))
+    assert worst <= tol and worst5 <= 0.05 * tol, (worst, worst5)
     return worst
 
 

@@ -628,7 +628,11 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
     K, N, first = 50, 512, 300_000
     seed = 20260927
     x0 = model.randomized_initial_states(N, first=first)
+    # the twin integrates every segment with the reference's 5 RKF78 steps; (a) pins the device to the same count so that the
+    # comparison isolates the solver and the loop.  The shipped default (2 steps at K = 50, 1e-13 away in A .. z)
+    # is compared with the pinned run below and is the one the literal audit (b) examines.
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=hip_lib).initialize()
+    alg.ctx.set_discretization_steps(5)
     nconv = alg.solve(x0)
     out = alg.getSolution()
     assert (out["status"] == 0).all() and nconv == int(out["converged"].sum()) and nconv >= 0.97 * N
@@ -654,6 +658,23 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
                                                                int((relU[same] > 1e-5).sum()), t_twin, threads))
     assert same.sum() >= 0.95 * N  # a decision within rounding of its threshold flips (measured: 14 of 512); both runs converge
     assert relX[same].max() <= 1e-5
+    # ---- (a') the shipped step rule against the pinned run: a 1e-13 perturbation of the sub-problem data.  Most instances
+    # reproduce the record and the trajectory to ~1e-9; in a few the perturbation reaches an accept / reject threshold or an
+    # ill-determined direction of the optimum and the runs part ways (the same sensitivity (b) documents between solvers); every run
+    # still converges and is audited below.
+    pinned = out
+    alg.ctx.close()
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=hip_lib).initialize()
+    nconv = alg.solve(x0)
+    out = alg.getSolution()
+    assert (out["status"] == 0).all() and nconv == int(out["converged"].sum()) and nconv >= 0.97 * N
+    same_d = (out["sc_iters"] == pinned["sc_iters"]) & (out["solves"] == pinned["solves"]) & (out["converged"] == pinned["converged"])
+    dX = np.array([np.abs(out["X"][b] - pinned["X"][b]).max() / np.abs(pinned["X"][b]).max() for b in range(N)])
+    print("adaptive step count (2 at K = 50) vs pinned 5: identical records %d of %d; over those rel dX median %.1e, 99th percentile "
+          "%.1e, max %.1e; converged %d vs %d" % (int(same_d.sum()), N, np.median(dX[same_d]), np.percentile(dX[same_d], 99),
+                                                 dX[same_d].max(), int(out["converged"].sum()), int(pinned["converged"].sum())))
+    assert same_d.sum() >= 0.9 * N and np.median(dX[same_d]) <= 1e-8
+    assert abs(int(out["converged"].sum()) - int(pinned["converged"].sum())) <= 0.01 * N
     # ---- (b) literal audit of the first 32 device paths + certificates for the instances of (a) whose inputs differ ----
     flagged = [int(b) for b in np.nonzero(same & (relU > 1e-5))[0] if b >= 32][:32]
     sel = list(range(32)) + flagged
