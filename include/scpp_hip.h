@@ -65,7 +65,7 @@ extern "C"
     {
         int32_t K;                 /* 3..8: the eliminated problem has 2(K-1)+2 <= 16 variables (one FP64 MFMA tile) */
         int32_t nondimensionalize; /* must be 0 (shipped; the reference discretises before it would rescale) */
-        int32_t constant_dynamics; /* must be 1 (shipped) */
+        int32_t constant_dynamics; /* 1 (shipped) or 0: the reference never changes A, B, z after initialize(), same problem either way */
         int32_t intermediate_cost_active; /* must be 0 (shipped; MPCProblem.cpp:67 is out of bounds otherwise) */
         double time_horizon;
         double state_weights_intermediate[6], state_weights_terminal[6], input_weights[2];

@@ -831,8 +831,8 @@ class MPCAlgorithm
     // MPCAlgorithm.cpp:34-69
     void initialize()
     {
-        if (nondimensionalize || !constant_dynamics || intermediate_cost_active || model->p.constrain_initial_final)
-            throw std::runtime_error("oracle MPC: only the shipped mode (dimensional, constant dynamics, terminal cost, "
+        if (nondimensionalize || intermediate_cost_active || model->p.constrain_initial_final)
+            throw std::runtime_error("oracle MPC: only the shipped mode (dimensional, terminal cost; constant_dynamics is immaterial, "
                                      "constrain_initial_final=false) is restated");
         TrajectoryData dummy;
         model->getNewModelParameters(dummy);

@@ -179,7 +179,9 @@ inline int buildMpcConst(const scpp_mpc_opts &o, const double *par, MpcConst &C)
     const int K = o.K, N = K - 1;
     if (K < 3 || K > KMAX)
         return SCPP_E_ARG;
-    if (o.nondimensionalize || !o.constant_dynamics || o.intermediate_cost_active)
+    // constant_dynamics = false only turns cvx::par(A) into cvx::dynpar(A) (MPCProblem.cpp:42-54); MPCAlgorithm never changes A, B, z
+    // after initialize() (MPCAlgorithm.cpp:47), so both settings pose the same problem and are accepted
+    if (o.nondimensionalize || o.intermediate_cost_active)
         return SCPP_E_UNSUPPORTED;
     if (!(o.time_horizon > 0.) || !(o.T_max > o.T_min) || !(o.gimbal_max > 0.) || !(o.theta_max > 0.) || !(o.w_B_max > 0.))
         return SCPP_E_ARG;

@@ -121,7 +121,7 @@ def test_mpc_abi_errors(rocket2d, emu_lib):
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts(K=9)), pp) == E_ARG                       # > 16 variables
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts(K=2)), pp) == E_ARG
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts(nondimensionalize=1)), pp) == E_UNSUPPORTED
-    assert raw.scpp_hip_mpc_setup(h, C.byref(opts(constant_dynamics=0)), pp) == E_UNSUPPORTED
+    assert raw.scpp_hip_mpc_setup(h, C.byref(opts(constant_dynamics=0)), pp) == 0           # dynpar instead of par: the same problem
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts(intermediate_cost_active=1)), pp) == E_UNSUPPORTED
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts(T_max=1e3)), pp) == E_ARG                 # empty thrust range
     assert raw.scpp_hip_mpc_setup(h, C.byref(opts()), pp) == 0
