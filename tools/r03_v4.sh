@@ -10,6 +10,7 @@ timeout -k 5 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench defa
 grep '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
 timeout -k 5 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_driver.log 2>&1; echo "bench driver-style rc=$?"
 grep '^{' $OUT/bench_driver.log | tail -1 > $OUT/bench_driver.json
+(cd scpp_amd/host && timeout 300 ./scvx_multi_gpu --batch 4096 --gpus 1 --slots 4096 --config ../config > $OUT/scvx_multi_gpu.log 2>&1; echo "scvx_multi_gpu rc=$?"; tail -4 $OUT/scvx_multi_gpu.log)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 0 --no-extras --no-cpu-baseline > $OUT/trace.log 2>&1
 echo "trace rc=$?"
