@@ -157,8 +157,11 @@ __device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const
 // nonlinear dynamics (RKF78 x 20 like scpp::simulate) and contributes ||x_prop - x_{k+1}||_1; fixed summation order
 // (wave_sum) keeps the accept/reject decisions reproducible.  Lane 0 then takes the decision of iterate(); a rejected
 // candidate is rolled back by the whole wavefront (td = old_td).
+#ifndef COST_WAVES_PER_SIMD
+#define COST_WAVES_PER_SIMD 1
+#endif
 template <class Model>
-__global__ void __launch_bounds__(WAVE) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
+__global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
 {
     using namespace ipm;
     constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP;
