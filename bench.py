@@ -53,30 +53,27 @@ class _DevArray:
 
 
 def _scvx_cpu(K, seed, solver, seconds_budget, threads):
-    """oracle.SCvx (CPU restatement) on `threads` host threads; ctypes releases the GIL inside the solve."""
-    from concurrent.futures import ThreadPoolExecutor
+    """oracle SCvx runs (CPU restatement) on `threads` native host threads (oracle/capi.cpp: oracle_scvx_run_batch -- one counter,
+    one std::thread per core, no interpreter between the instances).  The sample is sized from one timed instance so that the whole
+    leg takes about `seconds_budget` seconds."""
+    import ctypes as C
 
     import oracle_lib
 
-    def one(i):
-        s = oracle_lib.SCvx(K=K)
-        s.randomize(seed, i)
-        s.set_solver(solver)
-        rc = s.solve()
-        m = s.meta()
-        return rc, m["converged"], m["iterations"], m["solves"]
+    lib = oracle_lib.lib()
+    cfg = oracle_lib.CONFIG_ROOT.encode()
 
-    t0 = time.time()
-    r0 = one(0)
-    t1 = time.time() - t0
-    n = int(max(threads, min(32 * threads, (seconds_budget / max(t1, 1e-3)) * threads * 0.7)))
-    t0 = time.time()
-    with ThreadPoolExecutor(threads) as ex:
-        rs = list(ex.map(one, range(n)))
-    dt = time.time() - t0
-    conv = sum(r[1] for r in rs if r[0] == 0)
-    return dict(n=n, dt=dt, converged=conv, failures=sum(r[0] != 0 for r in rs), latency=t1,
-                mean_iters=float(np.mean([r[2] for r in rs])), mean_solves=float(np.mean([r[3] for r in rs])), first=r0)
+    def batch(first, n, nthreads):
+        counts = (C.c_longlong * 4)()
+        t0 = time.time()
+        rc = lib.oracle_scvx_run_batch(cfg, int(K), C.c_ulonglong(seed), C.c_ulonglong(first), int(n), int(solver), int(nthreads), counts)
+        assert rc == 0
+        return time.time() - t0, [int(v) for v in counts]
+
+    t1, c1 = batch(0, 1, 1)
+    n = int(max(threads, min(64 * threads, (seconds_budget / max(t1, 1e-3)) * threads * 0.5)))
+    dt, c = batch(0, n, threads)
+    return dict(n=n, dt=dt, converged=c[0], failures=c[1], latency=t1, mean_iters=c[2] / n, mean_solves=c[3] / n, first=c1)
 
 
 def cpu_baseline(K, seed, seconds_budget=12.0):
@@ -87,7 +84,7 @@ def cpu_baseline(K, seed, seconds_budget=12.0):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = cores
-    threads = max(1, min(usable, 32))
+    threads = max(1, usable)  # every logical CPU this process may run on, one native thread each
     tw = _scvx_cpu(K, seed, 1, seconds_budget, threads)
     out = {
         "value": tw["converged"] / tw["dt"],
@@ -98,7 +95,7 @@ def cpu_baseline(K, seed, seconds_budget=12.0):
         "kind": "port",
         "single_thread_latency_s": tw["latency"],
         "sample": f"{tw['n']} RocketQuat K={K} SCvx instances (seed {seed}, instances 0..{tw['n'] - 1}), oracle structured-IPM twin "
-                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} threads; {tw['converged']} converged, "
+                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} native threads (one per usable logical CPU); {tw['converged']} converged, "
                   f"{tw['failures']} solver failures, mean {tw['mean_iters']:.1f} SCvx iterations / {tw['mean_solves']:.1f} solves",
     }
     # the reference-shaped form: Epigraph-style literal problem (n=2273, p=814, m=2573) on the sparse ECOS restatement

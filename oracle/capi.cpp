@@ -3,6 +3,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -685,6 +686,53 @@ int oracle_scvx_meta(void *h, int *meta)
             meta[7 + i] = a.last_dims[i];
         return 0;
     });
+}
+// The CPU baseline of bench.py: `n` randomised RocketQuat SCvx runs (instances first .. first + n - 1 of `seed`) on `threads` native
+// threads pulling instance numbers from one counter -- the same calls the Python wrapper makes per instance (create, randomize,
+// set_solver, solve), without the interpreter in between.  counts: [converged, failures, sum of SCvx iterations, sum of solves]
+int oracle_scvx_run_batch(const char *config_root, int K, unsigned long long seed, unsigned long long first, int n, int solver,
+                          int threads, long long *counts)
+{
+    if (n < 1 || threads < 1 || !counts)
+        return -1;
+    std::atomic<int> next{0};
+    std::atomic<long long> conv{0}, fail{0}, iters{0}, solves{0};
+    auto worker = [&]() {
+        for (;;)
+        {
+            const int i = next.fetch_add(1);
+            if (i >= n)
+                return;
+            void *h = oracle_scvx_create_model(0, config_root, K);
+            if (!h)
+            {
+                fail++;
+                continue;
+            }
+            oracle_scvx_randomize(h, seed, first + (unsigned long long)i);
+            oracle_scvx_set_solver(h, solver);
+            const int rc = oracle_scvx_solve(h, 0);
+            int meta[12];
+            oracle_scvx_meta(h, meta);
+            if (rc != 0)
+                fail++;
+            else
+                conv += meta[3];
+            iters += meta[2];
+            solves += meta[6];
+            oracle_scvx_destroy(h);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back(worker);
+    for (auto &t : pool)
+        t.join();
+    counts[0] = conv;
+    counts[1] = fail;
+    counts[2] = iters;
+    counts[3] = solves;
+    return 0;
 }
 int oracle_scvx_get_iterate(void *h, int idx, double *X, double *U, double *t)
 {

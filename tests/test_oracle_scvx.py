@@ -83,3 +83,21 @@ def test_scvx_literal_whole_run_at_K50(oracle):
     print("literal", ia[:2], "twin", ib[:2])
     assert abs(ia[0] - ib[0]) <= 0.25 * max(ia[0], ib[0])
     assert abs(ia[1] - ib[1]) <= 0.25 * max(ia[1], ib[1])
+
+
+def test_native_batch_runner_matches_the_per_instance_calls(oracle):
+    """oracle_scvx_run_batch (bench.py's cpu_baseline leg: native threads, one instance counter) does per instance what the Python
+    wrapper does: same convergence, iteration and solve totals."""
+    import ctypes as C
+
+    n, first, K = 4, 7, 20
+    counts = (C.c_longlong * 4)()
+    rc = oracle.lib().oracle_scvx_run_batch(oracle.CONFIG_ROOT.encode(), K, C.c_ulonglong(20260927), C.c_ulonglong(first), n, 1, 3, counts)
+    assert rc == 0
+    conv = iters = solves = 0
+    for i in range(n):
+        s = oracle.SCvx(K=K); s.randomize(20260927, first + i); s.set_solver(1)
+        assert s.solve() == 0
+        m = s.meta()
+        conv += m["converged"]; iters += m["iterations"]; solves += m["solves"]
+    assert [int(v) for v in counts] == [conv, 0, iters, solves]
