@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
 #ifndef SCPP_HIP_EMU
     __builtin_assume(g >= 0 && g < NG);
 #endif
-    const double x0r = X[(inst * K + k) * NX + row];
+    const double x0r = lane_on ? X[(inst * K + k) * NX + row] : 0.; // (rows >= NX would read past the node: past the buffer at the last one)
     double y[EPL];
     bool eon[EPL];
 #pragma unroll

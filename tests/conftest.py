@@ -19,6 +19,9 @@ def emu_lib():
     """CPU emulation build of the HIP kernel sources (tests/emu/hip_emu.h) -- test infrastructure only."""
     import __graft_entry__ as g
 
+    alt = os.environ.get("SCPP_EMU_LIBRARY")  # e.g. an -fsanitize=address,undefined build of the same sources (DESIGN.md 4.7)
+    if alt:
+        return alt
     return g.build_emu()
 
 
