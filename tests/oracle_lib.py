@@ -26,7 +26,10 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        if not os.path.exists(path) or any(
+        alt = os.environ.get("SCPP_ORACLE_LIBRARY")  # e.g. a sanitizer build of oracle/capi.cpp (tools/asan_emu.sh)
+        if alt:
+            path = alt
+        elif not os.path.exists(path) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(path)
             for f in os.listdir(ORACLE_DIR)
             if f.endswith((".hpp", ".cpp"))

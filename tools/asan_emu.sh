@@ -11,3 +11,9 @@ LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.s
     python -m pytest tests/test_emu_kernels.py tests/test_mpc.py tests/test_abi_errors.py tests/test_sc_loop_pin.py tests/test_subproblem_pin.py \
     -q -m "not gpu" > $OUT/run.log 2>&1
 echo "pytest rc=$?"; grep -c "ERROR: AddressSanitizer\|runtime error" $OUT/run.log; tail -2 $OUT/run.log
+# the oracle (test infrastructure) under the same sanitizers
+g++ -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $OUT/liboracle_asan.so oracle/capi.cpp 2>> $OUT/build.log
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" SCPP_ORACLE_LIBRARY=$OUT/liboracle_asan.so \
+    python -m pytest tests/test_oracle_discretization.py tests/test_oracle_scvx.py tests/test_oracle_socp.py tests/test_oracle_sc.py tests/test_oracle_model.py \
+    tests/test_oracle_mpc.py tests/test_oracle_rkf78.py tests/test_oracle_sc_sim.py -q -m "not gpu" > $OUT/run_oracle.log 2>&1
+echo "oracle pytest rc=$?"; grep -c "ERROR: AddressSanitizer\|runtime error" $OUT/run_oracle.log; tail -2 $OUT/run_oracle.log
