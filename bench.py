@@ -76,6 +76,22 @@ def _scvx_cpu(K, seed, solver, seconds_budget, threads):
     return dict(n=n, dt=dt, converged=c[0], failures=c[1], latency=t1, mean_iters=c[2] / n, mean_solves=c[3] / n, first=c1)
 
 
+def _cgroup_cpu_quota():
+    """CPUs the cgroup of this process may use per scheduling period (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us); None if
+    unlimited or unreadable"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(K, seed, seconds_budget=12.0):
     """The oracle (CPU restatement of SCpp's algorithm, g++ -O2 -- NOT ECOS: the reference cannot be built)
     on the GPU box's host cores, same workload as the headline: converged SCvx trajectories/s."""
@@ -84,7 +100,11 @@ def cpu_baseline(K, seed, seconds_budget=12.0):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = cores
-    threads = max(1, usable)  # every logical CPU this process may run on, one native thread each
+    quota = _cgroup_cpu_quota()
+    # one native thread per CPU this process can actually use: the affinity mask, capped by the cgroup CPU quota of the box (the test
+    # boxes show 256 logical CPUs under a 16-CPU quota: beyond 16 threads the throughput FALLS -- 27.8 /s at 16, 12.9 /s at 256,
+    # tools/cpu_probe.py -- because the scheduler throttles the whole group)
+    threads = max(1, min(usable, int(quota + 0.5)) if quota else usable)
     tw = _scvx_cpu(K, seed, 1, seconds_budget, threads)
     out = {
         "value": tw["converged"] / tw["dt"],
@@ -92,10 +112,11 @@ def cpu_baseline(K, seed, seconds_budget=12.0):
         "cores": threads,
         "host_logical_cpus": cores,       # os.cpu_count() of the GPU box
         "host_usable_cpus": usable,       # sched_getaffinity: what this process may run on
+        "host_cgroup_cpu_quota": quota,   # cpu.max quota / period of the box's cgroup (None: unlimited)
         "kind": "port",
         "single_thread_latency_s": tw["latency"],
         "sample": f"{tw['n']} RocketQuat K={K} SCvx instances (seed {seed}, instances 0..{tw['n'] - 1}), oracle structured-IPM twin "
-                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} native threads (one per usable logical CPU); {tw['converged']} converged, "
+                  f"(CPU restatement of SCpp's algorithm -- not ECOS), g++ -O2, {threads} native threads (one per CPU of the cgroup quota / affinity mask); {tw['converged']} converged, "
                   f"{tw['failures']} solver failures, mean {tw['mean_iters']:.1f} SCvx iterations / {tw['mean_solves']:.1f} solves",
     }
     # the reference-shaped form: Epigraph-style literal problem (n=2273, p=814, m=2573) on the sparse ECOS restatement
