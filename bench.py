@@ -319,6 +319,25 @@ def main():
             }
         except Exception as e:
             extras["single_pool"] = {"error": str(e)}
+        # ---- the reference's integrator step count, literally: discretize_kernel pinned to 5 RKF78 steps per segment (the shipped
+        # rule takes 2 at K = 50, 1e-13 away), same engine and pools as the headline, a 2-batch job ----
+        try:
+            ctx.set_discretization_steps(5)
+            xs = model.randomized_initial_states(2 * B, seed=args.seed, first=30_000_000)
+            tp0 = time.perf_counter()
+            nc5 = alg.solveStream(xs, slots=B, pools=args.pools)
+            o5 = ctx.stream_download()
+            tp = time.perf_counter() - tp0
+            extras["reference_step_count"] = {
+                "note": "scpp_hip_set_discretization_steps(ctx, 5): the reference's five RKF78 steps per segment "
+                        "(discretizationImplementation.hpp:141,154) instead of the shipped rule; 2 batches as one streaming job",
+                "rkf78_steps_per_segment": 5, "converged_trajectories_per_s": nc5 / tp, "converged_fraction": nc5 / (2 * B),
+                "mean_subproblem_solves": float(o5["solves"].mean()),
+            }
+        except Exception as e:
+            extras["reference_step_count"] = {"error": str(e)}
+        finally:
+            ctx.set_discretization_steps(0)
         # ---- one isolated batch through the plain batch entry point (latency view: includes its own tail) ----
         try:
             xv = model.randomized_initial_states(B, seed=args.seed, first=10_000_000)
