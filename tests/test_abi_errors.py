@@ -98,3 +98,15 @@ def test_smallest_horizons_and_ragged_batches(oracle, model, emu_lib, K, B):
         assert out["status"][b] == 0
         assert np.abs(out["X"][b] - X1).max() <= 1e-7 * max(1.0, np.abs(X1).max())
         assert abs(out["sigma"][b] - t1) <= 1e-7 * abs(t1)
+
+
+def test_empty_jobs_are_refused_not_ignored(model, emu_lib):
+    """a job of zero instances is an argument error at every batched entry point (SCPP_E_ARG), never a silent no-op"""
+    alg = scpp_amd.SCvxAlgorithm(model, K=8, batch_max=2, library=emu_lib, max_iterations=2).initialize()
+    none = model.randomized_initial_states(2)[:0]
+    for call in (lambda: alg.solveStream(none, slots=2, pools=0), lambda: alg.solve(none)):
+        with pytest.raises(scpp_amd.ScppHipError, match="code -1"):
+            call()
+    sc = scpp_amd.SCAlgorithm(model, K=8, batch_max=2, library=emu_lib).initialize()
+    with pytest.raises(scpp_amd.ScppHipError, match="code -1"):
+        sc.ctx.sc_setup(model.p, sc.opts, none)
