@@ -477,3 +477,19 @@ def _adaptive_steps_case(oracle, model, lib, tol):
 
 def test_emu_discretize_adaptive_step_count_matches_the_five_step_oracle(oracle, model, emu_lib):
     _adaptive_steps_case(oracle, model, emu_lib, 1e-11)
+
+
+@pytest.mark.parametrize("K,N,S,P,it", [(7, 11, 1, 3, 2), (4, 13, 2, 2, 4), (6, 12, 8, 3, 2), (7, 1, 3, 3, 4), (8, 9, 6, 1, 4), (5, 6, 8, 0, 3)])
+def test_emu_stream_ragged_configurations_equal_batch(model, emu_lib, K, N, S, P, it):
+    """the streaming engine with more pools than slots, more slots than instances, one slot, one instance: bitwise the batch result
+    (a sample of the 25 random configurations of round 3's fuzz run, all equal)"""
+    x0 = model.randomized_initial_states(N, first=100 * K + N)
+    a = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=max(N, S), library=emu_lib, max_iterations=it).initialize()
+    nc = a.solveStream(x0, slots=S, pools=P)
+    rows = a.ctx.stream_download()
+    b = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=emu_lib, max_iterations=it).initialize()
+    assert nc == b.solve(x0)
+    ob = b.getSolution()
+    for k in ("X", "U", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+        assert np.array_equal(rows[k], ob[k]), k
+    a.ctx.close(); b.ctx.close()
