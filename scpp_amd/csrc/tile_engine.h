@@ -10,7 +10,7 @@
 //   backward:  t = mm(Zt, x') - c   lam = mm(Ti, t)   s = a - mm(Y, lam)   x = mm(Li, s)
 // Only the two inverse Cholesky factors per stage (Li = chol(Phi)^-1, Ti = chol(Theta)^-1) are not MFMA work:
 // they are computed by Gaussian elimination on [A | I] (rank-1 updates of both tiles, all 64 lanes busy, the
-// pivot column / row exchanged through 2 x 16 doubles of LDS).  Scalar twin: oracle/structured_ipm.hpp.
+// pivot row fetched by ds_bpermute, the pivot column by DPP row broadcast).  Scalar twin: oracle/structured_ipm.hpp.
 #pragma once
 #include "ipm_kernel.h"
 
@@ -105,8 +105,9 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 // Li = chol(A)^-1 (lower triangular, D-layout) of the SPD leading n x n block of tile A; rows/cols >= n: identity.
 // Gaussian elimination on [A | I], fully unrolled so that everything that depends only on the step index is
 // resolved at compile time (which register holds pivot row j, which register rows lie entirely above /
-// below the pivot).  Per step: ONE LDS turnaround (publish pivot column of A and pivot row of R, read the
-// <= 8 values this lane needs in one batch), a Newton reciprocal, <= 8 predicated FMAs.
+// below the pivot).  Per step: the pivot row of A and of R by ds_bpermute from the row group that holds it (INVCHOL_BPERMUTE;
+// the older exchange through 2 x 16 doubles of LDS remains selectable), the pivot column by DPP row broadcast, a Newton
+// reciprocal, <= 8 predicated FMAs.
 // Inlined into its callers: as a called function its entry waits for every outstanding memory operation of the wavefront
 // (s_waitcnt vmcnt(0) is part of the function-call ABI), which exposes the latency of the stage loads the factor sweep issues
 // to run under the elimination, and of the factor-record stores in front of the second elimination.
@@ -120,6 +121,13 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 #define INVCHOL_PERMLANE 0 // 0: pivot row / column exchanged through 2 x 16 doubles of LDS ; 1: by v_permlane16/32_swap (no LDS at all;
                            // measured on MI355X, round 3: 3930 vs 4046 converged/s -- 8 swaps + their hazard s_nops per step issue more than the
                            // LDS round trip costs, the eliminations are not LDS-latency bound)
+#endif
+#ifndef INVCHOL_BPERMUTE
+#define INVCHOL_BPERMUTE 1 // 1 (default since round 3): the pivot ROW of A and of R is fetched from the row group that holds it by
+                           // ds_bpermute -- ONE trip through the LDS crossbar, nothing stored -- instead of publish -> wait -> read (two
+                           // trips).  The kernel is latency-bound (SQ counters): 4420 / 4423 against 4313 / 4367
+                           // converged/s on the same box (+1.9 %).  Uses A[j][i] where the LDS exchange (-DINVCHOL_BPERMUTE=0) uses
+                           // A[i][j]: equal up to rounding, and the scalar twin's own formula (structured_ipm.hpp: invCholFactor)
 #endif
 template <int n>
 INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
@@ -147,7 +155,7 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         // it (and the multipliers m = A[row][j] / d, which come by row broadcast) are then structurally zero wherever the
         // elimination must not act, and no reader has to mask them (rows >= n of an n < 16 block are zero in column j anyway;
         // R[j][i] = 0 for i > j by construction).
-#if !INVCHOL_PERMLANE
+#if !INVCHOL_PERMLANE && !INVCHOL_BPERMUTE
         if (i == j)
         {
 #pragma unroll
@@ -167,7 +175,15 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         //  step, bitwise the same pivot -- was measured in round 3: 3915 vs 3923 converged/s, no difference; not kept)
         double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
         const double floor_ = readLane(od, (j & 3) * 16 + j);
-#if !INVCHOL_PERMLANE
+#if INVCHOL_BPERMUTE
+        // lane (j & 3, i) holds A[j][i] and R[j][i] in register j >> 2: every lane of column i fetches them from there
+        (void)b;
+        (void)sh;
+        const int src = (j & 3) * 16 + i;
+        const double arow = __shfl(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], src);
+        const double rj = __shfl(rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3], src); // R[j][i] (0 for i > j)
+        const double aj = i > j ? arow : 0.; // only the columns right of the pivot are eliminated
+#elif !INVCHOL_PERMLANE
         const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
         const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
 #endif
