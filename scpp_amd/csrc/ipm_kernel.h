@@ -150,6 +150,13 @@ __host__ __device__ inline size_t workspaceDoubles(int K)
 // byte offset beyond every record block of an instance: a buffer load at it returns 0, a buffer store is dropped
 constexpr int VO_OOB = 0x40000000;
 typedef unsigned int u32x2_t __attribute__((vector_size(8)));
+// cache policy of the workspace accesses (aux operand of the buffer instructions; gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef IPM_LD_AUX
+#define IPM_LD_AUX 0
+#endif
+#ifndef IPM_ST_AUX
+#define IPM_ST_AUX 0
+#endif
 struct SV
 {
     __amdgpu_buffer_rsrc_t rsrc; // wave-uniform: the instance's stage or segment record block
@@ -162,11 +169,11 @@ struct SV
         int lb, so;
         __device__ operator double() const
         {
-            return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lb, so, 0));
+            return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lb, so, IPM_LD_AUX));
         }
         __device__ const Ref &operator=(double x) const
         {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), rsrc, lb, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), rsrc, lb, so, IPM_ST_AUX);
             return *this;
         }
         __device__ const Ref &operator=(const Ref &o) const { return *this = double(o); }

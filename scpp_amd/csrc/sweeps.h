@@ -61,8 +61,8 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
 struct Buf
 {
     __amdgpu_buffer_rsrc_t r;
-    __device__ double ld(int vo, int so) const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0)); }
-    __device__ void st(int vo, int so, double x) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, vo, so, 0); }
+    __device__ double ld(int vo, int so) const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, IPM_LD_AUX)); }
+    __device__ void st(int vo, int so, double x) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, vo, so, IPM_ST_AUX); }
 };
 __device__ inline Buf makeBuf(const double *p, int ndoubles)
 {
