@@ -71,7 +71,7 @@ def _scvx_cpu(K, seed, solver, seconds_budget, threads):
         return time.time() - t0, [int(v) for v in counts]
 
     t1, c1 = batch(0, 1, 1)
-    n = int(max(threads, min(64 * threads, (seconds_budget / max(t1, 1e-3)) * threads * 0.5)))
+    n = int(max(threads, min(64 * threads, (seconds_budget / max(t1, 1e-3)) * threads)))
     dt, c = batch(0, n, threads)
     return dict(n=n, dt=dt, converged=c[0], failures=c[1], latency=t1, mean_iters=c[2] / n, mean_solves=c[3] / n, first=c1)
 
