@@ -180,9 +180,12 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         (void)b;
         (void)sh;
         const int src = (j & 3) * 16 + i;
-        const double arow = __shfl(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], src);
+        // NOT masked to the columns right of the pivot: columns <= j of A are dead from step j on (no later step reads them, Li is
+        // built from R and the pivots), so updating them with finite garbage is harmless -- and without the select the compiler
+        // no longer waits for the crossbar before it starts the reciprocal chain (measured: the 14-step elimination ran 390 cycles
+        // per step against 206 of the 16-step one, whose schedule happened to overlap the two)
+        const double aj = __shfl(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], src);
         const double rj = __shfl(rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3], src); // R[j][i] (0 for i > j)
-        const double aj = i > j ? arow : 0.; // only the columns right of the pivot are eliminated
 #elif !INVCHOL_PERMLANE
         const double aj = sh.colA[b][i];  // A[j][i] for i > j, 0 otherwise
         const double rj = sh.rowR[b][i];  // R[j][i] (0 for i > j)
