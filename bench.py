@@ -40,9 +40,15 @@ FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border (cold s
 IPM_ALGO_BYTES_PER_SOLVE = 131712 + 7208 + 7200  # read dd + td, write X, U: what one sub-problem solve must move
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
 DISC_FLOP_PER_RHS = 18.6e3        # one evaluation of the augmented right-hand side (J V on the matrix core + flow map + Jacobian rows)
-DISC_MAX_STEP = 12.0 / (14.0 * 5.0)  # csrc/discretize_kernel.h: n = clamp(ceil(segment seconds / this), 1, 5) RKF78 steps per segment
+DISC_MAX_STEP = 12.0 / (14.0 * 5.0)  # csrc/discretize_kernel.h, opt-in rule: n = clamp(ceil(segment seconds / this), 1, 5) RKF78 steps per segment
 PEAK_FP64_TFLOPS = 78.6           # MI355X FP64 vector == FP64 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
+
+
+def DISC_RULE_STEPS(model, K):
+    import math
+
+    return min(5, max(1, math.ceil(float(model.p.final_time) / (K - 1) / DISC_MAX_STEP)))
 
 
 class _DevArray:
@@ -319,25 +325,27 @@ def main():
             }
         except Exception as e:
             extras["single_pool"] = {"error": str(e)}
-        # ---- the reference's integrator step count, literally: discretize_kernel pinned to 5 RKF78 steps per segment (the shipped
-        # rule takes 2 at K = 50, 1e-13 away), same engine and pools as the headline, a 2-batch job ----
+        # ---- the opt-in step-length rule of discretize_kernel (round 3's default; since round 4 the default is the reference's five RKF78
+        # steps per segment and the HEADLINE is measured with it): 2 steps at K = 50, 1e-13 away in A .. z, same engine and
+        # pools as the headline, a 2-batch job ----
         try:
-            ctx.set_discretization_steps(5)
+            ctx.set_discretization_steps(0)
             xs = model.randomized_initial_states(2 * B, seed=args.seed, first=30_000_000)
             tp0 = time.perf_counter()
             nc5 = alg.solveStream(xs, slots=B, pools=args.pools)
             o5 = ctx.stream_download()
             tp = time.perf_counter() - tp0
-            extras["reference_step_count"] = {
-                "note": "scpp_hip_set_discretization_steps(ctx, 5): the reference's five RKF78 steps per segment "
-                        "(discretizationImplementation.hpp:141,154) instead of the shipped rule; 2 batches as one streaming job",
-                "rkf78_steps_per_segment": 5, "converged_trajectories_per_s": nc5 / tp, "converged_fraction": nc5 / (2 * B),
+            extras["step_length_rule"] = {
+                "note": "scpp_hip_set_discretization_steps(ctx, 0): n = clamp(ceil(segment seconds / 0.1714 s), 1, 5) RKF78 steps per segment "
+                        "instead of the reference's fixed five (discretizationImplementation.hpp:141,154), which the headline uses; 2 batches "
+                        "as one streaming job.  NOT the reference's scheme: a handful of accept / reject decisions differ",
+                "rkf78_steps_per_segment": DISC_RULE_STEPS(model, K), "converged_trajectories_per_s": nc5 / tp, "converged_fraction": nc5 / (2 * B),
                 "mean_subproblem_solves": float(o5["solves"].mean()),
             }
         except Exception as e:
-            extras["reference_step_count"] = {"error": str(e)}
+            extras["step_length_rule"] = {"error": str(e)}
         finally:
-            ctx.set_discretization_steps(0)
+            ctx.set_discretization_steps(5)
         # ---- one isolated batch through the plain batch entry point (latency view: includes its own tail) ----
         try:
             xv = model.randomized_initial_states(B, seed=args.seed, first=10_000_000)
@@ -426,7 +434,17 @@ def main():
         if pmc is not None:
             f, d = pmc
             traffic = d["ipm_bytes_per_instance_iteration"] * ipm_iters0 / launches
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import csrc_hash
+                here = csrc_hash.csrc_sha()
+            except Exception:
+                here = None
+            # stale: the PMC summary was taken from other kernel sources than the ones this run uses (content hash of scpp_amd/csrc +
+            # include/scpp_hip.h; the GPU box has no .git to ask for ancestry)
+            stale = (here is None) or (d.get("csrc_sha") != here)
             traffic_source = {"imported_from": os.path.relpath(f, ROOT), "commit_of_that_profile": d.get("commit", "?"),
+                              "csrc_sha_of_that_profile": d.get("csrc_sha"), "csrc_sha_of_this_run": here, "stale": stale,
                               "measured_in_this_run": False}
             traffic_note = (f"IMPORTED, not measured in this run: {os.path.relpath(f, ROOT)} (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, separate "
                             f"passes, of ipm_kernel at commit {d.get('commit', '?')}, {d.get('calibration', 'uncalibrated')}) = "
@@ -439,8 +457,7 @@ def main():
                     % (measured_gbs, 100 * hbm_frac, 100 * mfma_frac)) if (hbm_frac is not None and hbm_frac > mfma_frac) else "fp64 mfma"
         disc_s = tm.get("ms_discretize_union", 0.0) * 1e-3 or tm["ms_discretize"] * 1e-3
         # flops the kernel EXECUTES: 13 stages x n steps per segment (the reference's scheme is n = 5 whatever K: 5.9e7 flop at K = 50)
-        import math
-        disc_steps = min(5, max(1, math.ceil(float(model.p.final_time) / (K - 1) / DISC_MAX_STEP)))
+        disc_steps = 5  # the library default since round 4: the reference's fixed count (scpp_hip_set_discretization_steps)
         DISC_FLOP_PER_INSTANCE = (K - 1) * 13 * disc_steps * DISC_FLOP_PER_RHS
         # discretize launches are masked (needs_disc): instances that re-solve after a rejection skip it, so count solves
         line = {
@@ -460,7 +477,8 @@ def main():
                 "workload": f"RocketQuat SCvx (SCvxAlgorithm: fixed final time, hard input trust region, FOH), K={K}, {args.steps} steps x "
                             f"batch={B} randomised initial states per GPU (BASELINE configs[2]/[4]: 8192 per GPU, 65536 on 8), shipped "
                             f"Falcon-9 model.info + SCvx.info",
-                "algorithm": "SCvxAlgorithm::solve, cold start per instance; converged = |dL| < change_threshold (SCvxAlgorithm.cpp:125)",
+                "algorithm": "SCvxAlgorithm::solve, cold start per instance; converged = |dL| < change_threshold (SCvxAlgorithm.cpp:125); "
+                             "multipleShooting with the reference's 5 RKF78 steps per segment (discretizationImplementation.hpp:141,154)",
                 "engine": f"scpp_hip_scvx_solve_stream: continuous batching over {B} resident slots per GPU, steps x batch instances queued",
                 "global_batch": int(B * world),
                 "instances_timed": int(g_total),

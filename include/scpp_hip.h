@@ -56,7 +56,7 @@ extern "C"
 #define SCPP_E_HIP -2
 #define SCPP_E_UNSUPPORTED -3
 #define SCPP_E_STATE -4
-#define SCPP_STATUS_REJECTION_CAP -4 /* a per-instance STATUS (scpp_hip_download), not a return code */
+#define SCPP_STATUS_REJECTION_CAP -5 /* a per-instance STATUS (scpp_hip_download), not a return code; distinct from every SCPP_E_* value */
 
     typedef struct scpp_hip_ctx scpp_hip_ctx;
 
@@ -152,9 +152,11 @@ extern "C"
     int scpp_hip_upload_traj_zoh(scpp_hip_ctx *ctx, const double *X, const double *U, const double *sigma, int B);
     int scpp_hip_discretize(scpp_hip_ctx *ctx, int mode);
     /* RKF78 steps per shooting segment for every later discretisation of this context (the open-loop call above, the SC / SCvx /
-       MPC loops).  5 = the reference's fixed count (scpp_core/include/discretizationImplementation.hpp:141,154), literally; 0
-       (default) = n = clamp(ceil(segment seconds / 0.1714 s), 1, 5): never more steps than the reference, never a longer step than
-       the reference's own at the K = 15 it ships; at K = 50 that is 2 steps, 1e-13 from the 5-step result */
+       MPC loops).  5 (DEFAULT since round 4) = the reference's fixed count (scpp_core/include/discretizationImplementation.hpp:141,154),
+       literally.  0 = opt-in step-length rule n = clamp(ceil(segment seconds / 0.1714 s), 1, 5): never more steps than the reference,
+       never a longer step than the reference's own at the K = 15 it ships; at K = 50 / 12 s that is 2 steps, 1e-13 from the 5-step
+       A .. z -- but SCvx accept / reject decisions hinge on the sign of a dJ of ~1e-10, so a handful of decision
+       sequences differ from the reference-faithful scheme; that is why it is not the default.  1 .. 4 pin the count. */
     int scpp_hip_set_discretization_steps(scpp_hip_ctx *ctx, int steps);
     int scpp_hip_download_dd(scpp_hip_ctx *ctx, double *A, double *B, double *C, double *S, double *Z);
     int scpp_hip_simulate(scpp_hip_ctx *ctx, const double *dt /* [B] */, const double *u0, const double *u1,
@@ -215,7 +217,7 @@ extern "C"
     int scpp_hip_stream_rows(scpp_hip_ctx *ctx, void **rows, int *row_doubles, int *n);
     int scpp_hip_stream_download(scpp_hip_ctx *ctx, double *rows /* [count][K*18+10] */, int first, int count);
     int scpp_hip_stream_info(scpp_hip_ctx *ctx, long long *rounds_enqueued, int *pools_used); /* diagnostics of the last job */
-    /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure, SCPP_STATUS_REJECTION_CAP (-4):
+    /* results; any pointer may be NULL. status: 0 ok, -1 IPM iteration limit, -2 numerical failure, SCPP_STATUS_REJECTION_CAP (-5):
        SCvx only -- the instance used 64 x max_iterations sub-problem solves without leaving the reject / re-solve loop of
        SCvxAlgorithm::iterate (SCvxAlgorithm.cpp:75-153 has no other exit; seen with the shipped Rocket2D SCvx.info, whose
        trust radius collapses) and was retired; its trajectory is the last accepted iterate */

@@ -202,7 +202,7 @@ class Context:
             _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
 
     def set_discretization_steps(self, steps):
-        """RKF78 steps per segment: 5 = the reference's fixed count, 0 = the adaptive rule (default); include/scpp_hip.h"""
+        """RKF78 steps per segment: 5 = the reference's fixed count (default), 0 = the opt-in step-length rule; include/scpp_hip.h"""
         _chk(self.lib.scpp_hip_set_discretization_steps(self.h, int(steps)), "set_discretization_steps")
 
     def discretize(self, mode=MODE_FOH | MODE_VT):

@@ -45,13 +45,15 @@ __device__ inline void forEachStage(F &&f)
 // RKF78 steps per segment.  The reference takes exactly 5 whatever the segment length (integrate_adaptive(stepper, ode, V, 0., dt,
 // dt / 5.) with an uncontrolled stepper, discretizationImplementation.hpp:141,154): at its own shipped RocketQuat configuration
 // (K = 15, 12 s) that is a step of 0.171 s and leaves ~1e-13 relative in A .. z.  At K = 50 the same 5 steps are 0.049 s long -- an
-// order-8 scheme then integrates to round-off four times over.  The kernel therefore takes
+// order-8 scheme then integrates to round-off four times over.  The kernel can therefore take (OPT-IN since round 4: the default
+// of a context is the reference's 5 -- SCvx accept / reject decisions hinge on the sign of a dJ of ~1e-10, and a 1e-13 change of
+// A .. z flips a handful of them)
 //      n = clamp(ceil(segment length / DISC_MAX_STEP), 1, DISC_STEPS_MAX)     (wave-uniform, per instance and call)
 // steps: never more than the reference's 5, and never a step longer than the reference's own at the configuration it ships --
 // K = 50, 12 s: 2 steps of 0.122 s, A .. z within 1e-13 of the 5-step result (measured: 3 steps 3.5e-15, 2 steps 1.0e-13, 1 step
 // 2.4e-11; K = 15: 5 steps as the reference); test-enforced against the DOP853 goldens at 1e-9 like before, and against the 5-step
 // kernel at 1e-11.  40 % of the stage evaluations at K = 50: discretize_kernel 4.2 -> 1.9 ms per launch, headline +4.2 % (same box).
-// scpp_hip_set_discretization_steps(ctx, n) pins the count at run time (n = 5: the reference's scheme literally; 0 = this rule);
+// scpp_hip_set_discretization_steps(ctx, n) sets the count at run time (n = 5: the reference's scheme literally, the default; 0 = this rule);
 // -DDISC_STEPS=n pins it at compile time.
 #ifndef DISC_STEPS
 #define DISC_STEPS 0

@@ -90,7 +90,7 @@ struct scpp_hip_ctx
     int last_active = 0;
     long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
     int stream_pools = 0;
-    int disc_steps = 0; // RKF78 steps per segment: 0 = discretize_kernel.h's rule, 1 .. 5 pinned
+    int disc_steps = 5; // RKF78 steps per segment: 5 = the reference's fixed count (default since round 4), 1 .. 4 pinned, 0 = discretize_kernel.h's step-length rule (opt-in)
 };
 
 namespace
@@ -512,12 +512,10 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
         return SCPP_E_ARG;
 #if !defined(SCPP_HIP_EMU) && !SCPP_TOOLCHAIN_VALIDATED
     {
-        static bool warned = false;
-        if (!warned)
-        {
-            warned = true;
+        static std::once_flag warned; // contexts are created from several host threads (`--gpus N`)
+        std::call_once(warned, [] {
             std::fprintf(stderr, "scpp_hip: built with an unvalidated toolchain (%s); run `pytest -m gpu` before trusting results\n", scpp_hip_version());
-        }
+        });
     }
 #endif
     int prev_device = -1;
@@ -754,7 +752,7 @@ int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const
 
 int scpp_hip_set_discretization_steps(scpp_hip_ctx *c, int steps)
 {
-    if (!c || steps < 0 || steps > DISC_STEPS_MAX) // 0 = the adaptive rule, 1 .. 5 pinned
+    if (!c || steps < 0 || steps > DISC_STEPS_MAX) // 5 = the reference (default), 0 = the step-length rule (opt-in), 1 .. 4 pinned
         return SCPP_E_ARG;
     c->disc_steps = steps;
     return SCPP_OK;
@@ -1092,8 +1090,8 @@ SCvxBuffers scvxBuffersRange(scpp_hip_ctx *c, Range r)
 {
     SCvxBuffers v = scvxBuffers(c);
     const size_t f = size_t(r.first), K = size_t(c->K);
-    v.Xold += f * K * 14;
-    v.Uold += f * K * 4;
+    v.Xold += f * K * size_t(c->nx); // the pitch launchIpm snapshots with (ipm_kernel writes old_td at slot * K * nx)
+    v.Uold += f * K * size_t(c->nu);
     v.tr += f;
     v.last_cost += f;
     v.cost += f;
@@ -1160,7 +1158,9 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
     if (int rc = ensurePools(c, 1))
         return rc;
     // an instance is retired at the cap (scvxDecide); max_iterations <= 0: no iteration at all (the initial trajectory comes back)
-    const long max_rounds = c->scvx.max_iterations > 0 ? long(c->scvx.max_iterations) * SCVX_SOLVE_CAP + 8 : 0;
+    // (retired on a REJECTION with solves >= CAP x max_iterations: up to max_iterations accepted solves can follow the last rejection
+    // below the cap, hence CAP + 1)
+    const long max_rounds = c->scvx.max_iterations > 0 ? long(c->scvx.max_iterations) * (SCVX_SOLVE_CAP + 1) + 8 : 0;
     // One stream (measured: the two-stream skewed pipeline of scpp_hip_sc_solve loses here, rounds late in the run have few
     // active instances and are latency-bound either way).  The host does not wait for a round before enqueueing the next:
     // the active count is read back asynchronously every POLL rounds and looked at one poll later, so the device never
@@ -1233,6 +1233,7 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
 {
     constexpr int NX = T::NX, NU = T::NU;
     const int S = slots > 0 ? (slots < N ? slots : N) : (c->Bmax < N ? c->Bmax : N);
+    c->q_N = 0; // whatever fails from here on, the rows of a previous job are no longer valid (stream_download -> SCPP_E_STATE)
     // the engine's per-slot state is the batch state of scvx_setup: set it up on the first S instances' worth of slots
     // WITHOUT starting them (every slot starts empty and is filled by the first refill)
     if (int rc = scvxSetupFor(c, mp, so, x_init, S))
@@ -1262,7 +1263,6 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
             return SCPP_E_HIP;
     }
     (void)K;
-    c->q_N = N;
     CHECK_HIP(hipMemcpyAsync(c->q_xinit, x_init, size_t(N) * NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHECK_HIP(hipMemsetAsync(c->q_counters, 0, 4 * sizeof(int), c->stream));
     CHECK_HIP(hipMemsetAsync(c->q_slot_inst, 0xFF, size_t(c->Bmax) * sizeof(int), c->stream)); // -1: empty
@@ -1293,12 +1293,16 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
         return rc;
     std::vector<Range> pool;
     {
-        // keep the XCD groups of 8 instances intact (a performance nicety: tiny jobs split evenly instead)
-        const int per = S >= 16 * P ? (((S + P - 1) / P + 7) & ~7) : (S + P - 1) / P;
+        // exactly P pools (P <= S), sizes differing by at most one XCD group: whole groups of 8 slots where the job is large enough
+        // (a performance nicety), single slots otherwise
+        const int unit = S >= 16 * P ? 8 : 1;
+        const int units = S / unit, rem = S - units * unit; // the last pool also takes the slots beyond the last whole group
         int first = 0;
-        for (int p = 0; p < P && first < S; p++)
+        for (int p = 0; p < P; p++)
         {
-            const int cnt = first + per <= S ? per : S - first;
+            int cnt = (units / P + (p < units % P ? 1 : 0)) * unit;
+            if (p == P - 1)
+                cnt += rem;
             pool.push_back(Range{first, cnt, p == 0 ? c->stream : c->pool_streams[size_t(p - 1)]});
             first += cnt;
         }
@@ -1308,6 +1312,7 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     CHECK_HIP(hipEventRecord(c->pool_events[0], c->stream));
     for (int p = 1; p < P; p++)
         CHECK_HIP(hipStreamWaitEvent(pool[size_t(p)].stream, c->pool_events[0], 0));
+    c->q_N = N; // from here on every failure goes through fail(), which resets it
     StreamQueue q;
     q.N = N;
     q.x_init = c->q_xinit;
@@ -1317,7 +1322,7 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     q.nconv = c->q_counters + 2;
     scpp_sc_opts sc = c->sc; // as built by scvx_setup
     // an instance needs at most max_iterations accepted + ~log2 rejected solves each; the queue drains in ceil(N/S) waves
-    const long per_instance = long(so->max_iterations) * SCVX_SOLVE_CAP + 8; // an instance is retired at the cap (scvxDecide)
+    const long per_instance = long(so->max_iterations) * (SCVX_SOLVE_CAP + 1) + 8; // retired at the cap on a rejection (scvxDecide) + the accepted solves after it
     const long max_rounds = per_instance * ((N + S - 1) / S + 1);
     constexpr int POLL = 4;
     bool pending = false;

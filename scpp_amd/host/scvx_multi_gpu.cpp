@@ -17,6 +17,7 @@
 #include <cstring>
 #include <thread>
 
+#include "gather_layout.hpp"
 #include "sc_algorithm.hpp"
 
 #define CHECK(call)                                                                                      \
@@ -73,10 +74,10 @@ int main(int argc, char **argv)
             inst.p.randomizeInitialState(seed, uint64_t(b));
             x_inits.push_back(inst.p.x_init);
         }
-        const int base = batch / gpus, rem = batch % gpus, nmax = base + (rem ? 1 : 0);
-        std::vector<int> lo(size_t(gpus) + 1, 0);
-        for (int g = 0; g < gpus; g++)
-            lo[size_t(g) + 1] = lo[size_t(g)] + base + (g < rem ? 1 : 0);
+        // shards, chunks and receive-buffer offsets of the one collective (gather_layout.hpp; CPU-tested with gpus > 1)
+        const scpp::GatherLayout GL = scpp::makeGatherLayout(batch, gpus, rowd, chunk_mb);
+        const int nmax = GL.nmax;
+        const std::vector<int> &lo = GL.lo;
 
         std::vector<int> devs(static_cast<size_t>(gpus));
         for (int g = 0; g < gpus; g++)
@@ -131,22 +132,18 @@ int main(int argc, char **argv)
         // ---- the one collective: all-gather of the result rows, <= chunk_mb per rank and call (xGMI is point-to-point: the
         //      receive buffer of a call is gpus x chunk).  Layout of `gathered` on every device: [chunk][rank][rows of the chunk]
         //      -> re-indexed on the host; each chunk is one ncclGroup over the local communicators.
-        const size_t rows_per = std::max<size_t>(1, size_t(chunk_mb * 1e6) / (size_t(rowd) * sizeof(double)));
+        const size_t rows_per = GL.rows_per;
         int n_coll = 0;
-        std::vector<std::pair<size_t, size_t>> chunks; // (first row, count) within a shard
-        for (size_t first = 0; first < size_t(nmax); first += rows_per)
-            chunks.emplace_back(first, std::min(rows_per, size_t(nmax) - first));
-        size_t off = 0;
-        std::vector<size_t> chunk_off;
-        for (const auto &c : chunks)
+        const std::vector<std::pair<size_t, size_t>> &chunks = GL.chunks; // (first row, count) within a shard
+        for (size_t ci = 0; ci < chunks.size(); ci++)
         {
-            chunk_off.push_back(off);
+            const auto &c = chunks[ci];
+            const size_t off = GL.chunk_off[ci];
             CHECK(ncclGroupStart());
             for (int g = 0; g < gpus; g++)
                 CHECK(ncclAllGather(stage[size_t(g)] + c.first * rowd, gathered[size_t(g)] + off, c.second * rowd, ncclDouble, comms[size_t(g)],
                                     streams[size_t(g)]));
             CHECK(ncclGroupEnd());
-            off += size_t(gpus) * c.second * rowd;
             n_coll++;
         }
         for (int g = 0; g < gpus; g++)
@@ -159,18 +156,7 @@ int main(int argc, char **argv)
         std::vector<double> hg(size_t(gpus) * size_t(nmax) * rowd), all(size_t(batch) * rowd), own;
         CHECK(hipSetDevice(0));
         CHECK(hipMemcpy(hg.data(), gathered[0], hg.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t ci = 0; ci < chunks.size(); ci++)
-            for (int g = 0; g < gpus; g++)
-            {
-                const int n = lo[size_t(g) + 1] - lo[size_t(g)];
-                for (size_t r = 0; r < chunks[ci].second; r++)
-                {
-                    const size_t row = chunks[ci].first + r;
-                    if (row < size_t(n))
-                        std::memcpy(&all[(size_t(lo[size_t(g)]) + row) * rowd], &hg[chunk_off[ci] + (size_t(g) * chunks[ci].second + r) * rowd],
-                                    size_t(rowd) * sizeof(double));
-                }
-            }
+        scpp::reindexGathered(GL, hg.data(), all.data());
         bool same = true;
         for (int g = 0; g < gpus; g++)
         {

@@ -1,5 +1,5 @@
 """bench.py's OWN N > 1 path (one process per rank, instance sharding, the single all-gather of the result rows) executed end
-to end on CPU: world size 2 over gloo with the CPU emulation build of the kernels standing in for the GPU library.  The
+to end on CPU: world sizes 2, 4 and 8 over gloo with the CPU emulation build of the kernels standing in for the GPU library.  The
 gathered payload must equal what a single process computes for the same instance ids (bitwise: instances are independent
 and the engine is deterministic)."""
 import json
@@ -13,31 +13,35 @@ import scpp_amd
 from conftest import ROOT
 
 
-def test_bench_world2_gloo_matches_single_process(model, emu_lib, tmp_path):
-    K, B, steps, warm, maxit, seed = 8, 3, 2, 1, 4, 20260927
+import pytest
+
+
+@pytest.mark.parametrize("world,K,B,steps,warm", [(2, 8, 3, 2, 1), (4, 6, 2, 3, 0), (8, 5, 2, 1, 0)])
+def test_bench_world_n_gloo_matches_single_process(model, emu_lib, tmp_path, world, K, B, steps, warm):
+    """world 2, 4 and 8 (the first 8-GPU run must not be the first time this code sees N > 2), odd step counts"""
+    maxit, seed = 4, 20260927
     dump = str(tmp_path / "rows.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29731 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warm),
            "--backend", "gloo", "--library", emu_lib, "--K", str(K), "--batch", str(B), "--max-iterations", str(maxit),
            "--no-cpu-baseline", "--no-extras", "--dump", dump,
-           "--gather-chunk-mb", "0.0025"]  # 2.5 kB (two rows) per rank and collective: the 6 rows of a rank travel in 3 all-gathers
+           "--gather-chunk-mb", str(2 * (K * 18 + 10) * 8e-6 + 1e-7)]  # two rows per rank and collective
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warm
+    assert line["n_gpus"] == world and line["steps"] == steps and line["warmup"] == warm
     g = line["config"]["gather"]
-    assert g["collectives"] == 3 and g["rows_per_collective"] == 2 and g["gathered_equals_local_bitwise"] is True
-    assert g["bytes_per_rank_per_collective"] <= 2500
+    assert g["collectives"] == (steps * B + 1) // 2 and g["rows_per_collective"] == 2 and g["gathered_equals_local_bitwise"] is True
+    assert g["bytes_per_rank_per_collective"] <= 2 * (K * 18 + 10) * 8
     r_ = line["roofline"]
     assert r_["kernel_time_s"] <= r_["timed_region_s"] * 1.001  # union of the launch spans, not their sum
-    assert line["config"]["instances_timed"] == 2 * steps * B
+    assert line["config"]["instances_timed"] == world * steps * B
     rows = np.load(dump)
-    assert rows.shape == (2 * steps * B, K * 18 + 10)
+    assert rows.shape == (world * steps * B, K * 18 + 10)
     got = scpp_amd.Context.unpack_stream_rows(rows, K)
     # the same instance ids through the plain batch entry point of one process
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
-    world = 2
     at = 0
     for rank in range(world):
         for i in range(steps):

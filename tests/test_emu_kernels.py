@@ -443,7 +443,7 @@ def test_emu_sc_zero_order_hold(oracle, emu_lib, tmp_path):
 
 
 def _adaptive_steps_case(oracle, model, lib, tol):
-    """discretize_kernel takes n = clamp(ceil(segment seconds / 0.171 s), 1, 5) RKF78 steps per segment (never more than the
+    """On request (scpp_hip_set_discretization_steps(ctx, 0)) discretize_kernel takes n = clamp(ceil(segment seconds / 0.171 s), 1, 5) RKF78 steps per segment (never more than the
     reference's 5, never a longer step than the reference's own at its shipped K = 15 / 12 s configuration): 2 steps at K = 50.
     Checked where it matters -- LATE iterates of SCvx runs (non-trivial attitude and thrust profiles), fixed-time first-order hold
     like the headline mode -- against the oracle's 5-step integration of the reference's Phi^-1 formulation."""
@@ -455,10 +455,14 @@ def _adaptive_steps_case(oracle, model, lib, tol):
         par = model.flow_params(model.randomized_initial_states(1, first=b)[0])
         ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K, 1, library=lib)
         ctx.set_flow_params(par[None]); ctx.upload_traj(X[None], U[None], [t]); ctx.discretize(scpp_amd.MODE_FOH)
+        out_default = ctx.download_dd()
+        ctx.set_discretization_steps(0); ctx.discretize(scpp_amd.MODE_FOH)  # the opt-in step-length rule
         out = ctx.download_dd()
         # scpp_hip_set_discretization_steps: 5 = the reference's count literally (tighter against the oracle), out of range refused
         ctx.set_discretization_steps(5); ctx.discretize(scpp_amd.MODE_FOH)
         out5 = ctx.download_dd()
+        # a fresh context takes the reference's five steps (round 4: the rule is opt-in)
+        assert all(np.array_equal(a, b) for n, a, b in zip("ABCSZ", out_default, out5) if n != "S")  # (S is not written for a fixed final time)
         if K == 30:
             with pytest.raises(scpp_amd.ScppHipError):
                 ctx.set_discretization_steps(6)
@@ -493,3 +497,39 @@ def test_emu_stream_ragged_configurations_equal_batch(model, emu_lib, K, N, S, P
     for k in ("X", "U", "sc_iters", "solves", "converged", "status", "ipm_iters"):
         assert np.array_equal(rows[k], ob[k]), k
     a.ctx.close(); b.ctx.close()
+
+
+def _rocket2d_stream_multi_pool_case(lib, tmp_path, K, N, configs, maxit=None):
+    """Rocket2D SCvx through the streaming engine with MORE THAN ONE slot pool must be bitwise the batch entry.
+    The nondimensionalised configuration converges and exercises rejections (SCvxAlgorithm.cpp:132-138, `td = old_td`: the roll-back
+    reads the snapshot ipm_kernel wrote at slot * K * nx -- round 3 offset the pools' views by RocketQuat's 14 / 4 instead)."""
+    import os
+    import shutil
+
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    p = cfg / "Rocket2D" / "SCvx.info"
+    p.write_text(p.read_text().replace("nondimensionalize                   false", "nondimensionalize                   true"))
+    m2 = scpp_amd.Rocket2D(str(cfg)).loadParameters()
+    x0 = m2.randomized_initial_states(N)
+    ref = scpp_amd.SCvxAlgorithm(m2, K=K, batch_max=N, library=lib, max_iterations=maxit).initialize()
+    nref = ref.solve(x0)
+    r = ref.getSolution()
+    assert (r["solves"] > r["sc_iters"]).any(), "the case must contain rejected candidates"
+    keys = ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status", "ipm_iters")
+    for slots, pools in configs:
+        alg = scpp_amd.SCvxAlgorithm(m2, K=K, batch_max=max(slots, 1), library=lib, max_iterations=maxit).initialize()
+        n = alg.solveStream(x0, slots=slots, pools=pools)
+        o = alg.getStreamSolution()
+        assert alg.ctx.stream_rounds()["pools"] == pools
+        assert (o["instance"] == np.arange(N)).all()
+        for key in keys:
+            assert np.array_equal(o[key], r[key]), (slots, pools, key)
+        assert n == nref
+        alg.ctx.close()
+    ref.ctx.close()
+    return int(nref), r
+
+
+def test_emu_rocket2d_stream_multi_pool_equals_batch(emu_lib, tmp_path):
+    _rocket2d_stream_multi_pool_case(emu_lib, tmp_path, 8, 6, ((4, 2), (5, 3), (3, 3)))

@@ -219,3 +219,20 @@ def test_cpp_host_rccl_all_gather_on_gpu(model, hip_lib):
     assert n == conv and abs(float(o["X"].sum()) - cs) <= 1e-9 * abs(cs)
     alg.ctx.close()
     print(r.stdout.strip().replace("\n", " | "))
+
+
+@pytest.mark.parametrize("batch,gpus,rowd,chunk_mb", [(65536, 8, 910, 64.0), (37, 5, 910, 0.02), (100, 4, 910, 0.06), (7, 8, 26, 0.0002),
+                                                        (1000, 3, 910, 0.75)])
+def test_all_gather_layout_and_reindexing_with_several_gpus(batch, gpus, rowd, chunk_mb):
+    """host/scvx_multi_gpu's chunked ncclAllGather with gpus > 1, uneven shards (incl. an empty one) and >= 3 chunks, on CPU: the
+    layout / re-indexing arithmetic (host/gather_layout.hpp) under the collective's semantics, every device's copy checked
+    (the test boxes have one GPU, so N > 1 never ran on hardware)."""
+    import subprocess
+
+    host = os.path.join(ROOT, "scpp_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "gather_layout_test"])
+    r = subprocess.run([os.path.join(host, "gather_layout_test"), str(batch), str(gpus), str(rowd), str(chunk_mb)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "wrong entries 0" in r.stdout
+    if (batch, gpus) == (37, 5):
+        assert "4 chunk(s)" in r.stdout and "shards 8 8 7 7 7" in r.stdout

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic, matrix-core and stall counters of the shipped kernels (rocprofv3 PMC; every counter group in its own pass, no
 # tracing flags), with the FETCH_SIZE / WRITE_SIZE calibration of tools/hbm_calib.hip measured in the same session.
-#   usage: bash tools/pmc_hbm.sh [tag] [batch]      -> gpurun_out/pmc_<tag>/summary.json (copy to profiles/r02_pmc_hbm_<tag>.json)
+#   usage: bash tools/pmc_hbm.sh [tag] [batch]      -> gpurun_out/pmc_<tag>/summary.json (copy to profiles/rNN_pmc_hbm_v<n>_<tag>.json)
 TAG=${1:-v1}; BATCH=${2:-4096}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 # the calibration kernels (tools/bin/ is not tracked: built here if the checkout is fresh)
@@ -47,6 +47,10 @@ try:
     S["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     S["commit"] = os.environ.get("GRAFT_COMMIT", "worktree")
+try:
+    sys.path.insert(0, "tools"); import csrc_hash; S["csrc_sha"] = csrc_hash.csrc_sha()  # identity of the kernel sources (bench.py: stale check)
+except Exception as e:
+    S["csrc_sha"] = "unknown: %s" % e
 # ---- calibration ----
 cf, _ = load("calib_fetch"); cw, _ = load("calib_write")
 B4 = float(4 << 30); R50 = (B4 / 8 // 50) * 400
