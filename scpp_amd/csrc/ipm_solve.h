@@ -58,46 +58,17 @@ __device__ inline void prepareFactor(const Ctx &c, bool identity, Glob &g)
 {
     using L = Lay<P>;
     const int k = c.lane, K = c.K;
-    if (k < K - 1)
+    if (k < K - 1 && identity)
     {
+        // initialisation (W = I): E^-1 = 1/2, q = 0.  In the main loop E^-1 is written by the predictor's right-hand-side phase
+        // (rhsSegChunk<.., 0>, which holds the slacks anyway) and q is recomputed where it is used (segRhsRow)
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        // load group -> compute -> store group: a row-by-row loop puts a store between consecutive rows' loads, which the
-        // compiler may not reorder, i.e. one exposed memory round trip per row
-        double einv[L::NL], qv[L::NL];
-        if (identity)
-        {
-#pragma unroll
-            for (int i = 0; i < L::NL; i++)
-            {
-                einv[i] = 0.5;
-                qv[i] = 0.;
-            }
-        }
-        else
-        {
-            double s1[L::NL], z1[L::NL], s2[L::NL], z2[L::NL];
-#pragma unroll
-            for (int i = 0; i < L::NL; i++)
-            {
-                s1[i] = sg[G_S1 * L::NL + i];
-                z1[i] = sg[G_Z1 * L::NL + i];
-                s2[i] = sg[G_S2 * L::NL + i];
-                z2[i] = sg[G_Z2 * L::NL + i];
-            }
-#pragma unroll
-            for (int i = 0; i < L::NL; i++)
-            {
-                const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i];
-                einv[i] = 0.25 * (r1 + r2);
-                qv[i] = (r1 - r2) / (r1 + r2);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < L::NL; i++)
         {
-            xs[L::X_EINV + i] = einv[i];
-            sg[G_QV * L::NL + i] = qv[i];
+            xs[L::X_EINV + i] = 0.5;
+            sg[G_QV * L::NL + i] = 0.;
         }
     }
     if (k < K)
@@ -482,6 +453,9 @@ __device__ inline void forSegChunks(F &&f)
 #endif
 #ifndef IPM_RES_CHUNK
 #define IPM_RES_CHUNK 7
+#endif
+#ifndef IPM_UPD_CHUNK
+#define IPM_UPD_CHUNK 5
 #endif
 // Rows 1 .. NP of a vector that starts at the trust-region cone are STRUCTURAL ZEROS in SCvx mode (the state rows of the cone:
 // saff / Lmul produce 0 there, and every cone operation maps zero rows to zero rows).  They are accessed through a second view
@@ -1089,6 +1063,86 @@ __device__ inline void stf(const SV &r, int f, const double (&v)[N])
         r[f + i] = v[i];
 }
 
+// =====================================================================================================
+// Segment rows (virtual control nu_k, its bound nu_b, the LP pair nu_b -/+ nu >= 0 and the multiplier lam of the dynamics row).
+// Round 4: everything a lane phase needs of a row is RECOMPUTED from the seven state fields (nu, nu_b, s1, z1, s2, z2, lam), the
+// product fields of the predictor (ds_aff dz_aff of the two LP cones) and wave-uniform scalars, with ONE set of expressions
+// (segRhs / segDir below) shared by the right-hand-side, direction and update phases.  Until round 3 the residuals (rz1, rz2, rxnu,
+// rxnub), the right-hand-side pieces (t1, t2, bnb, btn) and the seven final directions were stored by one phase and re-read by the
+// next: 103 field accesses per row and interior-point iteration, now 71 -- the kernel is bound by the bytes it moves,
+// and the workspace streams from HBM, so a field that is not stored is a field that is not written AND not read back.
+// =====================================================================================================
+template <int N>
+struct SegState
+{
+    double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N];
+};
+template <class P, int I0, int N>
+__device__ inline void ldSegState(const SV &sg, SegState<N> &q)
+{
+    using L = Lay<P>;
+    ldf<N>(sg, G_NU * L::NL + I0, q.nu);
+    ldf<N>(sg, G_NUB * L::NL + I0, q.nub);
+    ldf<N>(sg, G_S1 * L::NL + I0, q.s1);
+    ldf<N>(sg, G_Z1 * L::NL + I0, q.z1);
+    ldf<N>(sg, G_S2 * L::NL + I0, q.s2);
+    ldf<N>(sg, G_Z2 * L::NL + I0, q.z2);
+    ldf<N>(sg, G_LAM * L::NL + I0, q.lam);
+}
+// right-hand-side pieces of the eliminated LP pair of one row (pass 0: affine, pass 1: corrector with the predictor's products p1, p2)
+struct SegRhsRow
+{
+    double rz1, rz2, t1, t2, bnb, btn, einv, qv, d1, d2, dinv;
+};
+template <int PASS>
+__device__ inline SegRhsRow segRhsRow(double nu, double nub, double s1, double z1, double s2, double z2, double lam, double p1, double p2, double om,
+                                      double sigmu, double z3, double dz3)
+{
+    SegRhsRow o;
+    // residuals of the row at the current iterate (what phResiduals evaluates for the termination test)
+    o.rz1 = s1 - (nub - nu);
+    o.rz2 = s2 - (nub + nu);
+    const double rxnu = -lam + z1 - z2, rxnub = -z1 - z2 + z3;
+    double c1 = 0., c2 = 0.;
+    if (PASS)
+    {
+        c1 = (sigmu - p1) / s1;
+        c2 = (sigmu - p2) / s2;
+    }
+    o.d1 = z1 / s1;
+    o.d2 = z2 / s2;
+    o.t1 = o.d1 * om * o.rz1 - z1 + c1;
+    o.t2 = o.d2 * om * o.rz2 - z2 + c2;
+    const double bxnu = -om * rxnu + (-o.t1 + o.t2);
+    const double bxnub = -om * rxnub + (o.t1 + o.t2);
+    // E^-1, q and 1 / (d1 + d2) of the eliminated LP pair
+    const double r1 = s1 / z1, r2 = s2 / z2;
+    o.einv = 0.25 * (r1 + r2);
+    o.qv = (r1 - r2) / (r1 + r2);
+    o.dinv = 1. / (o.d1 + o.d2);
+    o.bnb = bxnub - dz3;
+    o.btn = bxnu - o.qv * o.bnb;
+    return o;
+}
+// Newton direction of one row from the block solve's multiplier direction vl (- border column * dsigma)
+struct SegDirRow
+{
+    double dlam, dnu, dnub, dz1, ds1, dz2, ds2;
+};
+__device__ inline SegDirRow segDirRow(const SegRhsRow &r, double vl, double bcl, double om, double dsig)
+{
+    SegDirRow o;
+    o.dlam = vl - bcl * dsig;
+    o.dnu = r.einv * (o.dlam + r.btn);
+    o.dnub = r.bnb * r.dinv - r.qv * o.dnu;
+    const double L1v = o.dnub - o.dnu, L2v = o.dnub + o.dnu;
+    o.dz1 = -r.d1 * L1v + r.t1;
+    o.ds1 = -om * r.rz1 + L1v;
+    o.dz2 = -r.d2 * L2v + r.t2;
+    o.ds2 = -om * r.rz2 + L2v;
+    return o;
+}
+
 // ---- residuals, duality gap, termination quantities ----
 struct ResAcc
 {
@@ -1108,28 +1162,24 @@ __device__ inline void resSegChunk(const SV &sg, const SV &dyz, double z3, ResAc
     ldf<N>(sg, G_LAM * L::NL + I0, lam);
     ldf<N>(dyz, L::DY_S + I0, S); // dS/dsigma column: zero for a fixed final time (SCvx), read through the padded view
     LOADS_ISSUED();
-    double r1[N], r2[N], rnu[N], rnub[N];
+    // (the row residuals are not stored: the right-hand-side / direction phases recompute them from the state, segRhsRow)
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
-        r1[i] = s1[i] - (nub[i] - nu[i]);
-        r2[i] = s2[i] - (nub[i] + nu[i]);
-        rnu[i] = -lam[i] + z1[i] - z2[i];
-        rnub[i] = -z1[i] - z2[i] + z3;
+        const double r1 = s1[i] - (nub[i] - nu[i]);
+        const double r2 = s2[i] - (nub[i] + nu[i]);
+        const double rnu = -lam[i] + z1[i] - z2[i];
+        const double rnub = -z1[i] - z2[i] + z3;
         p.sumnb += nub[i];
         p.gap += s1[i] * z1[i] + s2[i] * z2[i];
-        p.rz += r1[i] * r1[i] + r2[i] * r2[i];
+        p.rz += r1 * r1 + r2 * r2;
         p.zz += z1[i] * z1[i] + z2[i] * z2[i];
         p.ss += s1[i] * s1[i] + s2[i] * s2[i];
         p.yy += lam[i] * lam[i];
-        p.rx += rnu[i] * rnu[i] + rnub[i] * rnub[i];
+        p.rx += rnu * rnu + rnub * rnub;
         p.xx += nu[i] * nu[i] + nub[i] * nub[i];
         p.rxs += S[i] * lam[i];
     }
-    stf<N>(sg, G_RZ1 * L::NL + I0, r1);
-    stf<N>(sg, G_RZ2 * L::NL + I0, r2);
-    stf<N>(sg, G_RXNU * L::NL + I0, rnu);
-    stf<N>(sg, G_RXNUB * L::NL + I0, rnub);
 }
 template <class P>
 PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
@@ -1381,66 +1431,34 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
 // segment rows [I0, I0+N): LP blocks of nu / nu_b, fused with the condensation (kktPrep) of those rows
-template <class P, int I0, int N>
-__device__ inline void rhsSegChunk(const SV &sg, const SV &xs, int pass, double om, double sigmu, double dz3)
+template <class P, int I0, int N, int PASS>
+__device__ inline void rhsSegChunk(const SV &sg, const SV &xs, double om, double sigmu, double z3, double dz3)
 {
     using L = Lay<P>;
-    double s1[N], z1[N], s2[N], z2[N], rz1[N], rz2[N], rxnu[N], rxnub[N], ry[N];
-    ldf<N>(sg, G_S1 * L::NL + I0, s1);
-    ldf<N>(sg, G_Z1 * L::NL + I0, z1);
-    ldf<N>(sg, G_S2 * L::NL + I0, s2);
-    ldf<N>(sg, G_Z2 * L::NL + I0, z2);
-    ldf<N>(sg, G_RZ1 * L::NL + I0, rz1);
-    ldf<N>(sg, G_RZ2 * L::NL + I0, rz2);
-    ldf<N>(sg, G_RXNU * L::NL + I0, rxnu);
-    ldf<N>(sg, G_RXNUB * L::NL + I0, rxnub);
-    ldf<N>(sg, G_RY * L::NL + I0, ry);
-    double c1[N], c2[N];
+    SegState<N> q;
+    double ry[N];
     double p1[N], p2[N]; // ds_aff dz_aff of the two LP cones (written by the predictor's direction phase)
-    if (pass)
+    ldSegState<P, I0, N>(sg, q);
+    ldf<N>(sg, G_RY * L::NL + I0, ry);
+    if (PASS)
     {
         ldf<N>(sg, G_DS1 * L::NL + I0, p1);
         ldf<N>(sg, G_DS2 * L::NL + I0, p2);
     }
     LOADS_ISSUED();
-    if (pass)
-    {
-#pragma unroll
-        for (int i = 0; i < N; i++)
-        {
-            c1[i] = (sigmu - p1[i]) / s1[i];
-            c2[i] = (sigmu - p2[i]) / s2[i];
-        }
-    }
-    else
-    {
-#pragma unroll
-        for (int i = 0; i < N; i++)
-            c1[i] = c2[i] = 0.;
-    }
-    double t1[N], t2[N], bnb[N], btn[N], rho[N];
+    double rho[N], einv[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
-        const double d1 = z1[i] / s1[i], d2 = z2[i] / s2[i];
-        t1[i] = d1 * om * rz1[i] - z1[i] + c1[i];
-        t2[i] = d2 * om * rz2[i] - z2[i] + c2[i];
-        const double bxnu = -om * rxnu[i] + (-t1[i] + t2[i]);
-        const double bxnub = -om * rxnub[i] + (t1[i] + t2[i]);
+        const SegRhsRow r = segRhsRow<PASS>(q.nu[i], q.nub[i], q.s1[i], q.z1[i], q.s2[i], q.z2[i], q.lam[i], PASS ? p1[i] : 0., PASS ? p2[i] : 0., om,
+                                            sigmu, z3, dz3);
         const double by = -om * ry[i];
-        // E^-1 and q of the eliminated LP pair, recomputed from the slacks this chunk holds anyway (same expressions as
-        // prepareFactor, whose X_EINV the factor sweep uses): three divisions instead of two more rows from memory
-        const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i];
-        const double einv = 0.25 * (r1 + r2), qv = (r1 - r2) / (r1 + r2);
-        bnb[i] = bxnub - dz3;
-        btn[i] = bxnu - qv * bnb[i];
-        rho[i] = by + einv * btn[i];
+        rho[i] = by + r.einv * r.btn;
+        einv[i] = r.einv;
     }
-    stf<N>(sg, G_TZ1 * L::NL + I0, t1);
-    stf<N>(sg, G_TZ2 * L::NL + I0, t2);
-    stf<N>(sg, G_BNB * L::NL + I0, bnb);
-    stf<N>(sg, G_BTN * L::NL + I0, btn);
     stf<N>(xs, L::X_RHO + I0, rho);
+    if (!PASS)
+        stf<N>(xs, L::X_EINV + I0, einv); // E^-1 of the factorisation (one per iteration: the predictor pass writes it)
 }
 template <class P, int PASS>
 PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
@@ -1492,7 +1510,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     g.dz3 = -b.n1;
     it.bts = b.s - g.Hsd * b.ds / g.Hdd;
     it.b = b;
-    const double g_dz3 = g.dz3;
+    const double g_dz3 = g.dz3, g_z3 = g.z3;
     PUT_BEGIN();
     PUT(gp, g, dz3);
     PUT(ip_, it, tzs);
@@ -1561,78 +1579,50 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     }
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, pass, om, sigmu, g_dz3); });
+        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value, PASS>(sg, v.xs, om, sigmu, g_z3, g_dz3); });
     }
     WAVE_SYNC();
 }
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
-template <class P, int I0, int N>
-__device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double dsig, double &ainv, double &sumdnb, bool store_final)
+template <class P, int I0, int N, int PASS>
+__device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig, double &ainv,
+                                   double &sumdnb)
 {
     using L = Lay<P>;
-    double vl[N], bcl[N], btn[N], bnb[N];
-    double s1[N], z1[N], s2[N], z2[N], tz1[N], tz2[N], rz1[N], rz2[N];
+    SegState<N> q;
+    double vl[N], bcl[N], p1[N], p2[N];
     ldf<N>(xs, L::X_VL + I0, vl);
     ldf<N>(xsz, L::X_BCL + I0, bcl); // border column: zero in SCvx mode (not stored)
-    ldf<N>(sg, G_BTN * L::NL + I0, btn);
-    ldf<N>(sg, G_BNB * L::NL + I0, bnb);
-    ldf<N>(sg, G_S1 * L::NL + I0, s1);
-    ldf<N>(sg, G_Z1 * L::NL + I0, z1);
-    ldf<N>(sg, G_S2 * L::NL + I0, s2);
-    ldf<N>(sg, G_Z2 * L::NL + I0, z2);
-    ldf<N>(sg, G_TZ1 * L::NL + I0, tz1);
-    ldf<N>(sg, G_TZ2 * L::NL + I0, tz2);
-    ldf<N>(sg, G_RZ1 * L::NL + I0, rz1);
-    ldf<N>(sg, G_RZ2 * L::NL + I0, rz2);
+    ldSegState<P, I0, N>(sg, q);
+    if (PASS)
+    {
+        ldf<N>(sg, G_DS1 * L::NL + I0, p1);
+        ldf<N>(sg, G_DS2 * L::NL + I0, p2);
+    }
     LOADS_ISSUED();
-    double dlam[N], dnu[N], dnub[N], dz1[N], ds1[N], dz2[N], ds2[N];
+    double o1[N], o2[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
-        // E^-1, q and 1/(d1 + d2) of the eliminated LP pair from the slacks (same expressions as prepareFactor / rhsSegChunk)
-        const double r1 = s1[i] / z1[i], r2 = s2[i] / z2[i], d1 = z1[i] / s1[i], d2 = z2[i] / s2[i];
-        const double einv = 0.25 * (r1 + r2), qv = (r1 - r2) / (r1 + r2), dinv = 1. / (d1 + d2);
-        dlam[i] = vl[i] - bcl[i] * dsig;
-        dnu[i] = einv * (dlam[i] + btn[i]);
-        dnub[i] = bnb[i] * dinv - qv * dnu[i];
-        sumdnb += dnub[i];
-        const double L1v = dnub[i] - dnu[i], L2v = dnub[i] + dnu[i];
-        dz1[i] = -d1 * L1v + tz1[i];
-        ds1[i] = -om * rz1[i] + L1v;
-        dz2[i] = -d2 * L2v + tz2[i];
-        ds2[i] = -om * rz2[i] + L2v;
-        double m1 = -ds1[i] / s1[i], m2 = -dz1[i] / z1[i], m3 = -ds2[i] / s2[i], m4 = -dz2[i] / z2[i];
+        const SegRhsRow r = segRhsRow<PASS>(q.nu[i], q.nub[i], q.s1[i], q.z1[i], q.s2[i], q.z2[i], q.lam[i], PASS ? p1[i] : 0., PASS ? p2[i] : 0., om,
+                                            sigmu, z3, dz3);
+        const SegDirRow d = segDirRow(r, vl[i], bcl[i], om, dsig);
+        sumdnb += d.dnub;
+        double m1 = -d.ds1 / q.s1[i], m2 = -d.dz1 / q.z1[i], m3 = -d.ds2 / q.s2[i], m4 = -d.dz2 / q.z2[i];
         m1 = m1 > m2 ? m1 : m2;
         m3 = m3 > m4 ? m3 : m4;
         m1 = m1 > m3 ? m1 : m3;
         ainv = m1 > ainv ? m1 : ainv;
+        o1[i] = d.ds1 * d.dz1;
+        o2[i] = d.ds2 * d.dz2;
     }
-    if (store_final)
+    if (!PASS)
     {
-        stf<N>(sg, G_DLAM * L::NL + I0, dlam);
-        stf<N>(sg, G_DNU * L::NL + I0, dnu);
-        stf<N>(sg, G_DNUB * L::NL + I0, dnub);
-    }
-    if (store_final)
-    {
-        stf<N>(sg, G_DZ1 * L::NL + I0, dz1);
-        stf<N>(sg, G_DS1 * L::NL + I0, ds1);
-        stf<N>(sg, G_DZ2 * L::NL + I0, dz2);
-        stf<N>(sg, G_DS2 * L::NL + I0, ds2);
-    }
-    else
-    {
-        // predictor: the corrector's right-hand side needs the products ds_aff dz_aff only (rhsSegChunk, pass 1)
-        double p1[N], p2[N];
-#pragma unroll
-        for (int i = 0; i < N; i++)
-        {
-            p1[i] = ds1[i] * dz1[i];
-            p2[i] = ds2[i] * dz2[i];
-        }
-        stf<N>(sg, G_DS1 * L::NL + I0, p1);
-        stf<N>(sg, G_DS2 * L::NL + I0, p2);
+        // predictor: the corrector's right-hand side needs the products ds_aff dz_aff only (segRhsRow<1>).  The corrector stores
+        // NOTHING: phUpdate recomputes the final direction of a row from the same inputs (state, products, vl)
+        stf<N>(sg, G_DS1 * L::NL + I0, o1);
+        stf<N>(sg, G_DS2 * L::NL + I0, o2);
     }
 }
 // One chunk as a function of its own: inside phDirSeg the scheduler of the (long) enclosing block turned the last chunk into
@@ -1642,8 +1632,8 @@ struct DirChunkOut
 {
     double ainv, sumdnb;
 };
-template <class P, int I0, int N, bool STORE_FINAL>
-PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, double ainv, double sumdnb)
+template <class P, int I0, int N, int PASS>
+PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu, double z3, double dz3, double dsig, double ainv, double sumdnb)
 {
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
@@ -1653,7 +1643,7 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double dsig, 
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N>(sg, xs, padView(xs, scvxMode(c.ip)), om, dsig, o.ainv, o.sumdnb, STORE_FINAL);
+        dirSegChunk<P, I0, N, PASS>(sg, xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
     }
     return o;
 }
@@ -1800,8 +1790,9 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const double om = 1. - sigma_c;
     double ainv = ip_->part_ainv, finite_chk = ip_->part_fin;
     double sumdnb = 0.;
+    const double sigmu = sigma_c * double(ip_->mu), z3 = gp->z3, dz3 = gp->dz3;
     forSegChunks<P, IPM_DIR_CHUNK>([&](auto i0, auto n) {
-        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, pass != 0>(cin, om, g.dsig, ainv, sumdnb);
+        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, PASS>(cin, om, sigmu, z3, dz3, g.dsig, ainv, sumdnb);
         ainv = o.ainv;
         sumdnb = o.sumdnb;
     });
@@ -1926,6 +1917,39 @@ __device__ inline void axpyFieldGroup(const SV &rec, const int (&fDst)[NF], cons
         for (int i = 0; i < N; i++)
             rec[fDst[f] + i] = d[f][i] + alpha * x[f][i];
 }
+template <class P, int I0, int N>
+__device__ inline void updSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig, double alpha)
+{
+    using L = Lay<P>;
+    SegState<N> q;
+    double vl[N], bcl[N], p1[N], p2[N];
+    ldf<N>(xs, L::X_VL + I0, vl);
+    ldf<N>(xsz, L::X_BCL + I0, bcl);
+    ldSegState<P, I0, N>(sg, q);
+    ldf<N>(sg, G_DS1 * L::NL + I0, p1);
+    ldf<N>(sg, G_DS2 * L::NL + I0, p2);
+    LOADS_ISSUED();
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        const SegRhsRow r = segRhsRow<1>(q.nu[i], q.nub[i], q.s1[i], q.z1[i], q.s2[i], q.z2[i], q.lam[i], p1[i], p2[i], om, sigmu, z3, dz3);
+        const SegDirRow d = segDirRow(r, vl[i], bcl[i], om, dsig);
+        q.nu[i] = q.nu[i] + alpha * d.dnu;
+        q.nub[i] = q.nub[i] + alpha * d.dnub;
+        q.lam[i] = q.lam[i] + alpha * d.dlam;
+        q.s1[i] = q.s1[i] + alpha * d.ds1;
+        q.z1[i] = q.z1[i] + alpha * d.dz1;
+        q.s2[i] = q.s2[i] + alpha * d.ds2;
+        q.z2[i] = q.z2[i] + alpha * d.dz2;
+    }
+    stf<N>(sg, G_NU * L::NL + I0, q.nu);
+    stf<N>(sg, G_NUB * L::NL + I0, q.nub);
+    stf<N>(sg, G_LAM * L::NL + I0, q.lam);
+    stf<N>(sg, G_S1 * L::NL + I0, q.s1);
+    stf<N>(sg, G_Z1 * L::NL + I0, q.z1);
+    stf<N>(sg, G_S2 * L::NL + I0, q.s2);
+    stf<N>(sg, G_Z2 * L::NL + I0, q.z2);
+}
 template <class P>
 PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
@@ -1958,9 +1982,13 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     }
     if (v.vsg)
     {
-        axpyFieldGroup<L::NL, 3>(sg, {G_NU * L::NL, G_NUB * L::NL, G_LAM * L::NL}, {G_DNU * L::NL, G_DNUB * L::NL, G_DLAM * L::NL}, alpha);
-        axpyFieldGroup<L::NL, 2>(sg, {G_S1 * L::NL, G_Z1 * L::NL}, {G_DS1 * L::NL, G_DZ1 * L::NL}, alpha);
-        axpyFieldGroup<L::NL, 2>(sg, {G_S2 * L::NL, G_Z2 * L::NL}, {G_DS2 * L::NL, G_DZ2 * L::NL}, alpha);
+        // the corrector direction of the segment rows is recomputed here from what phDirSeg<1> read (state, predictor products, the
+        // block solve's multiplier direction) instead of being stored by it and loaded back: segRhsRow<1> / segDirRow
+        const double sigma_c = ip_->sigma_c, om = 1. - sigma_c, sigmu = sigma_c * double(ip_->mu);
+        const SV xsz = padView(v.xs, scvx);
+        forSegChunks<P, IPM_UPD_CHUNK>([&](auto i0, auto n) {
+            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
+        });
     }
     g.sig += alpha * g.dsig;
     g.dsg += alpha * g.ddsg;
