@@ -93,6 +93,7 @@ inline double readLane(double v, int src) { return __shfl(v, src); }
 template <int J>
 inline double rowBcast(double v) { const int l = threadIdx.x & 63; return __shfl(v, (l & ~15) | J); }
 inline bool anyLane(bool p) { int v = p ? 1 : 0; for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m); return v != 0; }
+inline double prevLane(double v) { const int l = threadIdx.x & 63; const double o = __shfl(v, l > 0 ? l - 1 : 0); return l > 0 ? o : 0.; }
 #else
 template <int CTRL>
 __device__ __forceinline__ double dppMove(double v)
@@ -120,6 +121,8 @@ __device__ __forceinline__ double readLane(double v, int src)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ bool anyLane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// value of lane - 1 (lane 0: 0): wave_shr:1 on the VALU data path (GFX9 wavefront shift)
+__device__ __forceinline__ double prevLane(double v) { return dppMove<0x138>(v); }
 #endif
 // ---- exchanges ACROSS the four rows of 16 lanes, still on the VALU data path (gfx950: v_permlane16_swap / v_permlane32_swap) ----
 // v_permlane16_swap vdst, src: rows 1 / 3 of vdst <-> rows 0 / 2 of src; v_permlane32_swap: lanes 32..63 of vdst <-> lanes 0..31 of

@@ -213,9 +213,30 @@ struct Settings
     int use_mfma;
 };
 
+// LDS address space of the wave-uniform state and of the LDS-resident segment fields (plain pointers in the CPU emulation)
+#ifdef SCPP_HIP_EMU
+#define LDSP
+#else
+#define LDSP __attribute__((address_space(3)))
+#endif
+// Segment fields that live in LDS for the duration of the main loop (round 4).  gfx950 has 160 KB of LDS per CU = 20 KB for each of
+// the 8 wavefronts the register file admits, of which the kernel used 3.6 KB; the workspace on the other hand streams from HBM in
+// every phase.  The three most-travelled fields of the segment records -- lam (read 8 x, written once per
+// interior-point iteration), nu (7 + 1) and nu_b (6 + 1): 24 of the 71 field accesses per row -- are copied into LDS after the
+// initialisation, used from there by every per-iteration phase, and copied back when the solve ends (the warm start of the next
+// launch reads them from the workspace).  Element (slot, row i, segment k) lives at segl[(slot * NL + i) * pitch + k]: a lane = segment
+// access is one conflict-free ds_read_b64 / ds_write_b64.  K = 50: 3 x 14 x 50 x 8 = 16 800 B + 3.0 KB static <= 20 480 B.
+enum SegLdsSlot
+{
+    SL_LAM = 0,
+    SL_NU,
+    SL_NUB,
+    NSEGLDS
+};
 // everything a wavefront needs to know about its instance
 struct Ctx
 {
+    LDSP double *segl; // [NSEGLDS][NL][pitch] LDS-resident segment fields (main loop only)
     int K, lane;
     int pitch;   // row pitch of the field-major records (doubles)
     double *st;  // [STREC][pitch]   field-major
@@ -228,6 +249,13 @@ struct Ctx
     const double *A, *B, *C, *S, *Z; // dd of this instance
     const double *ip;                // instance parameters
 };
+
+// dynamic LDS of ipm_kernel<P> (bytes): the LDS-resident segment fields
+template <class P>
+__host__ __device__ inline unsigned segLdsBytes(int K)
+{
+    return unsigned(NSEGLDS * Lay<P>::NL * recPitch(K) * 8);
+}
 
 // ---------------- the table, evaluated ----------------
 // Every index into the table is a template constant (sfor hands the loop counter over as an integral_constant), so that the

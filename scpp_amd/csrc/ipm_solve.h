@@ -446,16 +446,16 @@ __device__ inline void forSegChunks(F &&f)
     }
 }
 #ifndef IPM_DIR_CHUNK
-#define IPM_DIR_CHUNK 5
+#define IPM_DIR_CHUNK 7 // (5 until round 4: with the recomputing chunks 7 rows = two chunks measured +0.4 %)
 #endif
 #ifndef IPM_RHS_CHUNK
-#define IPM_RHS_CHUNK 5
+#define IPM_RHS_CHUNK 7 // (5 until round 4: with the recomputing chunks 7 rows = two chunks measured +0.4 %)
 #endif
 #ifndef IPM_RES_CHUNK
 #define IPM_RES_CHUNK 7
 #endif
 #ifndef IPM_UPD_CHUNK
-#define IPM_UPD_CHUNK 5
+#define IPM_UPD_CHUNK 7 // (5 until round 4: with the recomputing chunks 7 rows = two chunks measured +0.4 %)
 #endif
 // Rows 1 .. NP of a vector that starts at the trust-region cone are STRUCTURAL ZEROS in SCvx mode (the state rows of the cone:
 // saff / Lmul produce 0 there, and every cone operation maps zero rows to zero rows).  They are accessed through a second view
@@ -1077,17 +1077,38 @@ struct SegState
 {
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N];
 };
+// this lane's view of the LDS-resident segment fields (ipm_kernel.h: SegLdsSlot): rows [I0, I0 + N) of slot SLOT
+struct SegLds
+{
+    LDSP double *p; // + segment index
+    int pitch;
+};
+__device__ inline SegLds makeSegLds(const Ctx &c, int seg) { return SegLds{c.segl + seg, c.pitch}; }
+template <class P, int SLOT, int I0, int N>
+__device__ inline void ldl(const SegLds &l, double (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch];
+}
+template <class P, int SLOT, int I0, int N>
+__device__ inline void stl(const SegLds &l, const double (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch] = v[i];
+}
 template <class P, int I0, int N>
-__device__ inline void ldSegState(const SV &sg, SegState<N> &q)
+__device__ inline void ldSegState(const SV &sg, const SegLds &sl, SegState<N> &q)
 {
     using L = Lay<P>;
-    ldf<N>(sg, G_NU * L::NL + I0, q.nu);
-    ldf<N>(sg, G_NUB * L::NL + I0, q.nub);
     ldf<N>(sg, G_S1 * L::NL + I0, q.s1);
     ldf<N>(sg, G_Z1 * L::NL + I0, q.z1);
     ldf<N>(sg, G_S2 * L::NL + I0, q.s2);
     ldf<N>(sg, G_Z2 * L::NL + I0, q.z2);
-    ldf<N>(sg, G_LAM * L::NL + I0, q.lam);
+    ldl<P, SL_NU, I0, N>(sl, q.nu);
+    ldl<P, SL_NUB, I0, N>(sl, q.nub);
+    ldl<P, SL_LAM, I0, N>(sl, q.lam);
 }
 // right-hand-side pieces of the eliminated LP pair of one row (pass 0: affine, pass 1: corrector with the predictor's products p1, p2)
 struct SegRhsRow
@@ -1149,17 +1170,17 @@ struct ResAcc
     double gap, rx, ry, rz, xx, yy, zz, ss, rxs, sumnb;
 };
 template <class P, int I0, int N>
-__device__ inline void resSegChunk(const SV &sg, const SV &dyz, double z3, ResAcc &p)
+__device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz, double z3, ResAcc &p)
 {
     using L = Lay<P>;
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N], S[N];
-    ldf<N>(sg, G_NU * L::NL + I0, nu);
-    ldf<N>(sg, G_NUB * L::NL + I0, nub);
     ldf<N>(sg, G_S1 * L::NL + I0, s1);
     ldf<N>(sg, G_Z1 * L::NL + I0, z1);
     ldf<N>(sg, G_S2 * L::NL + I0, s2);
     ldf<N>(sg, G_Z2 * L::NL + I0, z2);
-    ldf<N>(sg, G_LAM * L::NL + I0, lam);
+    ldl<P, SL_NU, I0, N>(sl, nu);
+    ldl<P, SL_NUB, I0, N>(sl, nub);
+    ldl<P, SL_LAM, I0, N>(sl, lam);
     ldf<N>(dyz, L::DY_S + I0, S); // dS/dsigma column: zero for a fixed final time (SCvx), read through the padded view
     LOADS_ISSUED();
     // (the row residuals are not stored: the right-hand-side / direction phases recompute them from the state, segRhsRow)
@@ -1196,12 +1217,14 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const bool scvx = scvxMode(ip);
     const SV stz = padView(v.st, scvx);
     const SV dyz = padView(v.dy, scvx); // for the S column only
+    // LDS-resident segment fields of this lane's segment and of the previous one (lanes without a segment read segment 0, masked)
+    const SegLds sl = makeSegLds(c, v.vsg ? k : 0), slP = makeSegLds(c, (k > 0 && k < v.K) ? k - 1 : 0);
     ResAcc p;
     p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
     double p_dl = 0.;
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, dyz, g_z3, p); });
+        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, sl, dyz, g_z3, p); });
     }
     if (v.vst)
     {
@@ -1252,10 +1275,17 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             sfor<NXV>([&](auto jt) { ra[decltype(jt)::value] = dy[L::DY_A + i * NX + P::XMAP[decltype(jt)::value]]; });
             sfor<NUV>([&](auto jt) { rb[decltype(jt)::value] = dy[L::DY_B + i * NU + P::UMAP[decltype(jt)::value]]; });
             sfor<NUV>([&](auto jt) { rc[decltype(jt)::value] = dy[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
+            // C of the PREVIOUS segment = what lane k - 1 just loaded as its own C row: one wavefront shift instead of a second load
+            // (the fiber emulator cannot exchange inside a divergent region: it reads the same value from memory)
+#ifdef SCPP_HIP_EMU
             sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = dyP[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
-            const double l = mk * double(sg[G_LAM * L::NL + i]), lp = mp * double(sgP[G_LAM * L::NL + i]);
+#else
+            (void)dyP;
+            sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = prevLane(rc[decltype(jt)::value]); });
+#endif
+            const double l = mk * sl.p[(SL_LAM * L::NL + i) * sl.pitch], lp = mp * slP.p[(SL_LAM * L::NL + i) * slP.pitch];
             const int xi = L::XINV.v[i]; // stage variable of state i, -1: pinned
-            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dyz[L::DY_S + i] * g_sig - sg[G_NU * L::NL + i] - dy[L::DY_Z + i];
+            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dyz[L::DY_S + i] * g_sig - sl.p[(SL_NU * L::NL + i) * sl.pitch] - dy[L::DY_Z + i];
 #pragma unroll
             for (int j = 0; j < NXV; j++)
             {
@@ -1432,13 +1462,13 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 // ---- right-hand side of one Newton system: t = W^-2 rz' + W^-1(lambda \ ds) ; bx = -rx' + L't ; condensation ----
 // segment rows [I0, I0+N): LP blocks of nu / nu_b, fused with the condensation (kktPrep) of those rows
 template <class P, int I0, int N, int PASS>
-__device__ inline void rhsSegChunk(const SV &sg, const SV &xs, double om, double sigmu, double z3, double dz3)
+__device__ inline void rhsSegChunk(const SV &sg, const SegLds &sl, const SV &xs, double om, double sigmu, double z3, double dz3)
 {
     using L = Lay<P>;
     SegState<N> q;
     double ry[N];
     double p1[N], p2[N]; // ds_aff dz_aff of the two LP cones (written by the predictor's direction phase)
-    ldSegState<P, I0, N>(sg, q);
+    ldSegState<P, I0, N>(sg, sl, q);
     ldf<N>(sg, G_RY * L::NL + I0, ry);
     if (PASS)
     {
@@ -1579,22 +1609,22 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     }
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value, PASS>(sg, v.xs, om, sigmu, g_z3, g_dz3); });
+        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value, PASS>(sg, makeSegLds(c, v.k), v.xs, om, sigmu, g_z3, g_dz3); });
     }
     WAVE_SYNC();
 }
 
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
 template <class P, int I0, int N, int PASS>
-__device__ inline void dirSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig, double &ainv,
-                                   double &sumdnb)
+__device__ inline void dirSegChunk(const SV &sg, const SegLds &sl, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3,
+                                   double dsig, double &ainv, double &sumdnb)
 {
     using L = Lay<P>;
     SegState<N> q;
     double vl[N], bcl[N], p1[N], p2[N];
     ldf<N>(xs, L::X_VL + I0, vl);
     ldf<N>(xsz, L::X_BCL + I0, bcl); // border column: zero in SCvx mode (not stored)
-    ldSegState<P, I0, N>(sg, q);
+    ldSegState<P, I0, N>(sg, sl, q);
     if (PASS)
     {
         ldf<N>(sg, G_DS1 * L::NL + I0, p1);
@@ -1643,7 +1673,7 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu,
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N, PASS>(sg, xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
+        dirSegChunk<P, I0, N, PASS>(sg, makeSegLds(c, k), xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
     }
     return o;
 }
@@ -1673,8 +1703,9 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         if (v.vsg)
         {
             double S[L::NL], vl[L::NL], bcl[L::NL];
+            // SCvx (fixed final time): S = 0, so neither product needs its other factor -- all three through the padded view
             ldf<L::NL>(padView(dy, scvx), L::DY_S, S);
-            ldf<L::NL>(v.xs, L::X_VL, vl);
+            ldf<L::NL>(padView(v.xs, scvx), L::X_VL, vl);
             ldf<L::NL>(padView(v.xs, scvx), L::X_BCL, bcl);
 #pragma unroll
             for (int i = 0; i < L::NL; i++)
@@ -1918,14 +1949,15 @@ __device__ inline void axpyFieldGroup(const SV &rec, const int (&fDst)[NF], cons
             rec[fDst[f] + i] = d[f][i] + alpha * x[f][i];
 }
 template <class P, int I0, int N>
-__device__ inline void updSegChunk(const SV &sg, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig, double alpha)
+__device__ inline void updSegChunk(const SV &sg, const SegLds &sl, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig,
+                                   double alpha)
 {
     using L = Lay<P>;
     SegState<N> q;
     double vl[N], bcl[N], p1[N], p2[N];
     ldf<N>(xs, L::X_VL + I0, vl);
     ldf<N>(xsz, L::X_BCL + I0, bcl);
-    ldSegState<P, I0, N>(sg, q);
+    ldSegState<P, I0, N>(sg, sl, q);
     ldf<N>(sg, G_DS1 * L::NL + I0, p1);
     ldf<N>(sg, G_DS2 * L::NL + I0, p2);
     LOADS_ISSUED();
@@ -1942,13 +1974,48 @@ __device__ inline void updSegChunk(const SV &sg, const SV &xs, const SV &xsz, do
         q.s2[i] = q.s2[i] + alpha * d.ds2;
         q.z2[i] = q.z2[i] + alpha * d.dz2;
     }
-    stf<N>(sg, G_NU * L::NL + I0, q.nu);
-    stf<N>(sg, G_NUB * L::NL + I0, q.nub);
-    stf<N>(sg, G_LAM * L::NL + I0, q.lam);
+    stl<P, SL_NU, I0, N>(sl, q.nu);
+    stl<P, SL_NUB, I0, N>(sl, q.nub);
+    stl<P, SL_LAM, I0, N>(sl, q.lam);
     stf<N>(sg, G_S1 * L::NL + I0, q.s1);
     stf<N>(sg, G_Z1 * L::NL + I0, q.z1);
     stf<N>(sg, G_S2 * L::NL + I0, q.s2);
     stf<N>(sg, G_Z2 * L::NL + I0, q.z2);
+}
+// the LDS-resident segment fields (ipm_kernel.h: SegLdsSlot): workspace -> LDS after the initialisation, LDS -> workspace when the
+// solve ends (warm start of the next launch; nothing else reads them)
+template <class P, bool TO_LDS>
+PHASE_FN void phSegLdsCopy(const PRIV Ctx *cin)
+{
+    using L = Lay<P>;
+    const Ctx c = uniformCtx(cin);
+    const int k = c.lane;
+    if (k < c.K - 1)
+    {
+        const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
+        const SegLds sl = makeSegLds(c, k);
+        double nu[L::NL], nub[L::NL], lam[L::NL];
+        if (TO_LDS)
+        {
+            ldf<L::NL>(sg, G_NU * L::NL, nu);
+            ldf<L::NL>(sg, G_NUB * L::NL, nub);
+            ldf<L::NL>(sg, G_LAM * L::NL, lam);
+            LOADS_ISSUED();
+            stl<P, SL_NU, 0, L::NL>(sl, nu);
+            stl<P, SL_NUB, 0, L::NL>(sl, nub);
+            stl<P, SL_LAM, 0, L::NL>(sl, lam);
+        }
+        else
+        {
+            ldl<P, SL_NU, 0, L::NL>(sl, nu);
+            ldl<P, SL_NUB, 0, L::NL>(sl, nub);
+            ldl<P, SL_LAM, 0, L::NL>(sl, lam);
+            stf<L::NL>(sg, G_NU * L::NL, nu);
+            stf<L::NL>(sg, G_NUB * L::NL, nub);
+            stf<L::NL>(sg, G_LAM * L::NL, lam);
+        }
+    }
+    WAVE_SYNC();
 }
 template <class P>
 PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
@@ -1987,7 +2054,7 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         const double sigma_c = ip_->sigma_c, om = 1. - sigma_c, sigmu = sigma_c * double(ip_->mu);
         const SV xsz = padView(v.xs, scvx);
         forSegChunks<P, IPM_UPD_CHUNK>([&](auto i0, auto n) {
-            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
+            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, makeSegLds(c, v.k), v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
         });
     }
     g.sig += alpha * g.dsig;
@@ -2076,6 +2143,14 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
     c.S = a.S + size_t(inst) * (K - 1) * NX;
     c.Z = a.Z + size_t(inst) * (K - 1) * NX;
     c.ip = a.ip + size_t(inst) * IP_N;
+    // dynamic LDS (launchIpm: segLdsBytes<P>(K) [+ pad]): the LDS-resident segment fields
+#ifdef SCPP_HIP_EMU
+    static double seg_lds[NSEGLDS * 16 * 64];
+    c.segl = seg_lds;
+#else
+    extern __shared__ double seg_lds[];
+    c.segl = (LDSP double *)seg_lds;
+#endif
     const Settings opt = a.opt;
 
     // wave-uniform state in LDS: one copy per wavefront, handed to the out-of-line phases by LDS address
@@ -2140,6 +2215,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         phInitDualFinish<P>(cs, gp, itp);
     }
     phDataNorms<P>(cs, gp, itp);
+    phSegLdsCopy<P, true>(cs);
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
 
@@ -2252,6 +2328,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         PROF_ADD(7, tu0, tu1);
     }
 
+    phSegLdsCopy<P, false>(cs);
     iter_total += iter;
     if (status == 0 || !warm)
         break;

@@ -373,13 +373,13 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     // one instantiation of the solver per model table (csrc/constraint_table.h)
     const bool zoh = !(c->mode & SCPP_MODE_FOH); // zero-order hold: the table's ZeroOrderHold variant (same record layout)
     if (rq && !zoh)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
     else if (rq)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
     else if (!zoh)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::Rocket2dSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::Rocket2dSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::Rocket2dSC>(c->K), r.stream, a);
     else
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::Rocket2dSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::Rocket2dSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::Rocket2dSC>(c->K), r.stream, a);
     spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }

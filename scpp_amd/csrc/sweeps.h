@@ -31,14 +31,18 @@ namespace ipm
 #endif
 
 // the instance context lives in LDS (one copy per wavefront); out-of-line phases / sweeps re-materialise it in SGPRs
+__device__ inline LDSP double *uniformLds(LDSP double *p)
+{
 #ifdef SCPP_HIP_EMU
-#define LDSP
+    return p;
 #else
-#define LDSP __attribute__((address_space(3)))
+    return (LDSP double *)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p);
 #endif
+}
 __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
 {
     Ctx c;
+    c.segl = uniformLds(cin->segl);
     c.K = uniformInt(cin->K);
     c.lane = threadIdx.x;
     c.pitch = uniformInt(cin->pitch);

@@ -75,11 +75,19 @@ __device__ inline void storeTile(double *p, int lane, const Tile &t)
 
 // ---- packed factor storage ----
 __device__ inline int triIdx(int row, int col) { return (row * (row + 1)) / 2 + col; }
+#ifndef INVCHOL_BPERMUTE
+#define INVCHOL_BPERMUTE 1
+#endif
+#ifndef INVCHOL_PERMLANE
+#define INVCHOL_PERMLANE 0
+#endif
 struct TileShared
 {
-    double colA[2][16];
-    double rowR[2][16];
+#if !INVCHOL_BPERMUTE && !INVCHOL_PERMLANE
+    double colA[2][16]; // pivot column / row exchange of the LDS variant of the eliminations only (640 B the LDS-resident
+    double rowR[2][16]; // segment fields need: 8 wavefronts x 20 KB fill the CU's 160 KB exactly)
     double pv[16];
+#endif
     double tr[16 * 17]; // transpose scratch
 #ifdef IPM_PROFILE
     double prof[6]; // factor sweep: cycles in the two eliminations, whole sweep, calls, stage head, between the eliminations
