@@ -110,7 +110,9 @@ extern "C"
         double nu_tol, delta_tol;
     } scpp_sc_opts;
 
-    /* SCvx.info (SCvxAlgorithm.cpp:22-44) */
+    /* SCvx.info (SCvxAlgorithm.cpp:22-44).  interpolate_input: 1 = first-order hold (shipped), 0 = zero-order hold (round 4:
+       buildSCvxProblem without C and with K-1 input trust regions, SCvxProblem.cpp:32-35,58-68; u1 = u0 in getNonlinearCost,
+       SCvxAlgorithm.cpp:269; results keep the [K][nu] pitch with row K-1 zero) */
     typedef struct
     {
         int K;

@@ -997,7 +997,9 @@ namespace
 // what SCvx set-up does for every model: buffers, options, the SC-style options the shared set-up kernels read
 int scvxSetupCommon(scpp_hip_ctx *c, const scpp_scvx_opts *so, const double *x_init, int B, int warm_start)
 {
-    if (so->K != c->K || !so->interpolate_input)
+    /* first-order hold (shipped) or zero-order hold (SCvxProblem.cpp:32-35: no C in the dynamics; :58-68: the trust-region loop runs
+       over the K-1 inputs; SCvxAlgorithm.cpp:269: u1 = u0 in the nonlinear cost) */
+    if (so->K != c->K)
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->scvx_ready || B != c->B))
         return SCPP_E_STATE;
@@ -1035,9 +1037,11 @@ int scvxSetupCommon(scpp_hip_ctx *c, const scpp_scvx_opts *so, const double *x_i
     sc.nu_tol = 0.;
     sc.delta_tol = 0.;
     c->sc = sc;
-    c->mode = SCPP_MODE_FOH;
+    c->mode = so->interpolate_input ? SCPP_MODE_FOH : 0; // fixed final time either way (SCvxAlgorithm.cpp:52: dd.initialize(K, interpolate_input, false))
     CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * size_t(c->nx) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
+    if (!so->interpolate_input) // zero-order hold: no C in the dynamics (discretizationData.hpp:56-59); the discretisation does not write it
+        CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * size_t(c->nu) * sizeof(double), c->stream));
     if (!warm_start)
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
     return SCPP_OK;
@@ -1108,7 +1112,7 @@ SCvxBuffers scvxBuffersRange(scpp_hip_ctx *c, Range r)
 // accept-reject kernel (which rolls a rejected candidate back).
 int scvxRound(scpp_hip_ctx *c, Range r)
 {
-    int rc = discretizeDispatch(c, SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, r.count, r);
+    int rc = discretizeDispatch(c, c->mode & SCPP_MODE_FOH, c->ip + ipm::IP_PAR, ipm::IP_N, c->vx_needs_disc, r.count, r);
     if (rc)
         return rc;
     rc = launchIpm(c, 0, r.count, true, r, 0, true);

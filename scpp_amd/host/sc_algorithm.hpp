@@ -95,8 +95,8 @@ public:
         check(scpp_hip_create(&ctx, device, Model::model_id, opts.K, batch_max, 0), "scpp_hip_create");
         td.initialize(size_t(opts.K), opts.interpolate_input != 0);
     }
-    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154), 0 = the
-    // engine's rule (default; include/scpp_hip.h).  Call after initialize().
+    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154; the default), 0 = the
+    // engine's opt-in step-length rule (include/scpp_hip.h).  Call after initialize().
     void setDiscretizationSteps(int steps)
     {
         if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
@@ -277,8 +277,8 @@ public:
         if (rc != SCPP_OK)
             throw std::runtime_error("scpp_hip_create failed with code " + std::to_string(rc));
     }
-    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154), 0 = the
-    // engine's rule (default; include/scpp_hip.h).  Call after initialize().
+    // RKF78 steps per shooting segment: 5 = the reference's fixed count (discretizationImplementation.hpp:141,154; the default), 0 = the
+    // engine's opt-in step-length rule (include/scpp_hip.h).  Call after initialize().
     void setDiscretizationSteps(int steps)
     {
         if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
@@ -331,14 +331,13 @@ public:
         for (size_t b = 0; b < nB; b++)
         {
             trajectory_data_t &t = out.td[b];
-            t.initialize(K, true);
+            t.initialize(K, opts.interpolate_input != 0); // zero-order hold: K - 1 inputs (trajectoryData.hpp:27-32); the device's slot K-1 is unused
             for (size_t k = 0; k < K; k++)
-            {
                 for (size_t j = 0; j < NX; j++)
                     t.X[k][j] = X[(b * K + k) * NX + j];
+            for (size_t k = 0; k < t.U.size(); k++)
                 for (size_t j = 0; j < NU; j++)
                     t.U[k][j] = U[(b * K + k) * NU + j];
-            }
             t.t = sigma[b];
         }
     }

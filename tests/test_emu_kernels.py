@@ -533,3 +533,72 @@ def _rocket2d_stream_multi_pool_case(lib, tmp_path, K, N, configs, maxit=None):
 
 def test_emu_rocket2d_stream_multi_pool_equals_batch(emu_lib, tmp_path):
     _rocket2d_stream_multi_pool_case(emu_lib, tmp_path, 8, 6, ((4, 2), (5, 3), (3, 3)))
+
+
+def _scvx_zoh_case(oracle, lib, tmp_path, KQ, K2, maxit=None):
+    """SCvx with ZERO-ORDER-HOLD inputs (VERDICT r3 missing #1): `interpolate_input false` in SCvx.info -- buildSCvxProblem drops C
+    (SCvxProblem.cpp:32-35), the trust-region loop runs over the K-1 inputs (:58-68), getNonlinearCost propagates with u1 = u0
+    (SCvxAlgorithm.cpp:269).  Both models, batch and streaming entry points, against the oracle's LITERAL formulation: the device run and the
+    literal run of the same file both converge (their decision sequences need not coincide), the input slot of node
+    K-1 stays zero, and EVERY accepted sub-problem of the nominal device path is feasible and eps-optimal in the literal sub-problem
+    linearised at the device's own iterate (tests/scvx_audit.py)."""
+    import os
+    import shutil
+
+    import scvx_audit
+
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    for mdl in ("RocketQuat", "Rocket2D"):
+        p = cfg / mdl / "SCvx.info"
+        t = p.read_text()
+        assert "interpolate_input                   true" in t
+        t = t.replace("interpolate_input                   true", "interpolate_input                   false")
+        p.write_text(t.replace("nondimensionalize                   false", "nondimensionalize                   true"))
+    res = {}
+    for name, mk, K, oid in (("RocketQuat", scpp_amd.RocketQuat, KQ, oracle.ROCKETQUAT), ("Rocket2D", scpp_amd.Rocket2D, K2, oracle.ROCKET2D)):
+        m = mk(str(cfg)).loadParameters()
+        alg = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=3, library=lib, max_iterations=maxit).initialize()
+        assert alg.opts.interpolate_input == 0
+        x0 = np.tile(m.x_init, (3, 1))
+        x0[1:] = m.randomized_initial_states(2, first=1)
+        n = alg.solve(x0)
+        o = alg.getSolution()
+        assert (o["status"] == 0).all() and n == int(o["converged"].sum())
+        assert (o["U"][:, K - 1, :] == 0.).all()  # K-1 inputs: the slot of node K-1 is unused
+        # the streaming engine computes the same rows
+        ns = alg.solveStream(x0, slots=2, pools=2)
+        so = alg.getStreamSolution()
+        assert ns == n
+        for key in ("X", "U", "sigma", "nu_norm", "trust_region", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+            assert np.array_equal(so[key], o[key]), (name, key)
+        # the literal (reference-shaped) run of the same file
+        s = oracle.SCvx(K=K, model=oid, config_root=str(cfg)); s.set_solver(0)
+        if maxit:
+            s.set_max_iterations(maxit)
+        lit_rc = s.solve()  # (the literal sparse-KKT solver fails on ~5 % of all sub-problems, DESIGN.md section 5: a whole literal run
+        mm = s.meta()       #  is informative, the parity statement is the audit of the device's own sub-problems below)
+        assert mm["nU"] == K - 1
+        if maxit is None:
+            assert o["converged"][0] == 1
+            assert lit_rc != 0 or mm["converged"] == 1
+        # literal audit of every accepted sub-problem of the nominal device path
+        path = scvx_audit.device_path(alg, x0[:1], int(alg.opts.max_iterations))
+        for st in path:
+            st["U"] = st["U"][:, : K - 1, :]  # the oracle's trajectories hold K-1 inputs
+        h = oracle.SCvx(K=K, model=oid, config_root=str(cfg)); h.set_tolerances(1e-9, 1e-9, 1e-9, 200)
+        rows = scvx_audit.audit_rows(h, path, 0, alg.opts.alpha)
+        solved = [r for r in rows if r["lit_exitflag"] in (0, 10)]
+        assert len(rows) == int(o["sc_iters"][0]) and len(solved) >= len(rows) - 1
+        assert max(r["eq_violation"] for r in rows) <= 1e-9
+        assert min(r["min_lp_slack"] for r in rows) >= -1e-9 and min(r["min_cone_slack"] for r in rows) >= -1e-9
+        gaps = np.array([(r["cost"] - r["lit_cost"]) / max(abs(r["lit_cost"]), 1e-12) for r in solved])
+        assert np.abs(gaps).max() <= 5e-5 and gaps.min() >= -1e-6
+        res[name] = dict(n=len(rows), iters=int(o["sc_iters"][0]), lit_iters=int(mm["iterations"]) if lit_rc == 0 else -1, gap_max=float(np.abs(gaps).max()),
+                         relX_max=max(r["relX"] for r in solved), relU_max=max(r["relU"] for r in solved))
+        alg.ctx.close()
+    return res
+
+
+def test_emu_scvx_zero_order_hold(oracle, emu_lib, tmp_path):
+    _scvx_zoh_case(oracle, emu_lib, tmp_path, 8, 8, maxit=6)
