@@ -1,0 +1,140 @@
+"""Independent pin of the RocketQuat sub-problems ABOVE K = 5: the first SC and SCvx sub-problem of the shipped
+scenario at K = 15 (the reference's shipped SC.info) and K = 50 (BASELINE), solved WITHOUT any interior-point code of this repository.
+
+scipy's trust-constr, which pins K = 5 (generate_subproblem_goldens.py), does not solve K = 15.  Tried first, as
+VERDICT r3 suggested: an ADMM on the literal conic standard form (OSQP / COSMO splitting, Ruiz equilibration, residual balancing) --
+after 400 000 iterations at K = 5 its objective was still 7 % from the known optimum (w_vc = 1000 against slacks of 1e-5: the splitting
+crawls on this LP-like problem), so it cannot deliver 1e-6.  What does: KELLEY'S CUTTING PLANES over an LP solver.  Every second-order
+cone t >= ||w|| of the sub-problem is the intersection of its supporting half-spaces t >= n'w (||n|| = 1); starting from the box
+|w_i| <= t, the LP relaxation is solved by HiGHS (scipy.optimize.linprog: dual simplex, a third-party solver that shares nothing with
+oracle/, scpp_amd or the HIP library), the half-space at n = w/||w|| is added for every violated cone, and the LP is solved again
+until no cone is violated by more than 1e-10.  The LP optimum is then a LOWER bound of the conic optimum attained at a point that is
+feasible to 1e-10: the objective is pinned to about 1e-8 relative.  The problem DATA come from the restatement
+generate_subproblem_goldens.py already holds (scenario constants of model.info:109-213, nondimensionalisation, initial guess, DOP853
+forward sensitivities, SCProblem.cpp:6-138 / SCvxProblem.cpp:6-71 + rocketQuat.cpp:70-144 as lists of linear rows and cones).
+
+Run: python tests/golden/generate_subproblem_cut_goldens.py   (K = 15 and 50; minutes) -> rocketquat_subproblem_cuts.npz
+     python tests/golden/generate_subproblem_cut_goldens.py 5 (validation against the trust-constr optimum of K = 5)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.optimize import linprog
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import generate_subproblem_goldens as G  # problem DATA only (scenario, initial guess, discretisation, rows / cones)
+
+
+def linear_parts(pb):
+    """equalities Ae v = be (exact columns of the linear map), linear rows Gl v <= hl, cones as (t_row, [w_rows]) with rows (const, coefs)"""
+    n = pb.n
+    e0 = pb.eq(np.zeros(n))
+    rows, cols, vals = [], [], []
+    for j in range(n):
+        e = np.zeros(n); e[j] = 1.0
+        col = pb.eq(e) - e0
+        nz = np.nonzero(col)[0]
+        rows += list(nz); cols += [j] * len(nz); vals += list(col[nz])
+    Ae = sp.csr_matrix((vals, (rows, cols)), shape=(e0.size, n))
+    lin, soc = pb._forms()
+    r_, c_, v_, h = [], [], [], []
+    for r, (c0, terms) in enumerate(lin):  # c0 + sum coef v >= 0  <=>  -sum coef v <= c0
+        for i, cf in terms:
+            r_.append(r); c_.append(i); v_.append(-cf)
+        h.append(c0)
+    Gl = sp.csr_matrix((v_, (r_, c_)), shape=(len(lin), n))
+
+    def dense(form):
+        c0, terms = form
+        a = np.zeros(n)
+        for i, cf in terms:
+            a[i] += cf
+        return c0, a
+
+    cones = []
+    socs = list(soc)
+    if pb.mode == "sc":  # (sigma - sigma0)^2 <= delta_sigma  as  (1 + d)/2 >= ||((1 - d)/2, sigma - sigma0)||   (SCProblem.cpp:91-96)
+        idx, f = pb._dsg_row
+        socs.append(((0.5, [(idx, 0.5)]), [(0.5, [(idx, -0.5)]), f]))
+    for t, ws in socs:
+        t0, ta = dense(t)
+        W = [dense(w) for w in ws]
+        cones.append((t0, ta, np.array([w[0] for w in W]), np.array([w[1] for w in W])))
+    return Ae, -e0, Gl, np.array(h), cones
+
+
+def solve_cuts(pb, tol=1e-10, max_rounds=400, verbose=True):
+    n = pb.n
+    q = pb.cost_grad(np.zeros(n))
+    Ae, be, Gl, hl, cones = linear_parts(pb)
+    cut_rows, cut_rhs = [], []
+    # t >= n'w  <=>  (n'Wa - ta) v <= t0 - n'w0
+    for t0, ta, w0, Wa in cones:  # initial outer box |w_i| <= t
+        for i in range(len(w0)):
+            for sgn in (1.0, -1.0):
+                cut_rows.append(sgn * Wa[i] - ta); cut_rhs.append(t0 - sgn * w0[i])
+    t_start = time.time()
+    x = None
+    for rnd in range(1, max_rounds + 1):
+        A_ub = sp.vstack([Gl, sp.csr_matrix(np.array(cut_rows))]).tocsr()
+        b_ub = np.concatenate([hl, np.array(cut_rhs)])
+        res = linprog(q, A_ub=A_ub, b_ub=b_ub, A_eq=Ae, b_eq=be, bounds=[(None, None)] * n, method="highs-ds",
+                      options=dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10, presolve=True))
+        assert res.status == 0, res.message
+        x = res.x
+        worst, added = 0.0, 0
+        for t0, ta, w0, Wa in cones:
+            t = t0 + ta @ x
+            w = w0 + Wa @ x
+            nw = np.linalg.norm(w)
+            viol = nw - t
+            worst = max(worst, viol)
+            if viol > tol and nw > 0:
+                nrm = w / nw
+                cut_rows.append(nrm @ Wa - ta); cut_rhs.append(t0 - nrm @ w0); added += 1
+        if verbose:
+            print("   round %3d  LP objective %.12f  worst cone violation %.2e  cuts %d (+%d)  %.0f s" % (rnd, res.fun, worst, len(cut_rows), added, time.time() - t_start), flush=True)
+        if added == 0:
+            break
+    eqv = float(np.abs(Ae @ x - be).max())
+    linv = float(max(0.0, (Gl @ x - hl).max()))
+    return x, dict(objective=float(q @ x), rounds=rnd, cuts=len(cut_rows), cone_violation=float(worst), eq_violation=eqv, lin_violation=linv,
+                   seconds=time.time() - t_start)
+
+
+def solve_mode(Kn, mode):
+    G.K = Kn
+    sc = G.scenario()
+    Xb, Ub, sb = G.initial_trajectory(sc)
+    dd = G.discretize(sc, Xb, Ub, sb, mode == "sc")
+    w = dict(t=1.0, trt=1.0, trx=50.0, vc=1000.0) if mode == "sc" else dict(vc=1000.0, tr=5.0)
+    pb = G.SubProblem(sc, Xb, Ub, sb, dd, mode, w)
+    print(" K=%d %s: %d variables" % (Kn, mode, pb.n), flush=True)
+    x, info = solve_cuts(pb)
+    X, U, P, M, Dl, sig, dsg = pb.split(x)
+    print(" K=%d %s: objective %.12f  ||nu||_1 %.12f  %s" % (Kn, mode, info["objective"], float((P + M).sum()), info), flush=True)
+    out = {"X": X.copy(), "U": U.copy(), "objective": info["objective"], "norm1_nu": float((P + M).sum()), "sigma": float(sig),
+           "rounds": info["rounds"], "violations": np.array([info["cone_violation"], info["eq_violation"], info["lin_violation"]])}
+    if mode == "sc":
+        out["sum_delta"] = float(Dl.sum()); out["delta_sigma"] = float(dsg)
+    return out
+
+
+def main():
+    ks = [int(a) for a in sys.argv[1:]] or [15, 50]
+    out = {}
+    for Kn in ks:
+        for mode in ("scvx", "sc"):
+            for k, v in solve_mode(Kn, mode).items():
+                out["K%d_%s_%s" % (Kn, mode, k)] = v
+    name = "rocketquat_subproblem_cuts.npz" if ks == [15, 50] else "rocketquat_subproblem_cuts_K%s.npz" % "_".join(map(str, ks))
+    np.savez(os.path.join(HERE, name), **out)
+    print("written", name)
+
+
+if __name__ == "__main__":
+    main()

@@ -94,3 +94,70 @@ def test_device_path_against_scipy_optimum_emulated(gold, emu_lib):
 @pytest.mark.gpu
 def test_device_path_against_scipy_optimum_on_gpu(gold, hip_lib):
     _device(gold, hip_lib)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Above K = 5.  trust-constr does not solve K = 15; tests/golden/rocketquat_subproblem_cuts.npz holds the optimal
+# OBJECTIVE of the first SC and SCvx sub-problem at K = 15 (the reference's shipped SC.info) and K = 50 (BASELINE) from Kelley's cutting
+# planes over HiGHS' dual simplex (generate_subproblem_cut_goldens.py: no interior point, no code of oracle/, scpp_amd or the HIP library;
+# cones satisfied to 1e-10, i.e. the objective is good to ~1e-8).  Both oracle solvers and the device path must reproduce it to 2e-6.
+# (Only the objective is compared: an LP vertex of the outer approximation need not be the analytic-centre-like point an interior-point
+# method returns where the optimum is not unique.)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cuts():
+    g = np.load(os.path.join(GOLDEN, "rocketquat_subproblem_cuts.npz"))
+    for Kn in (15, 50):
+        for mode in ("sc", "scvx"):
+            assert g["K%d_%s_violations" % (Kn, mode)].max() <= 1e-9
+    return g
+
+
+def _sc_objective(sigma, sigma_bar, norm1_nu, sum_delta):
+    return W_T * sigma + W_VC * norm1_nu + W_TRT * (sigma - sigma_bar) ** 2 + W_TRX * sum_delta
+
+
+@pytest.mark.parametrize("Kn,kind", [(15, 0), (15, 1), (50, 0), (50, 1)])
+def test_oracle_solvers_against_the_cutting_plane_optimum(oracle, cuts, Kn, kind):
+    s = oracle.SC(oracle.ROCKETQUAT, K=Kn); s.set_solver(kind); s.set_tolerances(1e-10, 1e-10, 1e-10, 200); s.solve()  # (whole run; iteration 1 is compared)
+    _, _, t0 = s.iterate(0)
+    _, _, t1 = s.iterate(1)
+    inf = s.info()[0]
+    obj = _sc_objective(t1, t0, inf[0], inf[1])
+    ref = float(cuts["K%d_sc_objective" % Kn])
+    assert abs(obj - ref) <= 2e-6 * ref, ("SC", Kn, kind, obj, ref)
+    v = oracle.SCvx(K=Kn); v.set_solver(kind); v.set_tolerances(1e-10, 1e-10, 1e-10, 200); v.set_max_iterations(1); v.solve()
+    objv, refv = W_VC * v.info()[0][0], float(cuts["K%d_scvx_objective" % Kn])
+    assert abs(objv - refv) <= 2e-6 * refv, ("SCvx", Kn, kind, objv, refv)
+
+
+def _device_cuts(cuts, lib, Kn):
+    m = scpp_amd.RocketQuat().loadParameters()
+    alg = scpp_amd.SCAlgorithm(m, K=Kn, batch_max=1, library=lib).initialize()
+    alg.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+    alg.ctx.sc_setup(m.p, alg.opts, m.x_init[None])
+    sigma_bar = float(m.p.final_time)
+    alg.ctx.sc_iterate()
+    o = alg.ctx.download()
+    obj, ref = _sc_objective(float(o["sigma"][0]), sigma_bar, float(o["nu_norm"][0]), float(o["sum_delta"][0])), float(cuts["K%d_sc_objective" % Kn])
+    assert o["status"][0] == 0 and abs(obj - ref) <= 2e-6 * ref, ("device SC", Kn, obj, ref)
+    alg.ctx.close()
+    v = scpp_amd.SCvxAlgorithm(m, K=Kn, batch_max=1, library=lib, max_iterations=1).initialize()
+    v.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+    v.solve(m.x_init[None])
+    ov = v.getSolution()
+    objv, refv = W_VC * float(ov["nu_norm"][0]), float(cuts["K%d_scvx_objective" % Kn])
+    assert ov["status"][0] == 0 and abs(objv - refv) <= 2e-6 * refv, ("device SCvx", Kn, objv, refv)
+    v.ctx.close()
+    return abs(obj - ref) / ref, abs(objv - refv) / refv
+
+
+def test_device_path_against_the_cutting_plane_optimum_emulated(cuts, emu_lib):
+    _device_cuts(cuts, emu_lib, 15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Kn", [15, 50])
+def test_device_path_against_the_cutting_plane_optimum_on_gpu(cuts, hip_lib, Kn):
+    r = _device_cuts(cuts, hip_lib, Kn)
+    print("K = %d first sub-problems vs the cutting-plane optimum (HiGHS): relative objective difference SC %.1e, SCvx %.1e" % ((Kn,) + r))
