@@ -158,6 +158,30 @@ def measured_traffic():
     return best
 
 
+def parity_summary():
+    """Counts of the at-scale parity test of the headline mode (tests/test_gpu_parity.py::test_scvx_at_scale_parity_and_literal_audit writes
+    gpurun_out/r04_parity_at_scale.json; the committed copy under profiles/ is what is reported here, with the kernel-source hash it was
+    taken on): identical records, instances beyond 1e-5 in states / inputs, certified instances."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_at_scale*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception as e:
+        return {"error": str(e)}
+    keep = ("instances", "identical_records", "non_identical_records", "non_identical_explained_by_a_tie", "largest_tie_margin",
+            "instances_beyond_1e5_states", "instances_beyond_1e5_inputs", "flagged", "certified", "rel_dX", "rel_dU", "bars", "csrc_sha")
+    out = {k: d[k] for k in keep if k in d}
+    out["imported_from"] = os.path.relpath(files[-1], ROOT)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import csrc_hash
+        out["stale"] = d.get("csrc_sha") != csrc_hash.csrc_sha()
+    except Exception:
+        out["stale"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -494,6 +518,7 @@ def main():
                 "median_final_virtual_control_norm1": float(np.median(out["nu_norm"])),
                 "median_final_nonlinear_defect": float(np.median(out["nonlinear_cost"])),
                 "rounds": rounds,
+                "parity": parity_summary(),
                 **extras,
             },
             "roofline": {

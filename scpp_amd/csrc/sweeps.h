@@ -495,7 +495,7 @@ template <class P>
 struct FactorOffs
 {
     OffMt<P> mt;
-    Off4 n, rl, rw, cols, triV, triL, yt;
+    Off4 n, rl, rw, cols, triV, triL, triVT, triLT, yt;
     int einv;
 };
 
@@ -521,6 +521,8 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     o.cols = offCols(lane, sp.n, 0);
     o.triV = offTri<NV>(lane, L::FAC_LI);
     o.triL = offTri<NL>(lane, L::FAC_TI);
+    o.triVT = offTriT<NV>(lane, L::FAC_LI);
+    o.triLT = offTriT<NL>(lane, L::FAC_TI);
     o.yt = offYt<NL>(lane, L::FAC_YT);
     o.einv = i < NL ? (L::X_EINV + i) * 8 : VO_OOB;
 #ifdef IPM_PROFILE
@@ -562,6 +564,14 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const long long tf0 = clock64();
         pfA += double(tf0 - tstage); // stage head: loads issued, H tile, Z'Z
 #endif
+#if INVCHOL_TRANSPOSED
+        const Tile Lit = invCholFactorT<NV>(Phi, lane);
+#ifdef IPM_PROFILE
+        const long long tf1 = clock64();
+        pf0 += double(tf1 - tf0);
+#endif
+        stTile(io.fac, o.triVT, io.sFac(k), Lit); // (same record: the transposed offsets store L[b][a] = Lit[a][b])
+#else
         const Tile Li = INVCHOL<NV>(Phi, sh, lane);
 #ifdef IPM_PROFILE
         const long long tf1 = clock64();
@@ -569,6 +579,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
 #endif
         stTile(io.fac, o.triV, io.sFac(k), Li);
         const Tile Lit = transposeTile(Li, sh, lane);
+#endif
         const Tile a = mm(Lit, G);
         stTile(io.sv, o.cols, io.sSv(k), a);
         if (k == K - 1)
@@ -588,6 +599,14 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const long long tf2 = clock64();
         pfC += double(tf2 - tf1); // between the eliminations: store Li, transpose, a, Yt, Theta
 #endif
+#if INVCHOL_TRANSPOSED
+        const Tile Tit = invCholFactorT<NL>(Th, lane);
+#ifdef IPM_PROFILE
+        tstage = clock64();
+        pf1 += double(tstage - tf2);
+#endif
+        stTile(io.fac, o.triLT, io.sFac(k), Tit);
+#else
         const Tile Ti = INVCHOL<NL>(Th, sh, lane);
 #ifdef IPM_PROFILE
         tstage = clock64();
@@ -595,6 +614,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
 #endif
         stTile(io.fac, o.triL, io.sFac(k), Ti);
         const Tile Tit = transposeTile(Ti, sh, lane);
+#endif
         Z = mm(Tit, finishN<P>(cn, fmn, lane));
         const Tile gl = tileSub(rhsLSign(sp, lane, crl), mm(Yt, a));
         const Tile cc = mm(Tit, gl);

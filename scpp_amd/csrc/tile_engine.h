@@ -245,6 +245,79 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
     return Li;
 }
 
+// The TRANSPOSED inverse factor Lit = (chol(A)^-1)' directly (round 4; selectable, NOT the default -- see INVCHOL_TRANSPOSED below).  The factor sweep needs Li only as the first operand of
+// X'Y products -- mm(Lit, .) = Li . -- so until round 3 every inverse factor went through a transpose in LDS (4 writes, 4 reads, two
+// waits) on the stage's dependent chain: two of them per stage = 1.0 k of the 7.6 k cycles of that chain.  Here the
+// elimination keeps R' instead of R: lane (g, i) holds Rt[c][i] = R[i][c], c = g + 4r, and step j is
+//      Rt[c][i] -= m_i Rt[c][j],   m_i = A[j][i] p  (i > j; the pivot-row entry the A update fetches anyway),   Rt[c][j] by DPP row broadcast,
+// i.e. the ds_bpermute pair that fetched R[j][i] is replaced by row broadcasts on the VALU data path as well: half the LDS-crossbar
+// traffic of an elimination, and no LDS transpose at all.  (m_i uses A[j][i] where the R update of invCholFactor uses A[i][j]: equal up
+// to rounding.)
+// Memory layout of the stored factor is unchanged: the caller stores Lit through the transposed offsets (sweeps.h: offTriT).
+template <int n>
+INVCHOL_LINKAGE Tile invCholFactorT(Tile A, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile Rt;
+    double od = 0.;  // original diagonal entry of MY column (for the pivot floor)
+    double pvc = 1.; // pivot of row i (my column of Lit)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        Rt.v[r] = (g + 4 * r == i) ? 1. : 0.;
+        od = (g + 4 * r == i) ? A.v[r] : od;
+    }
+    od *= 1e-14;
+    sfor<n>([&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        constexpr int rj_ = j >> 2;
+        double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
+        const double floor_ = readLane(od, (j & 3) * 16 + j);
+        // lane (j & 3, i) holds A[j][i] in register j >> 2: every lane of column i fetches it from there (not masked, see invCholFactor)
+        const double aj = __shfl(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + i);
+        double cr[4], rc[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            cr[r] = rc[r] = 0.;
+            if (4 * r + 3 > j) // column j below the pivot, for this lane's rows
+                cr[r] = rowBcast<j>((g + 4 * r > j) ? A.v[r] : 0.);
+            if (4 * r <= j) // R[j][c] for this lane's c = g + 4r (0 for c > j, 1 for c = j: by construction)
+                rc[r] = rowBcast<j>(Rt.v[r]);
+        }
+        d = fmax(d, floor_);
+        const double p = fastRcp(d);
+        const double mi = (i > j) ? aj * p : 0.; // multiplier of row i
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            if (4 * r + 3 > j)
+                A.v[r] -= (cr[r] * p) * aj;
+            if (4 * r <= j)
+                Rt.v[r] -= mi * rc[r];
+        }
+        pvc = (i == j) ? d : pvc;
+    });
+    const double sc = fastRsqrt(pvc);
+    Tile Lit;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int c = g + 4 * r;
+        if (i < n)
+            Lit.v[r] = (c <= i) ? Rt.v[r] * sc : 0.;
+        else
+            Lit.v[r] = (c == i) ? 1. : 0.;
+    }
+    return Lit;
+}
+#ifndef INVCHOL_TRANSPOSED
+#define INVCHOL_TRANSPOSED 0 // 1: the factor sweep takes Lit / Tit straight from invCholFactorT (no LDS transpose, half the ds_bpermute).  MEASURED, NOT KEPT
+                              // (round 4, same box, three alternating runs): 4551 / 4563 / 4564 against 4585 / 4619 / 4606 converged/s (-1 %).  With two
+                              // wavefronts per SIMD an elimination step is ISSUE-bound (42 instructions x 4 cycles x 2 waves = the 340 cycles measured):
+                              // the eight extra DPP moves per step cost more issue slots than the two LDS transposes per stage cost latency
+#endif
+
 #define INVCHOL invCholFactor
 
 } // namespace ipm

@@ -826,6 +826,13 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
                   cert_gap=BAR_CERT_GAP, flagged_fraction=BAR_FLAGGED_FRACTION),
     )
     try:
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import csrc_hash
+        summary["csrc_sha"] = csrc_hash.csrc_sha()  # identity of the kernel sources the counts belong to (bench.py: stale check)
+    except Exception:
+        pass
+    try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "r04_parity_at_scale.json"), "w"), indent=1)
     except OSError:
