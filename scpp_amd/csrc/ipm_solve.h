@@ -2203,14 +2203,14 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         {
             const RhsSpec sp = specBorderPlus();
             factorSweepFused<P>(cs, sh, sp);
-            bwdSweep<P>(cs, sp);
+            bwdSweepAny<P>(cs, sp);
         }
         phInitPrimalFinish<P>(cs, gp, itp);
         phInitDualRhs<P>(cs, gp, itp);
         {
             const RhsSpec sp = specSingle();
-            fwdSweep<P>(cs, sp);
-            bwdSweep<P>(cs, sp);
+            fwdSweepAny<P>(cs, sp);
+            bwdSweepAny<P>(cs, sp);
         }
         phInitDualFinish<P>(cs, gp, itp);
     }
@@ -2286,17 +2286,17 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
                 factorSweepFused<P>(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
-                bwdSweep<P>(cs, sp);
+                bwdSweepAny<P>(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }
             else
             {
                 const RhsSpec sp = specSingle();
-                fwdSweep<P>(cs, sp);
+                fwdSweepAny<P>(cs, sp);
                 PROF_T(tf1);
                 PROF_ADD(10, tq1, tf1);
-                bwdSweep<P>(cs, sp);
+                bwdSweepAny<P>(cs, sp);
                 PROF_T(tf2);
                 PROF_ADD(9, tf1, tf2);
             }

@@ -833,5 +833,165 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
     WAVE_SYNC();
 }
 
+// =====================================================================================================================
+// Single-column substitution sweeps on the matrix-VECTOR engine (tile_engine.h: mv; round 4).
+// fwdSweep / bwdSweep above carry up to two right-hand-side columns through X'Y products of 16 x 16 tiles: four 16-pass matrix-core
+// instructions per product whatever the number of columns.  Every sweep of the SCvx mode (no sigma border, specSingle) and the corrector
+// sweeps of the SC mode have ONE column: here the same recursion runs on vectors in V layout and tiles loaded in A4 layout, four
+// 4-pass v_mfma_f64_4x4x4_4b_f64 + four DPP row broadcasts per product, and a right-hand side is one register instead of a tile.
+// Same operands, same records; the contraction is grouped in blocks of four consecutive indices instead of four strided ones, so
+// results differ from the tile sweeps in the last bits only (the factor sweep keeps the tile engine: its products are matrix x matrix).
+// =====================================================================================================================
+// mv(X, v) = X' v for a tile X in the D layout of the 16-wide instruction: "A4 layout of T" (tile_engine.h) IS the D layout of T', so the
+// vector sweeps load exactly the tiles -- same offsets, same coalescing, same finish* masks -- the tile sweeps above load, and replace
+// mm(X, right-hand-side tile) by mv(X, right-hand-side vector).
+struct FwdVIn
+{
+    Tile lit, yt, tit, ti, n;
+    double rl, rwn;
+};
+template <class P>
+SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
+{
+    using L = Lay<P>;
+    constexpr int NL = L::NL;
+    const Ctx c = uniformCtx(cin);
+    const int lane = c.lane, K = c.K;
+    const SweepIO<P> io(c);
+    const int e = vElem(lane);
+    const Off4 oLit = offTriT<NV>(lane, L::FAC_LI), oYt = offYt<NL>(lane, L::FAC_YT), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
+               oN = offN<P>(lane);
+    const int oRw = (L::X_BETA + e) * 8, oRl = e < NL ? (L::X_RHO + e) * 8 : VO_OOB;
+    const int oColS = (lane & 3) == 0 ? e * 8 : VO_OOB; // every element lives in four lanes: one of them stores
+    auto load = [&](int k) {
+        const int ks = k < K - 1 ? k : K - 2; // the last stage has no segment: it re-reads segment K-2 (in range, unused)
+        FwdVIn f;
+        f.lit = ldTile(io.fac, oLit, io.sFac(k));
+        f.yt = ldTile(io.fac, oYt, io.sFac(ks));
+        f.tit = ldTile(io.fac, oTit, io.sFac(ks));
+        f.ti = ldTile(io.fac, oTi, io.sFac(ks));
+        f.n = ldTile(io.C, oN, io.sBC(ks));
+        f.rl = io.sx.ld(oRl, io.sX(ks));
+        f.rwn = io.sx.ld(oRw, io.sX(ks + 1));
+        return f;
+    };
+    double G = io.sx.ld(oRw, io.sX(0));
+    auto stage = [&](int k, const FwdVIn &cur) -> bool {
+        const double a = mv(cur.lit, G); // Li g
+        io.sv.st(oColS, io.sSv(k), a);
+        if (k == K - 1)
+            return false;
+        const double gl = cur.rl - mv(cur.yt, a); // rho - Yt' a
+        const double cc = mv(cur.tit, gl);        // Ti gl
+        io.sv.st(oColS, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
+        G = cur.rwn + mv(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mv(cur.ti, cc)); // beta' + N' (Ti' c)
+        return true;
+    };
+    auto clampK = [&](int k) { return k < K ? k : K - 1; };
+    FwdVIn b0 = load(0), b1 = load(clampK(1)), b2;
+    for (int k = 0; k < K; k += 3)
+    {
+        b2 = load(clampK(k + 2));
+        LOADS_ISSUED();
+        if (!stage(k, b0))
+            break;
+        b0 = load(clampK(k + 3));
+        LOADS_ISSUED();
+        if (!stage(k + 1, b1))
+            break;
+        b1 = load(clampK(k + 4));
+        LOADS_ISSUED();
+        if (!stage(k + 2, b2))
+            break;
+    }
+    WAVE_SYNC();
+}
+
+struct BwdVIn
+{
+    Tile li, nt, tit, ti, y;
+    double as, cs;
+};
+template <class P>
+SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
+{
+    using L = Lay<P>;
+    constexpr int NL = L::NL;
+    const Ctx c = uniformCtx(cin);
+    const int lane = c.lane, K = c.K;
+    const SweepIO<P> io(c);
+    const int e = vElem(lane);
+    const Off4 oLi = offTri<NV>(lane, L::FAC_LI), oNt = offNt<P>(lane), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
+               oY = offYtT<NL>(lane, L::FAC_YT);
+    const int oCol = e * 8;
+    const bool st0 = (lane & 3) == 0;
+    const int oSolW = st0 ? (L::X_VW + e) * 8 : VO_OOB, oSolL = (st0 && e < NL) ? (L::X_VL + e) * 8 : VO_OOB;
+    auto load = [&](int k) {
+        const int ks = k < K - 1 ? k : K - 2;
+        BwdVIn b;
+        b.li = ldTile(io.fac, oLi, io.sFac(k));
+        b.as = io.sv.ld(oCol, io.sSv(k));
+        b.nt = loadNtRaw<P>(io, oNt, ks);
+        b.tit = ldTile(io.fac, oTit, io.sFac(ks));
+        b.ti = ldTile(io.fac, oTi, io.sFac(ks));
+        b.y = ldTile(io.fac, oY, io.sFac(ks));
+        b.cs = io.sv.ld(oCol, io.sSv(ks) + NRHS_MAX * 16 * 8);
+        return b;
+    };
+    double x = 0.;
+    auto stage = [&](int k, const BwdVIn &cur) {
+        if (k == K - 1)
+            x = mv(cur.li, cur.as); // Li' a
+        else
+        {
+            const double t = mv(cur.tit, mv(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x)) - cur.cs; // Ti (N x') - c
+            const double lam = mv(cur.ti, t);                                                                  // Ti' t
+            const double s = cur.as - mv(cur.y, lam);                                                          // a - Yt lam
+            x = mv(cur.li, s);
+            io.sx.st(oSolL, io.sX(k), lam);
+        }
+        io.sx.st(oSolW, io.sX(k), x);
+    };
+    auto clampK = [&](int k) { return k > 0 ? k : 0; };
+    BwdVIn b0 = load(K - 1), b1 = load(clampK(K - 2)), b2;
+    for (int k = K - 1; k >= 0; k -= 3)
+    {
+        b2 = load(clampK(k - 2));
+        LOADS_ISSUED();
+        stage(k, b0);
+        if (k - 1 < 0)
+            break;
+        b0 = load(clampK(k - 3));
+        LOADS_ISSUED();
+        stage(k - 1, b1);
+        if (k - 2 < 0)
+            break;
+        b1 = load(clampK(k - 4));
+        LOADS_ISSUED();
+        stage(k - 2, b2);
+    }
+    WAVE_SYNC();
+}
+#ifndef SWEEPS_VECTOR
+#define SWEEPS_VECTOR 1 // single-column substitution sweeps on v_mfma_f64_4x4x4_4b_f64 (0: the 16-wide tile sweeps for every column count)
+#endif
+// the sweep for a right-hand-side specification
+template <class P>
+__device__ inline void fwdSweepAny(const LDSP Ctx *cin, const RhsSpec &sp)
+{
+    if (SWEEPS_VECTOR && sp.n == 1)
+        fwdSweepV<P>(cin);
+    else
+        fwdSweep<P>(cin, sp);
+}
+template <class P>
+__device__ inline void bwdSweepAny(const LDSP Ctx *cin, const RhsSpec &sp)
+{
+    if (SWEEPS_VECTOR && sp.n == 1)
+        bwdSweepV<P>(cin);
+    else
+        bwdSweep<P>(cin, sp);
+}
+
 } // namespace ipm
 } // namespace scpp

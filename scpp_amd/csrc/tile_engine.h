@@ -73,6 +73,34 @@ __device__ inline void storeTile(double *p, int lane, const Tile &t)
         p[(g + 4 * r) * 16 + i] = t.v[r];
 }
 
+// ---- matrix x VECTOR on the small-block FP64 matrix instruction (round 4) ----
+// The substitution sweeps of a single right-hand-side column multiply 16 x 16 tiles with ONE vector, five times per stage and in a
+// dependent chain.  As X'Y on v_mfma_f64_16x16x4_f64 that is four 16-pass instructions (64 cycles each, measured) per product for one
+// useful column of sixteen.  v_mfma_f64_4x4x4_4b_f64 computes four independent 4 x 4 x 4 blocks in 4 passes, and a 16 x 16 matrix-vector
+// product is exactly four such instructions: block b of instruction t multiplies T[4b .. 4b+3][4t .. 4t+3] with x[4t .. 4t+3], the
+// accumulator carries the sum over t.  Register layouts (measured on gfx950, tests/tools/mfma4x4_probe.hip: A lane = i + 4b + 16k,
+// B lane = j + 4b + 16k, D lane = j + 4b + 16i):
+//   V layout of a 16-vector:  lane l holds x[e(l)],  e(l) = 4 ((l >> 2) & 3) + (l >> 4)       (each element in four lanes, l & 3 free);
+//   A4 layout of a matrix T:  register t of lane l holds T[l & 15][4t + (l >> 4)] -- which IS the D layout (tile layout of the 16-wide
+//                             instruction: register r of lane (g, i) holds X[g + 4r][i]) of X = T', so  mv(X, x) = X' x  for every tile X;
+//   B operand of instruction t = x[4t + (l >> 4)] = the V-layout value of lane 4t of every row of 16 lanes: one DPP row broadcast.
+// The result is again in V layout, so products chain without any re-arrangement.
+#ifdef SCPP_HIP_EMU
+inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+#else
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+#endif
+__device__ inline int vElem(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+// y = X' x   (X: a D-layout tile, i.e. X' in A4 layout; x and y in V layout) -- the vector counterpart of mm(X, Y) = X'Y
+__device__ inline double mv(const Tile &T, double x)
+{
+    double acc = mfma4(T.v[0], rowBcast<0>(x), 0.);
+    acc = mfma4(T.v[1], rowBcast<4>(x), acc);
+    acc = mfma4(T.v[2], rowBcast<8>(x), acc);
+    acc = mfma4(T.v[3], rowBcast<12>(x), acc);
+    return acc;
+}
+
 // ---- packed factor storage ----
 __device__ inline int triIdx(int row, int col) { return (row * (row + 1)) / 2 + col; }
 #ifndef INVCHOL_BPERMUTE

@@ -257,6 +257,25 @@ inline d4_t __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, d4_t c, int
     return d;
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent blocks  D_b(4x4) = A_b(4x4) B_b(4x4) + C_b,  one double per lane and operand.
+//   lane l: block b = (l >> 2) & 3 ; A: A_b[i = l & 3][k = l >> 4] ; B: B_b[k = l >> 4][j = l & 3] ; C/D: D_b[i = l >> 4][j = l & 3]
+//   (the 16x16x4 layout with the 16-index split into block and 4-index; measured on gfx950: tests/tools/mfma4x4_probe.hip).
+//   cbsz / abid: the A block `abid` is broadcast to groups of 2^cbsz blocks (not used by the kernels: 0, 0).
+inline double __builtin_amdgcn_mfma_f64_4x4x4f64(double a, double b, double c, int, int, int)
+{
+    hipemu::State &s = hipemu::st();
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    s.xchg[t][0] = a;
+    s.xchg[t][1] = b;
+    __syncthreads();
+    const unsigned blk = (l >> 2) & 3u, j = l & 3u, i = l >> 4;
+    double acc = c;
+    for (unsigned k = 0; k < 4; k++)
+        acc += s.xchg[base + k * 16u + 4u * blk + i][0] * s.xchg[base + k * 16u + 4u * blk + j][1];
+    __syncthreads();
+    return acc;
+}
+
 // ---- buffer resources (raw, stride 0): base + voffset + soffset, out-of-range loads return 0, stores are dropped ----
 struct hipemu_rsrc
 {
