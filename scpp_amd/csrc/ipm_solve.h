@@ -2202,7 +2202,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         phInitPrimalRhs<P>(cs, gp, itp);
         {
             const RhsSpec sp = specBorderPlus();
-            factorSweepFused<P>(cs, sh, sp);
+            factorSweepAny<P>(cs, sh, sp);
             bwdSweepAny<P>(cs, sp);
         }
         phInitPrimalFinish<P>(cs, gp, itp);
@@ -2283,7 +2283,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
                 // column and of the affine right-hand side.  SCvx (fixed final time): S = 0, the border column is identically
                 // zero -- it is neither solved for nor stored; its readers see zeros through an out-of-range view (padView)
                 const RhsSpec sp = (c.ip[IP_SCVX] != 0.) ? specSingle() : specBorderPlus();
-                factorSweepFused<P>(cs, sh, sp);
+                factorSweepAny<P>(cs, sh, sp);
                 PROF_T(tf1);
                 PROF_ADD(3, tq1, tf1);
                 bwdSweepAny<P>(cs, sp);

@@ -499,7 +499,10 @@ struct FactorOffs
     int einv;
 };
 
-template <class P>
+// VEC: ONE right-hand-side column (SCvx mode: no sigma border) -- the forward substitution fused into the factorisation then runs on
+// vectors (tile_engine.h: mv, four 4-pass matrix-core instructions per product instead of four 16-pass ones) and the column, its
+// intermediates and the stage's right-hand sides are single registers instead of tiles
+template <class P, bool VEC>
 SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
     using L = Lay<P>;
@@ -530,7 +533,11 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     const long long tfs = clock64();
     long long tstage = tfs;
 #endif
-    Tile Z = tileZero(), G = ldTile(io.sx, o.rw, io.sX(0));
+    // vector form of the right-hand-side column (VEC): V-layout offsets, one of the four lanes of an element stores
+    const int ve = vElem(lane);
+    const int oVrw = (L::X_BETA + ve) * 8, oVrl = ve < NL ? (L::X_RHO + ve) * 8 : VO_OOB, oVcol = (lane & 3) == 0 ? ve * 8 : VO_OOB;
+    Tile Z = tileZero(), G = VEC ? tileZero() : ldTile(io.sx, o.rw, io.sX(0));
+    double Gv = VEC ? io.sx.ld(oVrw, io.sX(0)) : 0.;
     const HsLane hl = hsLane<P>(lane);
     // One stage.  What is consumed right after the first elimination (M' and E^-1: 12 VGPRs) and the Hessian entries are
     // requested ONE STAGE AHEAD into buffers that rotate by name (stage loop unrolled two-fold) -- under this traffic a load
@@ -553,8 +560,18 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     auto stage = [&](int k, const Early &cur, Early &nxt) -> bool {
         const int ks = k < K - 1 ? k : K - 2, kn = k + 1 < K ? k + 1 : k;
         const Tile cn = ldTile(io.C, o.n, io.sBC(ks));
-        const Tile crl = ldTile(io.sx, o.rl, io.sX(ks));
-        const Tile crwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
+        Tile crl, crwn;
+        double vrl = 0., vrwn = 0.;
+        if constexpr (VEC)
+        {
+            vrl = io.sx.ld(oVrl, io.sX(ks));
+            vrwn = io.sx.ld(oVrw, io.sX(ks + 1));
+        }
+        else
+        {
+            crl = ldTile(io.sx, o.rl, io.sX(ks));
+            crwn = ldTile(io.sx, o.rw, io.sX(ks + 1));
+        }
         nxt = loadEarly(kn);
         LOADS_ISSUED();
         Tile Phi = buildHTile<P>(cur.h, hl, k, K, lane, scvx);
@@ -580,8 +597,18 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         stTile(io.fac, o.triV, io.sFac(k), Li);
         const Tile Lit = transposeTile(Li, sh, lane);
 #endif
-        const Tile a = mm(Lit, G);
-        stTile(io.sv, o.cols, io.sSv(k), a);
+        Tile a;
+        double va = 0.;
+        if constexpr (VEC)
+        {
+            va = mv(Lit, Gv); // Li g
+            io.sv.st(oVcol, io.sSv(k), va);
+        }
+        else
+        {
+            a = mm(Lit, G);
+            stTile(io.sv, o.cols, io.sSv(k), a);
+        }
         if (k == K - 1)
             return false;
         const unsigned fm = L::fixedMask(k, K), fmn = L::fixedMask(k + 1, K);
@@ -616,10 +643,20 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const Tile Tit = transposeTile(Ti, sh, lane);
 #endif
         Z = mm(Tit, finishN<P>(cn, fmn, lane));
-        const Tile gl = tileSub(rhsLSign(sp, lane, crl), mm(Yt, a));
-        const Tile cc = mm(Tit, gl);
-        stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
-        G = tileAdd(crwn, mm(Z, cc));
+        if constexpr (VEC)
+        {
+            const double vgl = vrl - mv(Yt, va); // rho - Yt' a
+            const double vcc = mv(Tit, vgl);     // Ti gl
+            io.sv.st(oVcol, io.sSv(k) + NRHS_MAX * 16 * 8, vcc);
+            Gv = vrwn + mv(Z, vcc);              // beta' + Z' c
+        }
+        else
+        {
+            const Tile gl = tileSub(rhsLSign(sp, lane, crl), mm(Yt, a));
+            const Tile cc = mm(Tit, gl);
+            stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
+            G = tileAdd(crwn, mm(Z, cc));
+        }
         return true;
     };
     Early e0 = loadEarly(0), e1;
@@ -976,6 +1013,14 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
 #define SWEEPS_VECTOR 1 // single-column substitution sweeps on v_mfma_f64_4x4x4_4b_f64 (0: the 16-wide tile sweeps for every column count)
 #endif
 // the sweep for a right-hand-side specification
+template <class P>
+__device__ inline void factorSweepAny(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &sp)
+{
+    if (SWEEPS_VECTOR && sp.n == 1)
+        factorSweepFused<P, true>(cin, sh, sp);
+    else
+        factorSweepFused<P, false>(cin, sh, sp);
+}
 template <class P>
 __device__ inline void fwdSweepAny(const LDSP Ctx *cin, const RhsSpec &sp)
 {
