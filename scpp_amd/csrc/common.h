@@ -186,6 +186,18 @@ __device__ __forceinline__ double waveMaxDpp(double v)
     return fmax(fmax(readLane(v, 0), readLane(v, 16)), fmax(readLane(v, 32), readLane(v, 48)));
 }
 
+// Wave reductions on the VALU data path (round 4; used by the per-iteration phases of ipm_kernel): four symmetric DPP butterflies
+// inside every row of 16 lanes -- every lane of a row then holds the bitwise identical row sum -- and the four row results combined
+// through v_readlane in one fixed order, (r0 + r1) + (r2 + r3).  The xor butterflies below (wave_sum / wave_max) go through the LDS
+// crossbar six times per reduction (ds_bpermute: a dependent round trip each); a phase of the interior-point iteration takes up to
+// eleven such reductions.  Different summation ORDER than wave_sum: equal up to rounding, same value in every lane.
+__device__ __forceinline__ double waveSumDpp(double v)
+{
+    v = rowSum16(v);
+    return (readLane(v, 0) + readLane(v, 16)) + (readLane(v, 32) + readLane(v, 48));
+}
+__device__ __forceinline__ int waveOrBallot(int v) { return anyLane(v != 0) ? 1 : 0; }
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1)

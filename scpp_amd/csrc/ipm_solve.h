@@ -1321,17 +1321,17 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         if (v.vsg)
             stf<L::NL>(sg, G_RY * L::NL, resv);
     }
-    p.gap = wave_sum(p.gap);
-    p.rx = wave_sum(p.rx);
-    p.ry = wave_sum(p.ry);
-    p.rz = wave_sum(p.rz);
-    p.xx = wave_sum(p.xx);
-    p.yy = wave_sum(p.yy);
-    p.zz = wave_sum(p.zz);
-    p.ss = wave_sum(p.ss);
-    p.rxs = wave_sum(p.rxs);
-    p.sumnb = wave_sum(p.sumnb);
-    p_dl = wave_sum(p_dl);
+    p.gap = waveSumDpp(p.gap);
+    p.rx = waveSumDpp(p.rx);
+    p.ry = waveSumDpp(p.ry);
+    p.rz = waveSumDpp(p.rz);
+    p.xx = waveSumDpp(p.xx);
+    p.yy = waveSumDpp(p.yy);
+    p.zz = waveSumDpp(p.zz);
+    p.ss = waveSumDpp(p.ss);
+    p.rxs = waveSumDpp(p.rxs);
+    p.sumnb = waveSumDpp(p.sumnb);
+    p_dl = waveSumDpp(p_dl);
     const Glob g = reloadPriv(gp);
     Iter it = reloadPriv(ip_);
     const double sas = g.sig - 0.001, sa3 = g.n1 - p.sumnb;
@@ -1441,7 +1441,7 @@ PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             printf("[emu] sigma cone scaling failed: s=(%g %g %g) z=(%g %g %g)\n", g.sc3[0], g.sc3[1], g.sc3[2], g.zc3[0], g.zc3[1], g.zc3[2]);
 #endif
     }
-    bad = wave_or(bad);
+    bad = waveOrBallot(bad);
     if (!bad)
     {
         cone::applyW(g.seta, g.sw, 3, g.zc3, g.lamC);
@@ -1714,10 +1714,10 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 bs -= S[i] * bcl[i];
             }
         }
-        cv = wave_sum(cv);
+        cv = waveSumDpp(cv);
         if (pass == 0)
         {
-            bs = wave_sum(bs);
+            bs = waveSumDpp(bs);
             g.schur = gp->hsig - bs;
         }
         if (!(g.schur > 0.))
@@ -1789,8 +1789,8 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             stf<NLP>(st, L::F_DS + LP0, dsv);
         }
     }
-    ainv = wave_max(ainv);
-    finite_chk = wave_sum(finite_chk);
+    ainv = waveMaxDpp(ainv);
+    finite_chk = waveSumDpp(finite_chk);
     it.part_ainv = ainv;
     it.part_fin = finite_chk;
     PUT_BEGIN();
@@ -1827,12 +1827,12 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         ainv = o.ainv;
         sumdnb = o.sumdnb;
     });
-    sumdnb = wave_sum(sumdnb);
+    sumdnb = waveSumDpp(sumdnb);
     const Glob gt = reloadPriv(gp);
     const Iter itt = reloadPriv(ip_);
     // a non-finite Newton direction (breakdown of the factorisation near the end of the path) must not be applied
     // (sumdnb carries dlam through dnu / dnub)
-    finite_chk = finite_chk + wave_sum(sumdnb * 0.);
+    finite_chk = finite_chk + waveSumDpp(sumdnb * 0.);
     if (!(finite_chk == 0.))
         it.bad = 1;
     g.dn1 = sumdnb - (gt.s3 / gt.z3) * gt.dz3 - itt.b.rhs3;
@@ -1864,7 +1864,7 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         ainv = a1 > ainv ? a1 : ainv;
         ainv = a2 > ainv ? a2 : ainv;
     }
-    ainv = wave_max(ainv);
+    ainv = waveMaxDpp(ainv);
     if (pass == 0)
     {
         double alpha_a = ainv > 0. ? 1. / ainv : 1.;

@@ -165,8 +165,18 @@ __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
                            // converged/s on the same box (+1.9 %).  Uses A[j][i] where the LDS exchange (-DINVCHOL_BPERMUTE=0) uses
                            // A[i][j]: equal up to rounding, and the scalar twin's own formula (structured_ipm.hpp: invCholFactor)
 #endif
-template <int n>
-INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
+#ifndef INVCHOL_PIVOTS_AT_END
+#define INVCHOL_PIVOTS_AT_END 1
+#endif
+#ifndef INVCHOL_SPECULATE
+#define INVCHOL_SPECULATE 1
+#endif
+// FLOOR = false: the elimination WITHOUT the pivot floor (no floor read, no v_max between a pivot and its reciprocal: five instructions
+// less per step, and the eliminations are issue-bound at two wavefronts per SIMD); `*ok` then says whether every pivot was above its
+// floor, in which case the result is bitwise what the floored elimination returns.  invCholFactor runs this one first and repeats with
+// FLOOR = true in the (rare) other case.
+template <int n, bool FLOOR>
+INVCHOL_LINKAGE Tile invCholImpl(Tile A, TileShared &sh, int lane, bool *ok)
 {
     const int g = lane >> 4, i = lane & 15;
     Tile R;
@@ -210,7 +220,9 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         // (taking the maximum in the pivot's own lane before ONE broadcast -- two readlanes and two canonicalising v_max less per
         //  step, bitwise the same pivot -- was measured in round 3: 3915 vs 3923 converged/s, no difference; not kept)
         double d = readLane(rj_ == 0 ? A.v[0] : rj_ == 1 ? A.v[1] : rj_ == 2 ? A.v[2] : A.v[3], (j & 3) * 16 + j); // A[j][j]
-        const double floor_ = readLane(od, (j & 3) * 16 + j);
+        double floor_ = 0.;
+        if (FLOOR)
+            floor_ = readLane(od, (j & 3) * 16 + j);
 #if INVCHOL_BPERMUTE
         // lane (j & 3, i) holds A[j][i] and R[j][i] in register j >> 2: every lane of column i fetches them from there
         (void)b;
@@ -245,7 +257,12 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
         const double aj = rowGroupDiag(iq == 0 ? cr[0] : iq == 1 ? cr[1] : iq == 2 ? cr[2] : cr[3]);
         const double rj = rowGroupBcast<(j & 3)>(rj_ == 0 ? R.v[0] : rj_ == 1 ? R.v[1] : rj_ == 2 ? R.v[2] : R.v[3]);
 #endif
-        d = fmax(d, floor_);
+        // (round 4, measured and not kept: the floor taken off the dependent chain -- reciprocal of the raw pivot straight from the
+        //  v_readlane, 1 / floor precomputed per column, a select afterwards; bitwise identical, two v_max_f64 less on the chain but
+        //  seven instructions more per step: 4845 against 5128 converged/s on the same box (-5.5 %).  At two wavefronts per SIMD the
+        //  eliminations are bound by instruction ISSUE: every instruction added to a step costs, every one removed pays)
+        if (FLOOR)
+            d = fmax(d, floor_);
         const double p = fastRcp(d);
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -256,10 +273,28 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
                 A.v[r] -= m * aj;
                 R.v[r] -= m * rj;
             }
+#if !INVCHOL_PIVOTS_AT_END
             if (r == rj_)
                 pvr[r] = (g + 4 * r == j) ? d : pvr[r];
+#endif
         }
     });
+#if INVCHOL_PIVOTS_AT_END
+    // The pivots are read off the final A (round 4): row j of A is not touched after step j - 1 (its own multipliers are 0), so the
+    // diagonal lane (row & 3, row) still holds the raw pivot of its row, and its `od` is that row's floor: one v_max there, then every
+    // lane of a row fetches its row's pivot from the diagonal lane -- instead of two v_cndmask in every one of the n steps.  Bitwise
+    // the same value as max(d, floor) taken at the step.
+    {
+        const int q = i >> 2;
+        const double dg = q == 0 ? A.v[0] : q == 1 ? A.v[1] : q == 2 ? A.v[2] : A.v[3]; // A[i][i] where (i & 3) == g
+        const double dm = FLOOR ? fmax(dg, od) : dg;
+        if (!FLOOR) // every pivot strictly above its floor (NaN fails): otherwise the caller repeats with the floor
+            *ok = !anyLane((i & 3) == g && i < n && !(dg > od));
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            pvr[r] = (4 * r < n) ? __shfl(dm, g * 16 + g + 4 * r) : 1.;
+    }
+#endif
     Tile Li;
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -271,6 +306,20 @@ INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
             Li.v[r] = (i == row) ? 1. : 0.;
     }
     return Li;
+}
+template <int n>
+INVCHOL_LINKAGE Tile invCholFactor(Tile A, TileShared &sh, int lane)
+{
+#if INVCHOL_SPECULATE && INVCHOL_PIVOTS_AT_END
+    bool ok = true;
+    Tile Li = invCholImpl<n, false>(A, sh, lane, &ok);
+    if (!ok) // a pivot at or below 1e-14 of its original diagonal entry (or not finite): the floored elimination, as before
+        Li = invCholImpl<n, true>(A, sh, lane, &ok);
+    return Li;
+#else
+    bool ok = true;
+    return invCholImpl<n, true>(A, sh, lane, &ok);
+#endif
 }
 
 // The TRANSPOSED inverse factor Lit = (chol(A)^-1)' directly (round 4; selectable, NOT the default -- see INVCHOL_TRANSPOSED below).  The factor sweep needs Li only as the first operand of
