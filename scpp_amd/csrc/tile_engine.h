@@ -122,9 +122,28 @@ struct TileShared
 #endif
 };
 
+// transpose of a D-layout tile ON THE MATRIX CORE (round 4): mm(X, I) = X' I, exact in floating point (every product is x * 1 or x * 0),
+// four instructions of a pipe the kernel leaves mostly idle, no LDS traffic and no wavefront fences on the stage's dependent chain
+__device__ inline Tile transposeTileMfma(const Tile &t, int lane)
+{
+    const int g = lane >> 4, i = lane & 15;
+    Tile id;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        id.v[r] = (g + 4 * r == i) ? 1. : 0.;
+    return mm(t, id);
+}
+#ifndef TRANSPOSE_MFMA
+#define TRANSPOSE_MFMA 0 // measured (round 4, same box, bitwise identical): 5063 / 5149 / 5121 against 5091 / 5135 / 5136 converged/s with the LDS
+                         // transpose -- no difference; the LDS path stays the default
+#endif
 // transpose a D-layout tile through LDS
 __device__ inline Tile transposeTile(const Tile &t, TileShared &sh, int lane)
 {
+#if TRANSPOSE_MFMA
+    (void)sh;
+    return transposeTileMfma(t, lane);
+#endif
     const int g = lane >> 4, i = lane & 15;
     WAVE_SYNC();
 #pragma unroll
