@@ -1114,7 +1114,23 @@ __device__ inline void ldSegState(const SV &sg, const SegLds &sl, SegState<N> &q
 struct SegRhsRow
 {
     double rz1, rz2, t1, t2, bnb, btn, einv, qv, d1, d2, dinv;
+    double is1, iz1, is2, iz2; // reciprocals of the slacks and duals of the LP pair
 };
+// SEG_FAST_RCP: every quotient of a row goes through ONE reciprocal per slack / dual (v_rcp_f64 + two Newton steps, common.h: fastRcp:
+// 5 instructions, within 1 ulp) and multiplications, instead of an IEEE division (11 instructions, two of them quarter rate) each: a
+// row takes 8 .. 12 divisions per phase, 44 per interior-point iteration, i.e. ~600 per lane.  The operands are slacks and duals of an
+// interior point: positive, normal.
+#ifndef SEG_FAST_RCP
+#define SEG_FAST_RCP 1
+#endif
+__device__ inline double segRcp(double x)
+{
+#if SEG_FAST_RCP
+    return fastRcp(x);
+#else
+    return 1. / x;
+#endif
+}
 template <int PASS>
 __device__ inline SegRhsRow segRhsRow(double nu, double nub, double s1, double z1, double s2, double z2, double lam, double p1, double p2, double om,
                                       double sigmu, double z3, double dz3)
@@ -1124,6 +1140,20 @@ __device__ inline SegRhsRow segRhsRow(double nu, double nub, double s1, double z
     o.rz1 = s1 - (nub - nu);
     o.rz2 = s2 - (nub + nu);
     const double rxnu = -lam + z1 - z2, rxnub = -z1 - z2 + z3;
+#if SEG_FAST_RCP
+    o.is1 = segRcp(s1);
+    o.iz1 = segRcp(z1);
+    o.is2 = segRcp(s2);
+    o.iz2 = segRcp(z2);
+    double c1 = 0., c2 = 0.;
+    if (PASS)
+    {
+        c1 = (sigmu - p1) * o.is1;
+        c2 = (sigmu - p2) * o.is2;
+    }
+    o.d1 = z1 * o.is1;
+    o.d2 = z2 * o.is2;
+#else
     double c1 = 0., c2 = 0.;
     if (PASS)
     {
@@ -1132,15 +1162,23 @@ __device__ inline SegRhsRow segRhsRow(double nu, double nub, double s1, double z
     }
     o.d1 = z1 / s1;
     o.d2 = z2 / s2;
+#endif
     o.t1 = o.d1 * om * o.rz1 - z1 + c1;
     o.t2 = o.d2 * om * o.rz2 - z2 + c2;
     const double bxnu = -om * rxnu + (-o.t1 + o.t2);
     const double bxnub = -om * rxnub + (o.t1 + o.t2);
     // E^-1, q and 1 / (d1 + d2) of the eliminated LP pair
+#if SEG_FAST_RCP
+    const double r1 = s1 * o.iz1, r2 = s2 * o.iz2;
+    o.einv = 0.25 * (r1 + r2);
+    o.qv = (r1 - r2) * segRcp(r1 + r2);
+    o.dinv = segRcp(o.d1 + o.d2);
+#else
     const double r1 = s1 / z1, r2 = s2 / z2;
     o.einv = 0.25 * (r1 + r2);
     o.qv = (r1 - r2) / (r1 + r2);
     o.dinv = 1. / (o.d1 + o.d2);
+#endif
     o.bnb = bxnub - dz3;
     o.btn = bxnu - o.qv * o.bnb;
     return o;
@@ -1639,7 +1677,11 @@ __device__ inline void dirSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
                                             sigmu, z3, dz3);
         const SegDirRow d = segDirRow(r, vl[i], bcl[i], om, dsig);
         sumdnb += d.dnub;
+#if SEG_FAST_RCP
+        double m1 = -d.ds1 * r.is1, m2 = -d.dz1 * r.iz1, m3 = -d.ds2 * r.is2, m4 = -d.dz2 * r.iz2;
+#else
         double m1 = -d.ds1 / q.s1[i], m2 = -d.dz1 / q.z1[i], m3 = -d.ds2 / q.s2[i], m4 = -d.dz2 / q.z2[i];
+#endif
         m1 = m1 > m2 ? m1 : m2;
         m3 = m3 > m4 ? m3 : m4;
         m1 = m1 > m3 ? m1 : m3;

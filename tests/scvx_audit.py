@@ -41,6 +41,20 @@ def device_path(alg, x0, max_iterations):
     return path
 
 
+def _dump_literal_failure(s, Xb, Ub, radius, Xc, Uc, iteration, c):
+    """keep the inputs of a sub-problem on which the literal solver returned garbage, for an offline look at oracle/socp.hpp"""
+    import os
+
+    try:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "literal_failures")
+        os.makedirs(root, exist_ok=True)
+        np.savez(os.path.join(root, "subproblem_it%d_%d.npz" % (iteration, len(os.listdir(root)))), Xbar=Xb, Ubar=Ub, radius=radius, Xc=Xc, Uc=Uc,
+                 x_init=s.x_init() if hasattr(s, "x_init") else np.zeros(0), lit_cost=c["lit_cost"], cost=c["cost"],
+                 flag=c.get("lit_exitflag_reported", 0))
+    except Exception:
+        pass
+
+
 def audit_instance(oracle, K, seed, instance_id, path, b, alpha, lit_tol=1e-9):
     """check_point of every accepted sub-problem of instance b (= randomised RocketQuat instance `instance_id` of `seed`)."""
     s = oracle.SCvx(K=K)
@@ -64,6 +78,19 @@ def audit_rows(s, path, b, alpha):
         c = s.check_point(Xb, Ub, r_used, st["X"][b], st["U"][b], True)
         c["iteration"], c["radius"], c["rejections"] = j + 1, r_used, n_rej
         ok = c["lit_exitflag"] in (0, 10)
+        if ok:
+            # The CHECKER is checked before it is believed: the literal solver's own point must be a point of its own problem
+            # (round 4: on 1 of 540 sub-problems of a GPU session it returned exit flag 10, "close to optimal", with entries of 1e25).
+            # A literal result that is not feasible to 1e-6 counts as a literal-solver FAILURE (flag -3), like its -1 / -2 exits; the
+            # callers' bound on the number of such failures is unchanged.
+            v = s.check_point(Xb, Ub, r_used, c["X_lit"], c["U_lit"], False)
+            sane = (np.isfinite(c["lit_cost"]) and np.isfinite(v["cost"]) and v["eq_violation"] <= 1e-6 and v["min_lp_slack"] >= -1e-6
+                    and v["min_cone_slack"] >= -1e-6)
+            if not sane:
+                c["lit_exitflag_reported"] = c["lit_exitflag"]
+                c["lit_exitflag"] = -3
+                ok = False
+                _dump_literal_failure(s, Xb, Ub, r_used, st["X"][b], st["U"][b], j + 1, c)
         c["relX"] = float(np.abs(c["X_lit"] - st["X"][b]).max() / np.abs(st["X"][b]).max()) if ok else None
         c["relU"] = float(np.abs(c["U_lit"] - st["U"][b]).max() / np.abs(st["U"][b]).max()) if ok else None
         del c["X_lit"], c["U_lit"]
