@@ -882,6 +882,10 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 // mv(X, v) = X' v for a tile X in the D layout of the 16-wide instruction: "A4 layout of T" (tile_engine.h) IS the D layout of T', so the
 // vector sweeps load exactly the tiles -- same offsets, same coalescing, same finish* masks -- the tile sweeps above load, and replace
 // mm(X, right-hand-side tile) by mv(X, right-hand-side vector).
+#ifndef SWEEPV_PREFETCH
+#define SWEEPV_PREFETCH 2 // stages of loads in flight ahead of the dependent chain in the vector sweeps (3 = four buffers: measured 5116 against
+                          // 5137 converged/s, round 4: the vector sweeps are bound by their chain of dependent products, not by memory latency)
+#endif
 struct FwdVIn
 {
     Tile lit, yt, tit, ti, n;
@@ -925,6 +929,30 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         return true;
     };
     auto clampK = [&](int k) { return k < K ? k : K - 1; };
+#if SWEEPV_PREFETCH == 3
+    // four buffers rotated by name: the loads of stage k + 3 are in flight while stage k computes (a right-hand side is one register
+    // here, not a tile: the registers the tile sweeps spend on columns buy a third stage of prefetch distance)
+    FwdVIn b0 = load(0), b1 = load(clampK(1)), b2 = load(clampK(2)), b3;
+    for (int k = 0; k < K; k += 4)
+    {
+        b3 = load(clampK(k + 3));
+        LOADS_ISSUED();
+        if (!stage(k, b0))
+            break;
+        b0 = load(clampK(k + 4));
+        LOADS_ISSUED();
+        if (!stage(k + 1, b1))
+            break;
+        b1 = load(clampK(k + 5));
+        LOADS_ISSUED();
+        if (!stage(k + 2, b2))
+            break;
+        b2 = load(clampK(k + 6));
+        LOADS_ISSUED();
+        if (!stage(k + 3, b3))
+            break;
+    }
+#else
     FwdVIn b0 = load(0), b1 = load(clampK(1)), b2;
     for (int k = 0; k < K; k += 3)
     {
@@ -941,6 +969,7 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         if (!stage(k + 2, b2))
             break;
     }
+#endif
     WAVE_SYNC();
 }
 
@@ -990,6 +1019,30 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         io.sx.st(oSolW, io.sX(k), x);
     };
     auto clampK = [&](int k) { return k > 0 ? k : 0; };
+#if SWEEPV_PREFETCH == 3
+    BwdVIn b0 = load(K - 1), b1 = load(clampK(K - 2)), b2 = load(clampK(K - 3)), b3;
+    for (int k = K - 1; k >= 0; k -= 4)
+    {
+        b3 = load(clampK(k - 3));
+        LOADS_ISSUED();
+        stage(k, b0);
+        if (k - 1 < 0)
+            break;
+        b0 = load(clampK(k - 4));
+        LOADS_ISSUED();
+        stage(k - 1, b1);
+        if (k - 2 < 0)
+            break;
+        b1 = load(clampK(k - 5));
+        LOADS_ISSUED();
+        stage(k - 2, b2);
+        if (k - 3 < 0)
+            break;
+        b2 = load(clampK(k - 6));
+        LOADS_ISSUED();
+        stage(k - 3, b3);
+    }
+#else
     BwdVIn b0 = load(K - 1), b1 = load(clampK(K - 2)), b2;
     for (int k = K - 1; k >= 0; k -= 3)
     {
@@ -1007,6 +1060,7 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         LOADS_ISSUED();
         stage(k - 2, b2);
     }
+#endif
     WAVE_SYNC();
 }
 #ifndef SWEEPS_VECTOR

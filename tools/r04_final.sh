@@ -28,6 +28,8 @@ grep '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
 timeout -k 5 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_driver.log 2>&1; echo "bench driver-style rc=$?"
 grep '^{' $OUT/bench_driver.log | tail -1 > $OUT/bench_driver.json
 rm -f profiles/r04_pmc_hbm_v9_session.json
+# in-kernel phase timers of the same sources (-DIPM_PROFILE build made before the session: build/prof_final.so)
+[ -f build/prof_final.so ] && timeout 300 python tools/phase_prof_scvx.py build/prof_final.so 4096 3 > $OUT/phase_prof.txt 2>&1
 (cd scpp_amd/host && timeout 300 ./scvx_multi_gpu --batch 4096 --gpus 1 --slots 4096 --config ../config > $OUT/scvx_multi_gpu.log 2>&1; echo "scvx_multi_gpu rc=$?"; tail -3 $OUT/scvx_multi_gpu.log)
 python - <<PY
 import json
