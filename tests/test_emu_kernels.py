@@ -602,3 +602,34 @@ def _scvx_zoh_case(oracle, lib, tmp_path, KQ, K2, maxit=None):
 
 def test_emu_scvx_zero_order_hold(oracle, emu_lib, tmp_path):
     _scvx_zoh_case(oracle, emu_lib, tmp_path, 8, 8, maxit=6)
+
+
+def test_emu_round4_fast_paths_are_bitwise_the_reference_structure(emu_lib, tmp_path):
+    """Three round-4 changes of ipm_kernel claim BITWISE identical results: the single-column sweeps on the 4 x 4 x 4 matrix instruction
+    (SWEEPS_VECTOR: matrix x vector instead of X'Y on 16-wide tiles), the pivots read off the final diagonal (INVCHOL_PIVOTS_AT_END) and the
+    speculative floor-free elimination with its floored repeat (INVCHOL_SPECULATE: the repeat is the RARE path -- 8 of 8076 eliminations of
+    the SC run below, 19 of 26766 overall, counted with an instrumented build -- and this test is what exercises it against the
+    always-floored elimination).  The kernel sources are compiled once more with the three switches off (the round-3 structure of those
+    parts) and both builds must agree bit for bit on SC and SCvx runs of both models."""
+    import os
+    import subprocess
+
+    import __graft_entry__ as g
+
+    ref = str(tmp_path / "libscpp_emu_ref.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-DSCPP_HIP_EMU", "-DSWEEPS_VECTOR=0", "-DINVCHOL_PIVOTS_AT_END=0", "-DINVCHOL_SPECULATE=0",
+                           "-I" + os.path.join(g.ROOT, "tests", "emu"), "-shared", "-o", ref, "-x", "c++", os.path.join(g.CSRC, "scpp_hip.cpp")],
+                          stderr=subprocess.DEVNULL)
+    m = scpp_amd.RocketQuat().loadParameters()
+    m2 = scpp_amd.Rocket2D().loadParameters()
+    x0, x2 = m.randomized_initial_states(3), m2.randomized_initial_states(2)
+    outs = []
+    for lib in (emu_lib, ref):
+        o = []
+        a = scpp_amd.SCAlgorithm(m, K=10, batch_max=3, library=lib).initialize(); a.solve(x0); o.append(a.getSolution()); a.ctx.close()
+        v = scpp_amd.SCvxAlgorithm(m, K=12, batch_max=3, library=lib, max_iterations=8).initialize(); v.solve(x0); o.append(v.getSolution()); v.ctx.close()
+        v2 = scpp_amd.SCvxAlgorithm(m2, K=8, batch_max=2, library=lib, max_iterations=5).initialize(); v2.solve(x2); o.append(v2.getSolution()); v2.ctx.close()
+        outs.append(o)
+    for a, b in zip(*outs):
+        for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "ipm_iters", "status", "converged"):
+            assert np.array_equal(a[key], b[key]), key
