@@ -1,5 +1,5 @@
 // Stage sweeps of the block-tridiagonal KKT system on the tile engine (see tile_engine.h for the algebra).
-//   factorSweepFused : factorisation + forward substitution of up to 2 right-hand-side columns
+//   factorSweepFused : factorisation + forward substitution of up to 2 right-hand-side columns (NCV: columns as vectors; 0: as a tile)
 //   fwdSweep         : forward substitution only (re-uses the stored tiles)
 //   bwdSweep         : backward substitution, writes dw / dlam columns to the exchange records
 // Right-hand sides and solutions live in the stage-major exchange records (Lay<P>::X_*).  Column 0 of a 2-column
@@ -266,6 +266,38 @@ __device__ inline Tile rhsLSign(const RhsSpec &sp, int lane, const Tile &t)
     return t;
 }
 
+// ---- right-hand-side COLUMNS in V layout (vector sweeps; NC = 1: one regular column, NC = 2: sigma border + regular column) ----
+// column c of an NC-column sweep: border (reads -S_k, beta = 0, writes X_BCW / X_BCL) or regular (X_BETA / X_RHO -> X_VW / X_VL)
+template <int NC>
+__device__ inline constexpr bool colIsBorder(int c)
+{
+    return NC == 2 && c == 0;
+}
+template <class P, int NC>
+struct VCols
+{
+    using L = Lay<P>;
+    int rw[NC], rl[NC], solW[NC], solL[NC], colL[NC], colS[NC];
+    __device__ explicit VCols(int lane)
+    {
+        const int e = vElem(lane);
+        const bool st0 = (lane & 3) == 0; // every element lives in four lanes: one of them stores
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+        {
+            const bool border = colIsBorder<NC>(c);
+            rw[c] = border ? VO_OOB : (L::X_BETA + e) * 8;
+            rl[c] = e < L::NL ? ((border ? L::X_S : L::X_RHO) + e) * 8 : VO_OOB;
+            solW[c] = st0 ? ((border ? L::X_BCW : L::X_VW) + e) * 8 : VO_OOB;
+            solL[c] = (st0 && e < L::NL) ? ((border ? L::X_BCL : L::X_VL) + e) * 8 : VO_OOB;
+            colL[c] = (c * 16 + e) * 8; // saved forward intermediates: column c at [c * 16 + row] (the layout of offCols)
+            colS[c] = st0 ? (c * 16 + e) * 8 : VO_OOB;
+        }
+    }
+    // the border column stores S: the sign is applied at use
+    __device__ static double rlSign(int c, double v) { return colIsBorder<NC>(c) ? -v : v; }
+};
+
 __device__ inline Tile tileSub(const Tile &a, const Tile &b)
 {
     Tile t;
@@ -499,10 +531,10 @@ struct FactorOffs
     int einv;
 };
 
-// VEC: ONE right-hand-side column (SCvx mode: no sigma border) -- the forward substitution fused into the factorisation then runs on
-// vectors (tile_engine.h: mv, four 4-pass matrix-core instructions per product instead of four 16-pass ones) and the column, its
-// intermediates and the stage's right-hand sides are single registers instead of tiles
-template <class P, bool VEC>
+// NCV > 0: the NCV right-hand-side columns (1: SCvx mode, no sigma border; 2: [border | column]) in VECTOR form -- the forward substitution
+// fused into the factorisation then runs on vectors (tile_engine.h: mv, four 4-pass matrix-core instructions per product instead of four
+// 16-pass ones) and a column, its intermediates and the stage's right-hand sides are single registers instead of tiles.  NCV == 0: tiles.
+template <class P, int NCV>
 SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
     using L = Lay<P>;
@@ -533,11 +565,15 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     const long long tfs = clock64();
     long long tstage = tfs;
 #endif
-    // vector form of the right-hand-side column (VEC): V-layout offsets, one of the four lanes of an element stores
-    const int ve = vElem(lane);
-    const int oVrw = (L::X_BETA + ve) * 8, oVrl = ve < NL ? (L::X_RHO + ve) * 8 : VO_OOB, oVcol = (lane & 3) == 0 ? ve * 8 : VO_OOB;
+    // vector form of the right-hand-side columns (VEC): V-layout offsets, one of the four lanes of an element stores
+    constexpr bool VEC = NCV > 0;
+    constexpr int NC = VEC ? NCV : 1;
+    const VCols<P, NC> vc(lane);
     Tile Z = tileZero(), G = VEC ? tileZero() : ldTile(io.sx, o.rw, io.sX(0));
-    double Gv = VEC ? io.sx.ld(oVrw, io.sX(0)) : 0.;
+    double Gv[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        Gv[q] = VEC ? io.sx.ld(vc.rw[q], io.sX(0)) : 0.;
     const HsLane hl = hsLane<P>(lane);
     // One stage.  What is consumed right after the first elimination (M' and E^-1: 12 VGPRs) and the Hessian entries are
     // requested ONE STAGE AHEAD into buffers that rotate by name (stage loop unrolled two-fold) -- under this traffic a load
@@ -561,11 +597,15 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const int ks = k < K - 1 ? k : K - 2, kn = k + 1 < K ? k + 1 : k;
         const Tile cn = ldTile(io.C, o.n, io.sBC(ks));
         Tile crl, crwn;
-        double vrl = 0., vrwn = 0.;
+        double vrl[NC], vrwn[NC];
         if constexpr (VEC)
         {
-            vrl = io.sx.ld(oVrl, io.sX(ks));
-            vrwn = io.sx.ld(oVrw, io.sX(ks + 1));
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+            {
+                vrl[q] = io.sx.ld(vc.rl[q], io.sX(ks));
+                vrwn[q] = io.sx.ld(vc.rw[q], io.sX(ks + 1));
+            }
         }
         else
         {
@@ -598,11 +638,15 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         const Tile Lit = transposeTile(Li, sh, lane);
 #endif
         Tile a;
-        double va = 0.;
+        double va[NC];
         if constexpr (VEC)
         {
-            va = mv(Lit, Gv); // Li g
-            io.sv.st(oVcol, io.sSv(k), va);
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+            {
+                va[q] = mv(Lit, Gv[q]); // Li g
+                io.sv.st(vc.colS[q], io.sSv(k), va[q]);
+            }
         }
         else
         {
@@ -645,10 +689,14 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         Z = mm(Tit, finishN<P>(cn, fmn, lane));
         if constexpr (VEC)
         {
-            const double vgl = vrl - mv(Yt, va); // rho - Yt' a
-            const double vcc = mv(Tit, vgl);     // Ti gl
-            io.sv.st(oVcol, io.sSv(k) + NRHS_MAX * 16 * 8, vcc);
-            Gv = vrwn + mv(Z, vcc);              // beta' + Z' c
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+            {
+                const double vgl = VCols<P, NC>::rlSign(q, vrl[q]) - mv(Yt, va[q]); // rho - Yt' a
+                const double vcc = mv(Tit, vgl);                                    // Ti gl
+                io.sv.st(vc.colS[q], io.sSv(k) + NRHS_MAX * 16 * 8, vcc);
+                Gv[q] = vrwn[q] + mv(Z, vcc); // beta' + Z' c
+            }
         }
         else
         {
@@ -871,27 +919,28 @@ SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 }
 
 // =====================================================================================================================
-// Single-column substitution sweeps on the matrix-VECTOR engine (tile_engine.h: mv; round 4).
+// Substitution sweeps on the matrix-VECTOR engine (tile_engine.h: mv; round 4), one or two right-hand-side columns.
 // fwdSweep / bwdSweep above carry up to two right-hand-side columns through X'Y products of 16 x 16 tiles: four 16-pass matrix-core
 // instructions per product whatever the number of columns.  Every sweep of the SCvx mode (no sigma border, specSingle) and the corrector
-// sweeps of the SC mode have ONE column: here the same recursion runs on vectors in V layout and tiles loaded in A4 layout, four
-// 4-pass v_mfma_f64_4x4x4_4b_f64 + four DPP row broadcasts per product, and a right-hand side is one register instead of a tile.
-// Same operands, same records; the contraction is grouped in blocks of four consecutive indices instead of four strided ones, so
-// results differ from the tile sweeps in the last bits only (the factor sweep keeps the tile engine: its products are matrix x matrix).
+// sweeps of the SC mode have ONE column, the predictor sweeps of the SC mode two ([sigma border | column]): here the same recursion runs
+// on vectors in V layout and tiles loaded in A4 layout, four 4-pass v_mfma_f64_4x4x4_4b_f64 + four DPP row broadcasts per product and
+// column, and a right-hand side is one register instead of a tile.  Same operands, same records, and the contraction is grouped in the
+// same blocks of four as in the 16-wide instruction: results are BITWISE those of the tile sweeps (tests/test_emu_kernels.py compiles
+// both; tests/tools/lib_equal.py, sc_mode_ab.py on the GPU).  The factorisation itself keeps the tile engine: its products are matrix x
+// matrix; only its fused forward substitution is vectors.
 // =====================================================================================================================
 // mv(X, v) = X' v for a tile X in the D layout of the 16-wide instruction: "A4 layout of T" (tile_engine.h) IS the D layout of T', so the
 // vector sweeps load exactly the tiles -- same offsets, same coalescing, same finish* masks -- the tile sweeps above load, and replace
 // mm(X, right-hand-side tile) by mv(X, right-hand-side vector).
-#ifndef SWEEPV_PREFETCH
-#define SWEEPV_PREFETCH 2 // stages of loads in flight ahead of the dependent chain in the vector sweeps (3 = four buffers: measured 5116 against
-                          // 5137 converged/s, round 4: the vector sweeps are bound by their chain of dependent products, not by memory latency)
-#endif
+// (prefetch distance: two stages, three buffers rotated by name; four buffers = three stages ahead measured 5116 against 5137 converged/s,
+//  round 4: the vector sweeps are bound by their chain of dependent products, not by memory latency)
+template <int NC>
 struct FwdVIn
 {
     Tile lit, yt, tit, ti, n;
-    double rl, rwn;
+    double rl[NC], rwn[NC];
 };
-template <class P>
+template <class P, int NC>
 SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
 {
     using L = Lay<P>;
@@ -899,61 +948,52 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    const int e = vElem(lane);
+    const VCols<P, NC> vc(lane);
     const Off4 oLit = offTriT<NV>(lane, L::FAC_LI), oYt = offYt<NL>(lane, L::FAC_YT), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oN = offN<P>(lane);
-    const int oRw = (L::X_BETA + e) * 8, oRl = e < NL ? (L::X_RHO + e) * 8 : VO_OOB;
-    const int oColS = (lane & 3) == 0 ? e * 8 : VO_OOB; // every element lives in four lanes: one of them stores
     auto load = [&](int k) {
         const int ks = k < K - 1 ? k : K - 2; // the last stage has no segment: it re-reads segment K-2 (in range, unused)
-        FwdVIn f;
+        FwdVIn<NC> f;
         f.lit = ldTile(io.fac, oLit, io.sFac(k));
         f.yt = ldTile(io.fac, oYt, io.sFac(ks));
         f.tit = ldTile(io.fac, oTit, io.sFac(ks));
         f.ti = ldTile(io.fac, oTi, io.sFac(ks));
         f.n = ldTile(io.C, oN, io.sBC(ks));
-        f.rl = io.sx.ld(oRl, io.sX(ks));
-        f.rwn = io.sx.ld(oRw, io.sX(ks + 1));
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+        {
+            f.rl[q] = io.sx.ld(vc.rl[q], io.sX(ks));
+            f.rwn[q] = io.sx.ld(vc.rw[q], io.sX(ks + 1));
+        }
         return f;
     };
-    double G = io.sx.ld(oRw, io.sX(0));
-    auto stage = [&](int k, const FwdVIn &cur) -> bool {
-        const double a = mv(cur.lit, G); // Li g
-        io.sv.st(oColS, io.sSv(k), a);
+    double G[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        G[q] = io.sx.ld(vc.rw[q], io.sX(0));
+    auto stage = [&](int k, const FwdVIn<NC> &cur) -> bool {
+        double a[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+        {
+            a[q] = mv(cur.lit, G[q]); // Li g
+            io.sv.st(vc.colS[q], io.sSv(k), a[q]);
+        }
         if (k == K - 1)
             return false;
-        const double gl = cur.rl - mv(cur.yt, a); // rho - Yt' a
-        const double cc = mv(cur.tit, gl);        // Ti gl
-        io.sv.st(oColS, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
-        G = cur.rwn + mv(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mv(cur.ti, cc)); // beta' + N' (Ti' c)
+        const Tile Nfin = finishN<P>(cur.n, L::fixedMask(k + 1, K), lane);
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+        {
+            const double gl = VCols<P, NC>::rlSign(q, cur.rl[q]) - mv(cur.yt, a[q]); // rho - Yt' a
+            const double cc = mv(cur.tit, gl);                                       // Ti gl
+            io.sv.st(vc.colS[q], io.sSv(k) + NRHS_MAX * 16 * 8, cc);
+            G[q] = cur.rwn[q] + mv(Nfin, mv(cur.ti, cc)); // beta' + N' (Ti' c)
+        }
         return true;
     };
     auto clampK = [&](int k) { return k < K ? k : K - 1; };
-#if SWEEPV_PREFETCH == 3
-    // four buffers rotated by name: the loads of stage k + 3 are in flight while stage k computes (a right-hand side is one register
-    // here, not a tile: the registers the tile sweeps spend on columns buy a third stage of prefetch distance)
-    FwdVIn b0 = load(0), b1 = load(clampK(1)), b2 = load(clampK(2)), b3;
-    for (int k = 0; k < K; k += 4)
-    {
-        b3 = load(clampK(k + 3));
-        LOADS_ISSUED();
-        if (!stage(k, b0))
-            break;
-        b0 = load(clampK(k + 4));
-        LOADS_ISSUED();
-        if (!stage(k + 1, b1))
-            break;
-        b1 = load(clampK(k + 5));
-        LOADS_ISSUED();
-        if (!stage(k + 2, b2))
-            break;
-        b2 = load(clampK(k + 6));
-        LOADS_ISSUED();
-        if (!stage(k + 3, b3))
-            break;
-    }
-#else
-    FwdVIn b0 = load(0), b1 = load(clampK(1)), b2;
+    FwdVIn<NC> b0 = load(0), b1 = load(clampK(1)), b2;
     for (int k = 0; k < K; k += 3)
     {
         b2 = load(clampK(k + 2));
@@ -969,16 +1009,16 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         if (!stage(k + 2, b2))
             break;
     }
-#endif
     WAVE_SYNC();
 }
 
+template <int NC>
 struct BwdVIn
 {
     Tile li, nt, tit, ti, y;
-    double as, cs;
+    double as[NC], cs[NC];
 };
-template <class P>
+template <class P, int NC>
 SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
 {
     using L = Lay<P>;
@@ -986,64 +1026,55 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    const int e = vElem(lane);
+    const VCols<P, NC> vc(lane);
     const Off4 oLi = offTri<NV>(lane, L::FAC_LI), oNt = offNt<P>(lane), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oY = offYtT<NL>(lane, L::FAC_YT);
-    const int oCol = e * 8;
-    const bool st0 = (lane & 3) == 0;
-    const int oSolW = st0 ? (L::X_VW + e) * 8 : VO_OOB, oSolL = (st0 && e < NL) ? (L::X_VL + e) * 8 : VO_OOB;
     auto load = [&](int k) {
         const int ks = k < K - 1 ? k : K - 2;
-        BwdVIn b;
+        BwdVIn<NC> b;
         b.li = ldTile(io.fac, oLi, io.sFac(k));
-        b.as = io.sv.ld(oCol, io.sSv(k));
         b.nt = loadNtRaw<P>(io, oNt, ks);
         b.tit = ldTile(io.fac, oTit, io.sFac(ks));
         b.ti = ldTile(io.fac, oTi, io.sFac(ks));
         b.y = ldTile(io.fac, oY, io.sFac(ks));
-        b.cs = io.sv.ld(oCol, io.sSv(ks) + NRHS_MAX * 16 * 8);
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+        {
+            b.as[q] = io.sv.ld(vc.colL[q], io.sSv(k));
+            b.cs[q] = io.sv.ld(vc.colL[q], io.sSv(ks) + NRHS_MAX * 16 * 8);
+        }
         return b;
     };
-    double x = 0.;
-    auto stage = [&](int k, const BwdVIn &cur) {
+    double x[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        x[q] = 0.;
+    auto stage = [&](int k, const BwdVIn<NC> &cur) {
         if (k == K - 1)
-            x = mv(cur.li, cur.as); // Li' a
+        {
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+                x[q] = mv(cur.li, cur.as[q]); // Li' a
+        }
         else
         {
-            const double t = mv(cur.tit, mv(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x)) - cur.cs; // Ti (N x') - c
-            const double lam = mv(cur.ti, t);                                                                  // Ti' t
-            const double s = cur.as - mv(cur.y, lam);                                                          // a - Yt lam
-            x = mv(cur.li, s);
-            io.sx.st(oSolL, io.sX(k), lam);
+            const Tile Ntfin = finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane);
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+            {
+                const double t = mv(cur.tit, mv(Ntfin, x[q])) - cur.cs[q]; // Ti (N x') - c
+                const double lam = mv(cur.ti, t);                          // Ti' t
+                const double s = cur.as[q] - mv(cur.y, lam);               // a - Yt lam
+                x[q] = mv(cur.li, s);
+                io.sx.st(vc.solL[q], io.sX(k), lam);
+            }
         }
-        io.sx.st(oSolW, io.sX(k), x);
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+            io.sx.st(vc.solW[q], io.sX(k), x[q]);
     };
     auto clampK = [&](int k) { return k > 0 ? k : 0; };
-#if SWEEPV_PREFETCH == 3
-    BwdVIn b0 = load(K - 1), b1 = load(clampK(K - 2)), b2 = load(clampK(K - 3)), b3;
-    for (int k = K - 1; k >= 0; k -= 4)
-    {
-        b3 = load(clampK(k - 3));
-        LOADS_ISSUED();
-        stage(k, b0);
-        if (k - 1 < 0)
-            break;
-        b0 = load(clampK(k - 4));
-        LOADS_ISSUED();
-        stage(k - 1, b1);
-        if (k - 2 < 0)
-            break;
-        b1 = load(clampK(k - 5));
-        LOADS_ISSUED();
-        stage(k - 2, b2);
-        if (k - 3 < 0)
-            break;
-        b2 = load(clampK(k - 6));
-        LOADS_ISSUED();
-        stage(k - 3, b3);
-    }
-#else
-    BwdVIn b0 = load(K - 1), b1 = load(clampK(K - 2)), b2;
+    BwdVIn<NC> b0 = load(K - 1), b1 = load(clampK(K - 2)), b2;
     for (int k = K - 1; k >= 0; k -= 3)
     {
         b2 = load(clampK(k - 2));
@@ -1060,36 +1091,47 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         LOADS_ISSUED();
         stage(k - 2, b2);
     }
-#endif
     WAVE_SYNC();
 }
 #ifndef SWEEPS_VECTOR
-#define SWEEPS_VECTOR 1 // single-column substitution sweeps on v_mfma_f64_4x4x4_4b_f64 (0: the 16-wide tile sweeps for every column count)
+#define SWEEPS_VECTOR 1 // substitution sweeps on v_mfma_f64_4x4x4_4b_f64, one or two columns (0: the 16-wide tile sweeps for every column count)
 #endif
 // the sweep for a right-hand-side specification
 template <class P>
 __device__ inline void factorSweepAny(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &sp)
 {
-    if (SWEEPS_VECTOR && sp.n == 1)
-        factorSweepFused<P, true>(cin, sh, sp);
+#if SWEEPS_VECTOR
+    if (sp.n == 1)
+        factorSweepFused<P, 1>(cin, sh, sp);
     else
-        factorSweepFused<P, false>(cin, sh, sp);
+        factorSweepFused<P, 2>(cin, sh, sp);
+#else
+    factorSweepFused<P, 0>(cin, sh, sp);
+#endif
 }
 template <class P>
 __device__ inline void fwdSweepAny(const LDSP Ctx *cin, const RhsSpec &sp)
 {
-    if (SWEEPS_VECTOR && sp.n == 1)
-        fwdSweepV<P>(cin);
+#if SWEEPS_VECTOR
+    if (sp.n == 1)
+        fwdSweepV<P, 1>(cin);
     else
-        fwdSweep<P>(cin, sp);
+        fwdSweepV<P, 2>(cin);
+#else
+    fwdSweep<P>(cin, sp);
+#endif
 }
 template <class P>
 __device__ inline void bwdSweepAny(const LDSP Ctx *cin, const RhsSpec &sp)
 {
-    if (SWEEPS_VECTOR && sp.n == 1)
-        bwdSweepV<P>(cin);
+#if SWEEPS_VECTOR
+    if (sp.n == 1)
+        bwdSweepV<P, 1>(cin);
     else
-        bwdSweep<P>(cin, sp);
+        bwdSweepV<P, 2>(cin);
+#else
+    bwdSweep<P>(cin, sp);
+#endif
 }
 
 } // namespace ipm

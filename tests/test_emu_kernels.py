@@ -605,8 +605,9 @@ def test_emu_scvx_zero_order_hold(oracle, emu_lib, tmp_path):
 
 
 def test_emu_round4_fast_paths_are_bitwise_the_reference_structure(emu_lib, tmp_path):
-    """Three round-4 changes of ipm_kernel claim BITWISE identical results: the single-column sweeps on the 4 x 4 x 4 matrix instruction
-    (SWEEPS_VECTOR: matrix x vector instead of X'Y on 16-wide tiles), the pivots read off the final diagonal (INVCHOL_PIVOTS_AT_END) and the
+    """Three round-4 changes of ipm_kernel claim BITWISE identical results: the substitution sweeps on the 4 x 4 x 4 matrix instruction
+    (SWEEPS_VECTOR: matrix x vector per right-hand-side column instead of X'Y on 16-wide tiles -- one column in the SCvx mode, [sigma border |
+    column] in the SC mode), the pivots read off the final diagonal (INVCHOL_PIVOTS_AT_END) and the
     speculative floor-free elimination with its floored repeat (INVCHOL_SPECULATE: the repeat is the RARE path -- 8 of 8076 eliminations of
     the SC run below, 19 of 26766 overall, counted with an instrumented build -- and this test is what exercises it against the
     always-floored elimination).  The kernel sources are compiled once more with the three switches off (the round-3 structure of those
@@ -627,6 +628,7 @@ def test_emu_round4_fast_paths_are_bitwise_the_reference_structure(emu_lib, tmp_
     for lib in (emu_lib, ref):
         o = []
         a = scpp_amd.SCAlgorithm(m, K=10, batch_max=3, library=lib).initialize(); a.solve(x0); o.append(a.getSolution()); a.ctx.close()
+        a2 = scpp_amd.SCAlgorithm(m2, K=7, batch_max=2, library=lib).initialize(); a2.solve(x2); o.append(a2.getSolution()); a2.ctx.close()
         v = scpp_amd.SCvxAlgorithm(m, K=12, batch_max=3, library=lib, max_iterations=8).initialize(); v.solve(x0); o.append(v.getSolution()); v.ctx.close()
         v2 = scpp_amd.SCvxAlgorithm(m2, K=8, batch_max=2, library=lib, max_iterations=5).initialize(); v2.solve(x2); o.append(v2.getSolution()); v2.ctx.close()
         outs.append(o)
