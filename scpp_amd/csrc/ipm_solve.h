@@ -2163,7 +2163,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
     __shared__ TileShared sh;
 #ifdef IPM_PROFILE
     if (threadIdx.x == 0)
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 10; i++)
             sh.prof[i] = 0.;
 #endif
     const int K = a.K, lane = threadIdx.x, k = lane;
@@ -2397,7 +2397,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         prof[11] = double(clock64() - t_kernel0);
         for (int i = 0; i < 12; i++)
             d[8 + i] = prof[i];
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 10; i++)
             d[20 + i] = sh.prof[i];
     }
 #endif

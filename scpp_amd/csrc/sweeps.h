@@ -561,7 +561,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     o.yt = offYt<NL>(lane, L::FAC_YT);
     o.einv = i < NL ? (L::X_EINV + i) * 8 : VO_OOB;
 #ifdef IPM_PROFILE
-    double pf0 = 0., pf1 = 0., pfA = 0., pfC = 0.;
+    double pf0 = 0., pf1 = 0., pfA = 0., pfC = 0., pfT = 0., pfL = 0., pfH = 0., pfZ = 0.;
     const long long tfs = clock64();
     long long tstage = tfs;
 #endif
@@ -614,12 +614,21 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         }
         nxt = loadEarly(kn);
         LOADS_ISSUED();
+#ifdef IPM_PROFILE
+        const long long tfl = clock64();
+        pfL += double(tfl - tstage); // (tstage was advanced to the end of the previous stage's tail below)
+#endif
         Tile Phi = buildHTile<P>(cur.h, hl, k, K, lane, scvx);
+#ifdef IPM_PROFILE
+        const long long tfh = clock64();
+        pfH += double(tfh - tfl);
+#endif
         if (k > 0)
             Phi = tileAdd(Phi, mm(Z, Z));
 #ifdef IPM_PROFILE
         const long long tf0 = clock64();
-        pfA += double(tf0 - tstage); // stage head: loads issued, H tile, Z'Z
+        pfZ += double(tf0 - tfh);
+        pfA += double(tf0 - tstage); // stage head: loads issued, H tile, Z'Z (+ pfT: the tail of the previous stage)
 #endif
 #if INVCHOL_TRANSPOSED
         const Tile Lit = invCholFactorT<NV>(Phi, lane);
@@ -705,6 +714,14 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
             stTile(io.sv, o.cols, io.sSv(k) + NRHS_MAX * 16 * 8, cc);
             G = tileAdd(crwn, mm(Z, cc));
         }
+#ifdef IPM_PROFILE
+        {
+            const long long tft = clock64();
+            pfT += double(tft - tstage); // tail: store Ti, transpose, Z, forward pass of the columns
+            pfA += double(tft - tstage);
+            tstage = tft;
+        }
+#endif
         return true;
     };
     Early e0 = loadEarly(0), e1;
@@ -722,6 +739,10 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         sh.prof[1] += pf1;
         sh.prof[4] += pfA;
         sh.prof[5] += pfC;
+        sh.prof[6] += pfT;
+        sh.prof[7] += pfL;
+        sh.prof[8] += pfH;
+        sh.prof[9] += pfZ;
         sh.prof[2] += double(clock64() - tfs);
         sh.prof[3] += 1.;
     }

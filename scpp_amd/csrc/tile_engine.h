@@ -118,7 +118,8 @@ struct TileShared
 #endif
     double tr[16 * 17]; // transpose scratch
 #ifdef IPM_PROFILE
-    double prof[6]; // factor sweep: cycles in the two eliminations, whole sweep, calls, stage head, between the eliminations
+    double prof[10]; // factor sweep: cycles in the two eliminations, whole sweep, calls, stage head, between the eliminations; the stage head split:
+                     // tail of the previous stage (after the second elimination), issuing the loads, H tile, Z'Z
 #endif
 };
 

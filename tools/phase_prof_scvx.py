@@ -17,8 +17,10 @@ p = info[:, 8:20].mean(axis=0)
 print(f"SCvx B={B} mean ipm iters of the last solve {it:.1f}")
 for n, v in zip(names, p):
     print(f"  {n:22s} total {v:14.0f}   per-iter {v / it:12.0f}   share {100 * v / p[11]:5.1f}%")
-f = info[:, 20:26].mean(axis=0)
+f = info[:, 20:30].mean(axis=0)
 if f[3] > 0:
     print(f"  factor sweep detail (per call, {f[3]:.1f} calls): elimination<16> {f[0] / f[3]:.0f}  elimination<NL> {f[1] / f[3]:.0f}  whole sweep {f[2] / f[3]:.0f}"
           f"  -> eliminations {100 * (f[0] + f[1]) / f[2]:.1f}% of the sweep;"
           f" stage head (loads, H tile, Z'Z) {f[4] / f[3]:.0f}  between the eliminations {f[5] / f[3]:.0f}  tail {(f[2] - f[0] - f[1] - f[4] - f[5]) / f[3]:.0f}")
+    print(f"  stage head split (per call): tail of the previous stage (store Ti, transpose, Z, forward pass) {f[6] / f[3]:.0f}  loads issued {f[7] / f[3]:.0f}"
+          f"  H tile {f[8] / f[3]:.0f}  Z'Z + add {f[9] / f[3]:.0f}")
