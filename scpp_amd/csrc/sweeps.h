@@ -969,9 +969,9 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    const VCols<P, NC> vc(lane);
     const Off4 oLit = offTriT<NV>(lane, L::FAC_LI), oYt = offYt<NL>(lane, L::FAC_YT), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oN = offN<P>(lane);
+    const VCols<P, NC> vc(lane);
     auto load = [&](int k) {
         const int ks = k < K - 1 ? k : K - 2; // the last stage has no segment: it re-reads segment K-2 (in range, unused)
         FwdVIn<NC> f;
@@ -1002,14 +1002,13 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         }
         if (k == K - 1)
             return false;
-        const Tile Nfin = finishN<P>(cur.n, L::fixedMask(k + 1, K), lane);
 #pragma unroll
         for (int q = 0; q < NC; q++)
         {
             const double gl = VCols<P, NC>::rlSign(q, cur.rl[q]) - mv(cur.yt, a[q]); // rho - Yt' a
             const double cc = mv(cur.tit, gl);                                       // Ti gl
             io.sv.st(vc.colS[q], io.sSv(k) + NRHS_MAX * 16 * 8, cc);
-            G[q] = cur.rwn[q] + mv(Nfin, mv(cur.ti, cc)); // beta' + N' (Ti' c)
+            G[q] = cur.rwn[q] + mv(finishN<P>(cur.n, L::fixedMask(k + 1, K), lane), mv(cur.ti, cc)); // beta' + N' (Ti' c)
         }
         return true;
     };
@@ -1047,23 +1046,23 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    const VCols<P, NC> vc(lane);
     const Off4 oLi = offTri<NV>(lane, L::FAC_LI), oNt = offNt<P>(lane), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oY = offYtT<NL>(lane, L::FAC_YT);
+    const VCols<P, NC> vc(lane);
     auto load = [&](int k) {
         const int ks = k < K - 1 ? k : K - 2;
         BwdVIn<NC> b;
         b.li = ldTile(io.fac, oLi, io.sFac(k));
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+            b.as[q] = io.sv.ld(vc.colL[q], io.sSv(k));
         b.nt = loadNtRaw<P>(io, oNt, ks);
         b.tit = ldTile(io.fac, oTit, io.sFac(ks));
         b.ti = ldTile(io.fac, oTi, io.sFac(ks));
         b.y = ldTile(io.fac, oY, io.sFac(ks));
 #pragma unroll
         for (int q = 0; q < NC; q++)
-        {
-            b.as[q] = io.sv.ld(vc.colL[q], io.sSv(k));
             b.cs[q] = io.sv.ld(vc.colL[q], io.sSv(ks) + NRHS_MAX * 16 * 8);
-        }
         return b;
     };
     double x[NC];
@@ -1079,11 +1078,10 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         }
         else
         {
-            const Tile Ntfin = finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane);
 #pragma unroll
             for (int q = 0; q < NC; q++)
             {
-                const double t = mv(cur.tit, mv(Ntfin, x[q])) - cur.cs[q]; // Ti (N x') - c
+                const double t = mv(cur.tit, mv(finishNt<P>(cur.nt, L::fixedMask(k + 1, K), lane), x[q])) - cur.cs[q]; // Ti (N x') - c
                 const double lam = mv(cur.ti, t);                          // Ti' t
                 const double s = cur.as[q] - mv(cur.y, lam);               // a - Yt lam
                 x[q] = mv(cur.li, s);
