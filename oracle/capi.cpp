@@ -656,6 +656,18 @@ int oracle_scvx_set_max_iterations(void *h, int n)
         return 0;
     });
 }
+// test support (scvx.hpp: solve_cap): retire an instance like the device engine does; 0 = the reference's behaviour
+int oracle_scvx_set_solve_cap(void *h, int cap)
+{
+    return withScvx(h, [&](auto &a) {
+        a.solve_cap = size_t(cap > 0 ? cap : 0);
+        return 0;
+    });
+}
+int oracle_scvx_retired(void *h)
+{
+    return withScvx(h, [&](auto &a) { return a.retired ? 1 : 0; });
+}
 int oracle_scvx_solve(void *h, int warm_start)
 {
     try

@@ -147,6 +147,13 @@ class SCvxAlgorithm
     double last_nonlinear_cost = 0.;
     bool converged = false, solver_failed = false;
     int iterations = 0, solves = 0;
+    // Test support, NOT the reference: SCvxAlgorithm::iterate's `while (true)` (SCvxAlgorithm.cpp:75-153) leaves only through an accepted
+    // candidate, and with the shipped Rocket2D SCvx.info some start states are rejected indefinitely.  The device engine retires such an
+    // instance on a rejection once it has used solve_cap x max_iterations sub-problem solves (csrc/scvx_kernels.h: SCVX_SOLVE_CAP = 64,
+    // status SCPP_STATUS_REJECTION_CAP, last accepted iterate kept); with solve_cap > 0 this restatement does the same so that the two can
+    // be compared at the cap.  0 (default) = the reference's behaviour: no exit.
+    size_t solve_cap = 0;
+    bool retired = false;
 
     SCvxAlgorithm(Model *m, const std::string &folder, int K_over = 0) : model(m), param_folder(folder), K_override(K_over)
     {
@@ -331,6 +338,11 @@ class SCvxAlgorithm
                 trust_region /= alpha;
                 td = old_td;
                 info.push_back({norm1_nu, nonlinear_cost, actual_change, predicted_change, rho, trust_region, 0, ipm_iters, exitflag});
+                if (solve_cap && size_t(solves) >= solve_cap * max_iterations)
+                {
+                    retired = true; // (build-defined, see solve_cap)
+                    return false;
+                }
             }
             else
             {
@@ -366,13 +378,14 @@ class SCvxAlgorithm
         all_td.push_back(td);
         converged = false;
         solver_failed = false;
-        while (iteration < max_iterations && !converged && !solver_failed)
+        retired = false;
+        while (iteration < max_iterations && !converged && !solver_failed && !retired)
         {
             iteration++;
             converged = iterate();
             all_td.push_back(td);
         }
-        iterations = int(iteration);
+        iterations = int(iteration); // (a retired instance reports the iteration it was retired in, like the device's sc_iters)
         if (nondimensionalize)
         {
             model->redimensionalize();

@@ -9,6 +9,8 @@ from ._lib import (  # noqa: F401
     MODEL_ROCKETQUAT,
     MODE_FOH,
     MODE_VT,
+    STATUS_REJECTION_CAP,
+    SCVX_SOLVE_CAP,
     RocketQuatParams,
     SCOpts,
     SocpOpts,

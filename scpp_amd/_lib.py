@@ -6,6 +6,10 @@ import numpy as np
 
 MODEL_ROCKETQUAT, MODEL_ROCKET2D = 0, 1
 MODE_FOH, MODE_VT = 1, 2
+# include/scpp_hip.h: return codes, and the per-instance status of an SCvx run retired in the reference's exit-less reject loop
+E_ARG, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4
+STATUS_REJECTION_CAP = -5
+SCVX_SOLVE_CAP = 64  # csrc/scvx_kernels.h: sub-problem solves per configured iteration before an instance is retired
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

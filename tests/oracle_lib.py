@@ -288,6 +288,13 @@ class SCvx:
     def set_max_iterations(self, n):
         lib().oracle_scvx_set_max_iterations(self.h, int(n))
 
+    def set_solve_cap(self, cap):
+        """test support (oracle/scvx.hpp: solve_cap): retire on a rejection after cap x max_iterations solves, like the device engine"""
+        lib().oracle_scvx_set_solve_cap(self.h, int(cap))
+
+    def retired(self):
+        return bool(lib().oracle_scvx_retired(self.h))
+
     def solve(self, warm_start=False):
         return lib().oracle_scvx_solve(self.h, int(warm_start))
 

@@ -4,6 +4,7 @@ the context solved before.  Checked bitwise on the CPU wave emulator for the thr
 MPCAlgorithm) by solving a batch, then -- on the SAME context -- a permuted, shorter batch (stale rows of the longer one behind it) and a
 batch of copies of one instance.  (The streaming engine's version of this property is tests/test_emu_stream_fuzz.py.)"""
 import numpy as np
+import pytest
 
 import scpp_amd
 
@@ -18,10 +19,30 @@ def _take(o, idx, keys):
 
 
 def test_emu_sc_rows_do_not_depend_on_batch_composition(model, emu_lib):
+    _sc_case(model, emu_lib, 7, 4)
+
+
+def test_emu_scvx_rows_do_not_depend_on_batch_composition(model, emu_lib):
+    _scvx_case(model, emu_lib, 7, 5)
+
+
+def test_emu_mpc_rows_do_not_depend_on_batch_composition(emu_lib):
+    _mpc_case(emu_lib)
+
+
+@pytest.mark.gpu
+def test_rows_do_not_depend_on_batch_composition_on_gpu(model, hip_lib):
+    """the same three properties on hardware, SC / SCvx at the bench's K = 50"""
+    _sc_case(model, hip_lib, 50, 15)
+    _scvx_case(model, hip_lib, 50, 12)
+    _mpc_case(hip_lib)
+
+
+def _sc_case(model, emu_lib, K, maxit):
     keys = ("X", "U", "sigma", "nu_norm", "sum_delta", "sc_iters", "ipm_iters", "status", "converged")
-    K, B = 7, 6
+    B = 6
     alg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, library=emu_lib).initialize()
-    alg.opts.max_iterations = 4
+    alg.opts.max_iterations = maxit
     x0 = model.randomized_initial_states(B, first=4100)
     alg.solve(x0)
     full = alg.getSolution()
@@ -36,10 +57,10 @@ def test_emu_sc_rows_do_not_depend_on_batch_composition(model, emu_lib):
     alg.ctx.close()
 
 
-def test_emu_scvx_rows_do_not_depend_on_batch_composition(model, emu_lib):
+def _scvx_case(model, emu_lib, K, maxit):
     keys = ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "ipm_iters", "status", "converged")
-    K, B = 7, 6
-    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=5).initialize()
+    B = 6
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
     x0 = model.randomized_initial_states(B, first=5200)
     alg.solve(x0)
     full = alg.getSolution()
@@ -53,7 +74,7 @@ def test_emu_scvx_rows_do_not_depend_on_batch_composition(model, emu_lib):
     alg.ctx.close()
 
 
-def test_emu_mpc_rows_do_not_depend_on_batch_composition(emu_lib):
+def _mpc_case(emu_lib):
     keys = ("X", "U", "iters", "status", "cost")
     m2 = scpp_amd.Rocket2D().loadParameters()
     m2.p.constrain_initial_final = False  # model.info: "enable for SC and disable for MPC/LQR"

@@ -365,19 +365,63 @@ def test_emu_rocket2d_scvx(oracle, emu_lib, tmp_path):
     _rocket2d_scvx_case(oracle, emu_lib, 8, tmp_path, maxit=5)  # (the GPU test runs the shipped K = 30 / 20 iterations)
 
 
-def test_emu_scvx_rejection_loop_cap(emu_lib):
-    """SCvxAlgorithm::iterate's `while (true)` leaves only through an accepted candidate (SCvxAlgorithm.cpp:75-153).  With the
-    shipped Rocket2D SCvx.info (radius 5 in SI units) some start states never get there once the radius has collapsed; the
-    batched engine retires such an instance after 64 x max_iterations sub-problem solves with status SCPP_STATUS_REJECTION_CAP
-    (-4) instead of spinning, keeps its last accepted iterate, and the streaming engine still hands back every row."""
-    m2 = scpp_amd.Rocket2D().loadParameters()
-    x0 = m2.randomized_initial_states(2, first=1)
-    alg = scpp_amd.SCvxAlgorithm(m2, K=8, batch_max=2, library=emu_lib, max_iterations=1).initialize()
-    n = alg.solveStream(x0, slots=2, pools=1)
-    o = alg.getStreamSolution()
-    assert (o["instance"] == np.arange(2)).all() and n == 0
-    assert (o["solves"] <= 64 * 1 + 1).all() and (o["status"] <= 0).all()
+def _rejection_cap_case(oracle, lib, tmp_path, name, K):
+    """SCvxAlgorithm::iterate's `while (true)` leaves only through an accepted candidate (SCvxAlgorithm.cpp:75-153); with the shipped
+    Rocket2D SCvx.info some start states are rejected indefinitely at K = 30 once the radius has collapsed.  The batched
+    engine retires such an instance ON A REJECTION once it has used 64 x max_iterations sub-problem solves: status
+    SCPP_STATUS_REJECTION_CAP (-5, distinct from every return code), last ACCEPTED iterate kept, the row still delivered by both entry
+    points.  Made deterministic and cheap here: `rho_0 1e9` rejects every candidate, `alpha 1` keeps the radius (the re-solve returns the
+    same candidate again) -- iteration 1 is accepted unconditionally (SCvxAlgorithm.cpp:109-113), iteration 2 spins.  The oracle with
+    its test-support cap (oracle/scvx.hpp: solve_cap) must retire at the same solve count with the same iterate."""
+    import os
+    import shutil
+
+    cfg = tmp_path / ("config_" + name)
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    p = cfg / name / "SCvx.info"
+    t = p.read_text()
+    assert "rho_0                               0.0" in t and "alpha                               2.0" in t
+    p.write_text(t.replace("rho_0                               0.0", "rho_0                               1e9")
+                  .replace("alpha                               2.0", "alpha                               1.0"))
+    m = (scpp_amd.RocketQuat if name == "RocketQuat" else scpp_amd.Rocket2D)(str(cfg)).loadParameters()
+    maxit, cap = 2, scpp_amd.SCVX_SOLVE_CAP
+    x0 = m.randomized_initial_states(2, first=7)
+    alg = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=2, library=lib, max_iterations=maxit).initialize()
+    assert alg.solve(x0) == 0
+    o = alg.getSolution()
+    assert (o["status"] == scpp_amd.STATUS_REJECTION_CAP).all() and scpp_amd.STATUS_REJECTION_CAP == -5
+    assert (o["solves"] == cap * maxit).all() and (o["sc_iters"] == 2).all() and (o["converged"] == 0).all()  # retired IN iteration 2
+    # the streaming engine hands back the same rows (one slot: the second instance enters after the first was retired)
+    for slots, pools in (((1, 1), (2, 2)) if name == "Rocket2D" else ((2, 2),)):
+        assert alg.solveStream(x0, slots=slots, pools=pools) == 0
+        so = alg.getStreamSolution()
+        for key in ("X", "U", "sigma", "nu_norm", "trust_region", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+            assert np.array_equal(so[key], o[key]), (name, slots, key)
+    # last accepted iterate = the result of iteration 1: the same run stopped after one iteration
+    one = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=2, library=lib, max_iterations=1).initialize()
+    one.solve(x0)
+    o1 = one.getSolution()
+    assert (o1["status"] == 0).all() and (o1["solves"] == 1).all()
+    assert np.array_equal(o1["X"], o["X"]) and np.array_equal(o1["U"], o["U"])
+    one.ctx.close()
     alg.ctx.close()
+    # the oracle retires at the same point
+    s = oracle.SCvx(K=K, model=oracle.ROCKETQUAT if name == "RocketQuat" else oracle.ROCKET2D, config_root=str(cfg))
+    s.set_solver(1 if name == "RocketQuat" else 0); s.set_max_iterations(maxit); s.set_solve_cap(cap); s.set_x_init(x0[0])
+    assert s.solve() == 0 and s.retired()
+    mm = s.meta()
+    assert mm["solves"] == cap * maxit and mm["iterations"] == 2 and mm["converged"] == 0
+    Xo, Uo, _ = s.iterate(-1)
+    X1, U1, _ = s.iterate(1)
+    X2, U2, _ = s.iterate(mm["n_all_td"] - 1)  # (stored iterates are in the solver's units, the final one is dimensional)
+    assert mm["n_all_td"] == 3 and np.array_equal(X2, X1) and np.array_equal(U2, U1)  # td = old_td on every rejection: iteration 1's iterate is left
+    if name == "RocketQuat":  # structured twin: the same iterate (two different solvers' Rocket2D optima in SI units are 3e-3 apart, DESIGN.md 6)
+        assert np.abs(Xo - o["X"][0]).max() <= 1e-5 * np.abs(Xo).max() and np.abs(Uo - o["U"][0][: Uo.shape[0]]).max() <= 1e-5 * np.abs(Uo).max()
+
+
+def test_emu_scvx_rejection_loop_cap(oracle, emu_lib, tmp_path):
+    _rejection_cap_case(oracle, emu_lib, tmp_path, "Rocket2D", 6)
+    _rejection_cap_case(oracle, emu_lib, tmp_path, "RocketQuat", 5)
 
 
 def _sc_variant_case(oracle, lib, tmp_path, KQ, K2, variant):

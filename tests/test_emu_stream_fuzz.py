@@ -33,26 +33,42 @@ def _config(tmp_path, hold_foh):
     return str(cfg)
 
 
-def _cases(n, seed):
+def _cases(n, seed, big=False):
     rng = np.random.default_rng(seed)
     out = []
     for i in range(n):
         model = ("RocketQuat", "Rocket2D")[int(rng.integers(2))]
         foh = bool(rng.integers(2))
-        K = int(rng.integers(5, 10))
-        N = int(rng.integers(2, 10))
-        slots = int(rng.integers(1, N + 3))
+        K = int(rng.integers(10, 51)) if big else int(rng.integers(5, 10))
+        N = int(rng.integers(20, 200)) if big else int(rng.integers(2, 10))
+        slots = int(rng.integers(8, N + 10)) if big else int(rng.integers(1, N + 3))
         pools = int(rng.integers(1, 5))
-        maxit = int(rng.integers(3, 7))
+        maxit = int(rng.integers(3, 9)) if big else int(rng.integers(3, 7))
         out.append((i, model, foh, K, N, slots, pools, maxit))
+    if big:
+        return out
     # hand-picked corners: one slot; as many pools as slots; slots beyond the instance count; a single instance through several pools
     out += [(n, "Rocket2D", True, 6, 5, 1, 1, 4), (n + 1, "RocketQuat", False, 5, 7, 3, 3, 3), (n + 2, "Rocket2D", False, 7, 3, 9, 4, 5),
             (n + 3, "RocketQuat", True, 6, 1, 4, 3, 4)]
     return out
 
 
-@pytest.mark.parametrize("case", _cases(8, 20260928), ids=lambda c: "%d-%s-%s-K%d-N%d-s%d-p%d-it%d" % (c[0], c[1], "foh" if c[2] else "zoh", *c[3:]))
+_ID = lambda c: "%d-%s-%s-K%d-N%d-s%d-p%d-it%d" % (c[0], c[1], "foh" if c[2] else "zoh", *c[3:])  # noqa: E731
+
+
+@pytest.mark.parametrize("case", _cases(8, 20260928), ids=_ID)
 def test_emu_stream_equals_batch_on_random_configurations(emu_lib, tmp_path, case):
+    _stream_case(emu_lib, tmp_path, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases(10, 20260929, big=True), ids=_ID)
+def test_stream_equals_batch_on_random_configurations_on_gpu(hip_lib, tmp_path, case):
+    """the same property on hardware at K up to 50, 20 .. 200 instances through 8 .. N + 10 slots in 1 .. 4 pools"""
+    _stream_case(hip_lib, tmp_path, case)
+
+
+def _stream_case(emu_lib, tmp_path, case):
     i, model, foh, K, N, slots, pools, maxit = case
     cfg = _config(tmp_path, foh)
     m = (scpp_amd.RocketQuat if model == "RocketQuat" else scpp_amd.Rocket2D)(cfg).loadParameters()

@@ -873,3 +873,14 @@ def test_sc_variants_on_gpu(oracle, hip_lib, tmp_path):
     for variant in ("fixed_time", "zoh"):
         r = _sc_variant_case(oracle, hip_lib, tmp_path / variant, 50, 30, variant)
         print("SC variant %s vs the literal run: " % variant + ", ".join("%s rel dX %.1e rel dU %.1e" % (k, v[0], v[1]) for k, v in r.items()))
+
+
+@pytest.mark.gpu
+def test_scvx_rejection_loop_cap_on_gpu(oracle, hip_lib, tmp_path):
+    """The reference's exit-less reject loop (SCvxAlgorithm.cpp:75-153) forced deterministically: status SCPP_STATUS_REJECTION_CAP after
+    64 x max_iterations solves, last accepted iterate kept, same rows from the streaming engine, same retirement point as the oracle with
+    its test-support cap -- the emulator case (tests/test_emu_kernels.py::_rejection_cap_case) on hardware, at the bench's K for RocketQuat."""
+    from test_emu_kernels import _rejection_cap_case
+
+    _rejection_cap_case(oracle, hip_lib, tmp_path, "Rocket2D", 30)
+    _rejection_cap_case(oracle, hip_lib, tmp_path, "RocketQuat", 50)
