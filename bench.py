@@ -324,7 +324,7 @@ def main():
             np.save(args.dump, gathered.cpu().numpy() if gathered is not None else ctx.stream_download_rows())
 
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # (single-GPU runs only: at N > 1 the other ranks would idle behind these legs)
         # ---- un-overlapped kernel times: the same engine with ONE slot pool (one stream), a 2-batch job ----
         try:
             ctx.timing(reset=True)
@@ -566,7 +566,7 @@ def main():
                 },
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(K, args.seed)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
