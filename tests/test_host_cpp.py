@@ -14,6 +14,9 @@ HOST = os.path.join(ROOT, "scpp_amd", "host")
 CONFIG = os.path.join(ROOT, "scpp_amd", "config")
 
 
+pytestmark = pytest.mark.xdist_group("host_cpp")  # one build directory (`make -C scpp_amd/host emu`): keep the module on one worker
+
+
 @pytest.fixture(scope="module")
 def host_emu(emu_lib):
     subprocess.check_call(["make", "-s", "-C", HOST, "emu"])
