@@ -161,3 +161,96 @@ def test_device_path_against_the_cutting_plane_optimum_emulated(cuts, emu_lib):
 def test_device_path_against_the_cutting_plane_optimum_on_gpu(cuts, hip_lib, Kn):
     r = _device_cuts(cuts, hip_lib, Kn)
     print("K = %d first sub-problems vs the cutting-plane optimum (HiGHS): relative objective difference SC %.1e, SCvx %.1e" % ((Kn,) + r))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The second model.  tests/golden/rocket2d_subproblem_cuts.npz: the first SC sub-problem of the shipped Rocket2D scenario at K = 25 (the
+# reference's SC.info) and K = 30 (this repository's), and the first SCvx sub-problem at K = 30 in SI units (as shipped) and
+# nondimensionalised, from the same cutting planes over HiGHS on an independent restatement of rocket2d.cpp / SCProblem.cpp /
+# SCvxProblem.cpp (generate_rocket2d_cut_goldens.py: numpy / sympy / DOP853, nothing of oracle/, scpp_amd or the HIP library).  The
+# oracle's literal solver (the only one it has for this model) and the device path must reproduce the optimal OBJECTIVE to 2e-6.
+# ---------------------------------------------------------------------------------------------------------------------
+R2D_W_T, R2D_W_TRT, R2D_W_TRX, R2D_W_VC = 1.0, 1.0, 1.0, 1000.0  # Rocket2D/SC.info
+
+
+@pytest.fixture(scope="module")
+def cuts2d():
+    g = np.load(os.path.join(GOLDEN, "rocket2d_subproblem_cuts.npz"))
+    for name in ("sc_K25", "sc_K30", "scvx_K30_si", "scvx_K30_nd"):
+        assert g[name + "_violations"].max() <= 1e-9
+    return g
+
+
+def _r2d_config(tmp_path, nondim_scvx):
+    import shutil
+
+    cfg = tmp_path / ("config_nd" if nondim_scvx else "config_si")
+    if not cfg.exists():
+        shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+        p = cfg / "Rocket2D" / "SCvx.info"
+        t = p.read_text()
+        assert "nondimensionalize                   false" in t
+        if nondim_scvx:
+            p.write_text(t.replace("nondimensionalize                   false", "nondimensionalize                   true"))
+    return str(cfg)
+
+
+def _r2d_sc_objective(sigma, sigma_bar, norm1_nu, sum_delta):
+    return R2D_W_T * sigma + R2D_W_VC * norm1_nu + R2D_W_TRT * (sigma - sigma_bar) ** 2 + R2D_W_TRX * sum_delta
+
+
+@pytest.mark.parametrize("Kn", [25, 30])
+def test_rocket2d_oracle_sc_against_the_cutting_plane_optimum(oracle, cuts2d, Kn):
+    s = oracle.SC(oracle.ROCKET2D, K=Kn); s.set_solver(0); s.set_tolerances(1e-10, 1e-10, 1e-10, 200); s.solve()
+    _, _, t0 = s.iterate(0)
+    _, _, t1 = s.iterate(1)
+    inf = s.info()[0]
+    obj, ref = _r2d_sc_objective(t1, t0, inf[0], inf[1]), float(cuts2d["sc_K%d_objective" % Kn])
+    assert t0 == float(cuts2d["sc_K%d_sigma_bar" % Kn]) and abs(obj - ref) <= 2e-6 * ref, ("Rocket2D SC", Kn, obj, ref)
+    assert abs(t1 - float(cuts2d["sc_K%d_sigma" % Kn])) <= 1e-4
+
+
+@pytest.mark.parametrize("name,nondim", [("scvx_K30_si", False), ("scvx_K30_nd", True)])
+def test_rocket2d_oracle_scvx_against_the_cutting_plane_optimum(oracle, cuts2d, tmp_path, name, nondim):
+    v = oracle.SCvx(K=30, model=oracle.ROCKET2D, config_root=_r2d_config(tmp_path, nondim)); v.set_solver(0)
+    v.set_tolerances(1e-10, 1e-10, 1e-10, 200); v.set_max_iterations(1)
+    assert v.solve() == 0
+    obj, ref = R2D_W_VC * v.info()[0][0], float(cuts2d[name + "_objective"])
+    assert abs(obj - ref) <= 2e-6 * ref, ("Rocket2D SCvx", name, obj, ref)
+
+
+def _r2d_device_cuts(cuts2d, lib, tmp_path):
+    out = {}
+    for Kn in (25, 30):
+        m = scpp_amd.Rocket2D().loadParameters()
+        alg = scpp_amd.SCAlgorithm(m, K=Kn, batch_max=1, library=lib).initialize()
+        alg.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+        alg.ctx.sc_setup(m.sc_params(), alg.opts, m.x_init[None])
+        alg.ctx.sc_iterate()
+        o = alg.ctx.download()
+        obj = _r2d_sc_objective(float(o["sigma"][0]), float(cuts2d["sc_K%d_sigma_bar" % Kn]), float(o["nu_norm"][0]), float(o["sum_delta"][0]))
+        ref = float(cuts2d["sc_K%d_objective" % Kn])
+        assert o["status"][0] == 0 and abs(obj - ref) <= 2e-6 * ref, ("device Rocket2D SC", Kn, obj, ref)
+        out["sc_K%d" % Kn] = abs(obj - ref) / ref
+        alg.ctx.close()
+    for name, nondim in (("scvx_K30_si", False), ("scvx_K30_nd", True)):
+        m = scpp_amd.Rocket2D(_r2d_config(tmp_path, nondim)).loadParameters()
+        v = scpp_amd.SCvxAlgorithm(m, K=30, batch_max=1, library=lib, max_iterations=1).initialize()
+        v.ctx.set_socp_opts(1e-10, 1e-10, 1e-10, 200)
+        v.solve(m.x_init[None])
+        ov = v.getSolution()
+        obj, ref = R2D_W_VC * float(ov["nu_norm"][0]), float(cuts2d[name + "_objective"])
+        assert ov["status"][0] == 0 and abs(obj - ref) <= 2e-6 * ref, ("device Rocket2D SCvx", name, obj, ref)
+        out[name] = abs(obj - ref) / ref
+        v.ctx.close()
+    return out
+
+
+def test_rocket2d_device_path_against_the_cutting_plane_optimum_emulated(cuts2d, emu_lib, tmp_path):
+    _r2d_device_cuts(cuts2d, emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_rocket2d_device_path_against_the_cutting_plane_optimum_on_gpu(cuts2d, hip_lib, tmp_path):
+    r = _r2d_device_cuts(cuts2d, hip_lib, tmp_path)
+    print("Rocket2D first sub-problems vs the cutting-plane optimum (HiGHS): relative objective differences", {k: "%.1e" % v for k, v in r.items()})
