@@ -82,8 +82,13 @@ def solve_cuts(pb, tol=1e-10, max_rounds=400, verbose=True):
     for rnd in range(1, max_rounds + 1):
         A_ub = sp.vstack([Gl, sp.csr_matrix(np.array(cut_rows))]).tocsr()
         b_ub = np.concatenate([hl, np.array(cut_rhs)])
-        res = linprog(q, A_ub=A_ub, b_ub=b_ub, A_eq=Ae, b_eq=be, bounds=[(None, None)] * n, method="highs-ds",
-                      options=dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10, presolve=True))
+        # (a round on which the dual simplex gives up with these settings -- seen on later sub-problems of a run, "Status 0: Not Set" -- is
+        #  repeated without presolve, then with HiGHS' default tolerances: what is accepted is always an LP optimum of the same relaxation)
+        for opts in (dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10, presolve=True),
+                     dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10, presolve=False), dict(presolve=True), dict(presolve=False)):
+            res = linprog(q, A_ub=A_ub, b_ub=b_ub, A_eq=Ae, b_eq=be, bounds=[(None, None)] * n, method="highs-ds", options=opts)
+            if res.status == 0:
+                break
         assert res.status == 0, res.message
         x = res.x
         worst, added = 0.0, 0

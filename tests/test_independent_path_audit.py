@@ -1,0 +1,129 @@
+"""Sub-problems ALONG the device's own SCvx path against an optimum that owes nothing to this repository's solvers.
+
+tests/test_subproblem_pin.py pins the FIRST sub-problem (linearised at the initial guess).  Here the nominal RocketQuat run of the device
+(CPU wave emulator) is followed for a few iterations; every accepted sub-problem -- linearised at the device's previous iterate, with the
+trust radius the accept / reject history had produced by then (SCvxAlgorithm.cpp:118-152) -- is restated by the independent numpy / sympy /
+DOP853 code of tests/golden/generate_subproblem_goldens.py (no line of oracle/, scpp_amd or the kernels) and solved by Kelley's cutting
+planes over HiGHS (generate_subproblem_cut_goldens.py).  The device's candidate must be a point of that problem (equalities 1e-9, cones and
+rows -1e-9) whose objective w_vc ||nu||_1 -- nu taken as the candidate's defect in the RESTATED linearised dynamics -- is within 5e-5 of the
+LP-based optimum and not below it by more than 1e-6 (the bars of the literal audit, tests/test_gpu_parity.py: BAR_CERT_*).
+What this adds to the literal audit (tests/scvx_audit.py): the checker there is the oracle's own literal solver and discretisation.
+Checked the same way: the nonlinear cost J the device reports for every iterate (SCvxAlgorithm.cpp:262-278: sum over the segments of
+||x_propagated - x_{k+1}||_1) against DOP853 propagation of the restated flow map, and -- on the iterations whose candidate was accepted at
+the first attempt, where the previous J is known -- the device's rho = dJ / dL and its trust-radius update (SCvxAlgorithm.cpp:118-152)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import scpp_amd
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+
+K = 15
+N_IT = 6
+W_VC = 1000.0
+
+
+def _nondim(X, U, ms, rs):
+    X = X.copy(); U = U.copy()
+    X[:, 0] /= ms; X[:, 1:7] /= rs; U[:, :3] /= ms * rs; U[:, 3] /= ms * rs * rs
+    return X, U
+
+
+def _nonlinear_cost(G, sc, X, U, t):
+    """SCvxAlgorithm.cpp:262-278 + simulation.cpp:25-42 with the restated flow map, first-order-hold inputs, DOP853 instead of RKF78"""
+    import sympy as sp
+    from scipy.integrate import solve_ivp
+    from generate_goldens import rocketquat_sym
+
+    x_, u_, p_, f_ = rocketquat_sym()
+    fn = sp.lambdify([x_, u_, p_], f_, "numpy")
+    dt, J = t / (K - 1), 0.0
+    for k in range(K - 1):
+        rhs = lambda tau, x: np.asarray(fn(x, U[k] + tau / dt * (U[k + 1] - U[k]), sc["par"]), dtype=float).ravel()  # noqa: E731
+        xe = solve_ivp(rhs, [0, dt], X[k], method="DOP853", rtol=1e-13, atol=1e-16).y[:, -1]
+        J += np.abs(xe - X[k + 1]).sum()
+    return J
+
+
+def _device_path(alg, x0, n):
+    """iterate j of the nominal run = the run capped at max_iterations = j (deterministic), with what the device reports about it"""
+    path, keep = [], alg._max_iterations
+    try:
+        for j in range(n + 1):
+            alg._max_iterations = j
+            alg.solve(x0)
+            o = alg.getSolution()
+            assert o["status"][0] == 0
+            path.append({k: np.array(o[k][0]).copy() for k in ("X", "U", "trust_region", "solves", "sc_iters", "converged", "nonlinear_cost", "nu_norm", "last_decision")})
+    finally:
+        alg._max_iterations = keep
+    return path
+
+
+def test_emu_scvx_path_sub_problems_against_independent_cutting_planes(emu_lib):
+    _path_audit(emu_lib, N_IT)
+
+
+@pytest.mark.gpu
+def test_scvx_path_sub_problems_against_independent_cutting_planes_on_gpu(hip_lib):
+    _path_audit(hip_lib, 4)
+
+
+def _path_audit(emu_lib, n_it):
+    import generate_subproblem_cut_goldens as C
+    import generate_subproblem_goldens as G
+
+    G.K = K
+    sc = G.scenario()
+    ms, rs = sc["m_scale"], sc["r_scale"]
+    m = scpp_amd.RocketQuat().loadParameters()
+    alg = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=1, library=emu_lib).initialize()
+    o_ = alg.opts
+    alpha, beta, rho_1, rho_2 = float(o_.alpha), float(o_.beta), float(o_.rho_1), float(o_.rho_2)
+    path = _device_path(alg, m.x_init[None], n_it)
+    alg.ctx.close()
+    Xb, Ub = _nondim(path[0]["X"], path[0]["U"], ms, rs)
+    r_prev, solves_prev, J_prev = float(path[0]["trust_region"]), 0, None
+    gaps, rejected, rho_checked = [], 0, 0
+    for j, st in enumerate(path[1:]):
+        n_rej = int(st["solves"] - solves_prev) - 1
+        assert st["sc_iters"] == j + 1 and n_rej >= 0 and st["converged"] == 0
+        rejected += n_rej
+        r_used = r_prev / alpha ** n_rej
+        Xc, Uc = _nondim(st["X"], st["U"], ms, rs)
+        dd = G.discretize(sc, Xb, Ub, sc["final_time"], False)
+        pb = G.SubProblem(sc, Xb, Ub, sc["final_time"], dd, "scvx", dict(vc=W_VC, tr=r_used))
+        _, info = C.solve_cuts(pb, verbose=False)
+        assert max(info["cone_violation"], info["eq_violation"], info["lin_violation"]) <= 1e-9
+        # the device's candidate as a point of the restated problem: nu := its defect in the restated dynamics
+        A, B, Cm, S, Z = dd
+        nu = np.array([Xc[k + 1] - (A[k] @ Xc[k] + B[k] @ Uc[k] + Cm[k] @ Uc[k + 1] + Z[k]) for k in range(K - 1)])
+        v = np.concatenate([Xc.ravel(), Uc.ravel(), np.maximum(nu, 0).ravel(), np.maximum(-nu, 0).ravel()])
+        assert np.abs(pb.eq(v)).max() <= 1e-9, ("equalities", j + 1, float(np.abs(pb.eq(v)).max()))
+        assert pb.ineq(v).min() >= -1e-9, ("rows / cones", j + 1, float(pb.ineq(v).min()))
+        gap = (pb.cost(v) - info["objective"]) / info["objective"]
+        assert -1e-6 <= gap <= 5e-5, ("objective", j + 1, pb.cost(v), info["objective"])
+        gaps.append(gap)
+        # the nonlinear cost of the candidate, and the accept / radius rule where the previous J is known (no rejection in between)
+        J = _nonlinear_cost(G, sc, Xc, Uc, sc["final_time"])
+        L = pb.cost(v) / W_VC
+        assert abs(J - float(st["nonlinear_cost"])) <= 1e-8 * J, ("J", j + 1, J, float(st["nonlinear_cost"]))
+        assert abs(L - float(st["nu_norm"])) <= 1e-6 * L, ("L", j + 1, L, float(st["nu_norm"]))  # (the solver's norm1_nu: tight to its 1e-8 tolerances)
+        rho_dev, dJ_dev, dL_dev, code = [float(x) for x in st["last_decision"]]
+        if j == 0:
+            assert code == 2.0 and float(st["trust_region"]) == r_used  # first pass: J is stored, nothing is decided (SCvxAlgorithm.cpp:109-113)
+        elif n_rej == 0:
+            dJ, dL = J_prev - J, J_prev - L
+            rho = dJ / dL
+            assert code == 1.0 and abs(dJ - dJ_dev) <= 1e-7 * abs(dL) and abs(dL - dL_dev) <= 1e-7 * abs(dL) and abs(rho - rho_dev) <= 1e-6
+            r_next = r_used / alpha if rho < rho_1 else (r_used * beta if rho >= rho_2 else r_used)
+            assert min(abs(rho - rho_1), abs(rho - rho_2)) > 1e-4 and abs(float(st["trust_region"]) - r_next) <= 1e-12 * r_next, ("radius", j + 1, rho)
+            rho_checked += 1
+        Xb, Ub, r_prev, solves_prev, J_prev = Xc, Uc, float(st["trust_region"]), int(st["solves"]), J
+    assert rejected >= 1 and rho_checked >= 1  # the path exercises both: rejected candidates and first-attempt acceptances
+    print("independent audit of %d sub-problems along the device path (K = %d, %d rejected candidates on the way, rho and the radius rule checked "
+          "on %d iterations): relative objective gaps %s" % (len(gaps), K, rejected, rho_checked, ["%.1e" % g for g in gaps]))
