@@ -157,6 +157,23 @@ class SubProblem:
         return lin, soc
 
 
+    # ---- evaluation of a given point (used by tests/test_independent_path_audit.py) ----
+    def cost(self, v):
+        return float(self.cost_grad(v) @ v)
+
+    def ineq(self, v):
+        """every linear row and every cone t - ||w|| (and delta_sigma - (sigma - sigma0)^2 in SC mode): >= 0 at a feasible point"""
+        lin, soc = self._forms()
+        val = lambda f: f[0] + sum(cf * v[i] for i, cf in f[1])  # noqa: E731
+        r = [val(f) for f in lin]
+        for t, ws in soc:
+            r.append(val(t) - np.sqrt(sum(val(w) ** 2 for w in ws)))
+        if self.mode == "sc":
+            idx, f = self._dsg_row
+            r.append(v[idx] - val(f) ** 2)
+        return np.array(r)
+
+
 def solve_case(K, mode, nondim):
     sc = scenario(nondim)
     Xb, Ub, sb = initial_trajectory(sc, K)
