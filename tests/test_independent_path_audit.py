@@ -287,3 +287,132 @@ def test_emu_rocket2d_scvx_path_sub_problems_against_independent_cutting_planes(
     assert len(gaps) >= 3
     print("independent audit of %d Rocket2D SCvx sub-problems along the device path (K = %d, %d rejected candidates): relative objective gaps %s" % (
         len(gaps), Kn, rejected, ["%.1e" % g for g in gaps]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SCvx with ZERO-ORDER-HOLD inputs (on the device since round 4): K - 1 inputs, no C (SCvxProblem.cpp:32-35), the trust region over the K - 1
+# inputs (:58-68), the model's final-input rows on column K - 2 (rocketQuat.cpp:109-111: v_U.cols() - 1), the discretisation with a constant
+# input and dV_B = Phi^-1 B (discretizationImplementation.hpp:45-52,95-100) -- restated here (forward sensitivities: P_B' = A P_B + B).
+# ---------------------------------------------------------------------------------------------------------------------
+class _ZohSubProblem:
+    mode = "scvx"
+
+    def __init__(self, G, sc, Xb, Ub, dd, w):
+        self.G, self.sc, self.Xb, self.Ub, self.dd, self.w = G, sc, Xb, Ub, dd, w
+        self.nX, self.nU, self.nN = K * 14, (K - 1) * 4, (K - 1) * 14
+        self.oU = self.nX; self.oP = self.oU + self.nU; self.oM = self.oP + self.nN
+        self.n = self.oM + self.nN
+
+    def split(self, v):
+        return (v[:self.nX].reshape(K, 14), v[self.oU:self.oP].reshape(K - 1, 4), v[self.oP:self.oM].reshape(K - 1, 14), v[self.oM:].reshape(K - 1, 14))
+
+    def cost_grad(self, v):
+        g = np.zeros(self.n); g[self.oP:] = self.w["vc"]
+        return g
+
+    def cost(self, v):
+        return float(self.cost_grad(v) @ v)
+
+    def eq(self, v):
+        X, U, P, M = self.split(v)
+        A, B, Z = self.dd
+        ff = self.G.FINAL_FIXED
+        r = [X[0] - self.sc["x_init"], X[K - 1][ff] - self.sc["x_final"][ff], U[K - 2][[0, 1, 3]], X[1:K - 1, 13], U[:K - 2, 3]]
+        for k in range(K - 1):
+            r.append(X[k + 1] - (A[k] @ X[k] + B[k] @ U[k] + Z[k] + P[k] - M[k]))
+        return np.concatenate(r)
+
+    def _forms(self):
+        if hasattr(self, "_lin"):
+            return self._lin, self._soc
+        sc = self.sc
+        iX = lambda k, j: k * 14 + j  # noqa: E731
+        iU = lambda k, j: self.oU + k * 4 + j  # noqa: E731
+        lin, soc = [], []
+        for i in range(2 * self.nN):
+            lin.append((0.0, [(self.oP + i, 1.0)]))
+        for k in range(K):
+            lin.append((-sc["x_final"][0], [(iX(k, 0), 1.0)]))  # mass >= m_dry
+        for k in range(1, K - 1):  # (nodes 0 and K-1 are fixed by the equalities)
+            soc.append(((0.0, [(iX(k, 3), sc["gs"])]), [(0.0, [(iX(k, 1), 1.0)]), (0.0, [(iX(k, 2), 1.0)])]))
+            lin.append((0.0, [(iX(k, 3), 1.0)]))
+            soc.append(((sc["tilt"], []), [(0.0, [(iX(k, 8), 1.0)]), (0.0, [(iX(k, 9), 1.0)])]))
+            soc.append(((sc["wmax"], []), [(0.0, [(iX(k, 11 + j), 1.0)]) for j in range(3)]))
+        for k in range(K - 1):
+            lin.append((-sc["T_min"], [(iU(k, 2), 1.0)]))
+            soc.append(((sc["T_max"], []), [(0.0, [(iU(k, j), 1.0)]) for j in range(3)]))
+            soc.append(((0.0, [(iU(k, 2), sc["gim"])]), [(0.0, [(iU(k, 0), 1.0)]), (0.0, [(iU(k, 1), 1.0)])]))
+            soc.append(((self.w["tr"], []), [(-self.Ub[k, j], [(iU(k, j), 1.0)]) for j in range(4)]))
+        self._lin, self._soc = lin, soc
+        return lin, soc
+
+    def ineq(self, v):
+        lin, soc = self._forms()
+        val = lambda f: f[0] + sum(cf * v[i] for i, cf in f[1])  # noqa: E731
+        return np.array([val(f) for f in lin] + [val(t) - np.sqrt(sum(val(w) ** 2 for w in ws)) for t, ws in soc])
+
+
+def _discretize_zoh(sc, X, U, sigma):
+    import sympy as sp
+    from scipy.integrate import solve_ivp
+    from generate_goldens import rocketquat_sym
+
+    x_, u_, p_, f_ = rocketquat_sym()
+    fn = sp.lambdify([x_, u_, p_], [f_, f_.jacobian(sp.Matrix(x_)), f_.jacobian(sp.Matrix(u_))], "numpy")
+    dt = sigma / (K - 1)
+    A = np.zeros((K - 1, 14, 14)); B = np.zeros((K - 1, 14, 4)); Z = np.zeros((K - 1, 14))
+    for k in range(K - 1):
+        def rhs(tau, y):
+            x = y[:14]; Phi = y[14:210].reshape(14, 14); PB = y[210:266].reshape(14, 4); pz = y[266:280]
+            fx, a, b = fn(x, U[k], sc["par"])
+            fx = np.asarray(fx, dtype=float).ravel(); a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+            return np.concatenate([fx, (a @ Phi).ravel(), (a @ PB + b).ravel(), a @ pz - a @ x - b @ U[k] + fx])
+        y = solve_ivp(rhs, [0, dt], np.concatenate([X[k], np.eye(14).ravel(), np.zeros(56 + 14)]), method="DOP853", rtol=1e-13, atol=1e-16).y[:, -1]
+        A[k] = y[14:210].reshape(14, 14); B[k] = y[210:266].reshape(14, 4); Z[k] = y[266:280]
+    return A, B, Z
+
+
+def test_emu_scvx_zero_order_hold_path_against_independent_cutting_planes(emu_lib, tmp_path):
+    import shutil
+
+    import generate_subproblem_cut_goldens as C
+    import generate_subproblem_goldens as G
+
+    G.K = K
+    sc = G.scenario()
+    ms, rs = sc["m_scale"], sc["r_scale"]
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+    p = cfg / "RocketQuat" / "SCvx.info"
+    t = p.read_text()
+    assert "interpolate_input                   true" in t and "nondimensionalize                   true" in t
+    p.write_text(t.replace("interpolate_input                   true", "interpolate_input                   false"))
+    m = scpp_amd.RocketQuat(str(cfg)).loadParameters()
+    alg = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=1, library=emu_lib).initialize()
+    assert alg.opts.interpolate_input == 0
+    alpha = float(alg.opts.alpha)
+    path = _device_path(alg, m.x_init[None], 4)
+    alg.ctx.close()
+    Xb, Ub = _nondim(path[0]["X"], path[0]["U"], ms, rs)
+    r_prev, solves_prev, gaps, rejected = float(path[0]["trust_region"]), 0, [], 0
+    for j, st in enumerate(path[1:]):
+        n_rej = int(st["solves"] - solves_prev) - 1
+        assert st["sc_iters"] == j + 1 and n_rej >= 0
+        rejected += n_rej
+        r_used = r_prev / alpha ** n_rej
+        Xc, Uc = _nondim(st["X"], st["U"], ms, rs)
+        assert (Uc[K - 1] == 0).all()  # K - 1 inputs: the slot of node K - 1 is unused
+        dd = _discretize_zoh(sc, Xb, Ub[:K - 1], sc["final_time"])
+        pb = _ZohSubProblem(G, sc, Xb, Ub[:K - 1], dd, dict(vc=W_VC, tr=r_used))
+        _, info = C.solve_cuts(pb, verbose=False)
+        assert info["cone_violation"] <= 1e-9 and max(info["eq_violation"], info["lin_violation"]) <= 1e-7
+        A, B, Z = dd
+        nu = np.array([Xc[k + 1] - (A[k] @ Xc[k] + B[k] @ Uc[k] + Z[k]) for k in range(K - 1)])
+        v = np.concatenate([Xc.ravel(), Uc[:K - 1].ravel(), np.maximum(nu, 0).ravel(), np.maximum(-nu, 0).ravel()])
+        assert np.abs(pb.eq(v)).max() <= 1e-9 and pb.ineq(v).min() >= -1e-9, (j + 1, float(np.abs(pb.eq(v)).max()), float(pb.ineq(v).min()))
+        gap = (pb.cost(v) - info["objective"]) / info["objective"]
+        assert -1e-6 <= gap <= 5e-5, ("ZOH objective", j + 1, pb.cost(v), info["objective"])
+        gaps.append(gap)
+        Xb, Ub, r_prev, solves_prev = Xc, Uc, float(st["trust_region"]), int(st["solves"])
+    print("independent audit of %d zero-order-hold SCvx sub-problems along the device path (K = %d, %d rejected candidates): relative objective gaps %s" % (
+        len(gaps), K, rejected, ["%.1e" % g for g in gaps]))
