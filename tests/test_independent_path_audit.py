@@ -416,3 +416,49 @@ def test_emu_scvx_zero_order_hold_path_against_independent_cutting_planes(emu_li
         Xb, Ub, r_prev, solves_prev = Xc, Uc, float(st["trust_region"]), int(st["solves"])
     print("independent audit of %d zero-order-hold SCvx sub-problems along the device path (K = %d, %d rejected candidates): relative objective gaps %s" % (
         len(gaps), K, rejected, ["%.1e" % g for g in gaps]))
+
+
+def test_emu_simulate_against_dop853_of_the_restated_flow_maps(emu_lib):
+    """scpp_hip_simulate (simulation.cpp:25-42: RKF78, 20 fixed steps, first-order-hold input) against DOP853 (rtol 1e-13) on the sympy restatements of
+    both models' flow maps (generate_goldens.py: rocketquat_sym; generate_rocket2d_cut_goldens.py: flow_map) -- the plant step of SC_sim / MPC_sim."""
+    import sympy as sp
+    from scipy.integrate import solve_ivp
+
+    import generate_rocket2d_cut_goldens as R
+    import generate_subproblem_goldens as G
+    from generate_goldens import rocketquat_sym
+
+    rng = np.random.default_rng(5)
+    # RocketQuat, nondimensional scenario parameters of the restatement
+    G.K = K
+    sc = G.scenario()
+    x_, u_, p_, f_ = rocketquat_sym()
+    fq = sp.lambdify([x_, u_, p_], f_, "numpy")
+    m = scpp_amd.RocketQuat().loadParameters()
+    ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKETQUAT, K=K, batch_max=4, library=emu_lib)
+    ctx.set_flow_params(np.tile(sc["par"], (4, 1)))
+    X0, U0, _ = G.initial_trajectory(sc)
+    x0 = X0[[1, 4, 7, 10]] + 1e-2 * rng.standard_normal((4, 14))
+    u0 = U0[:4] + 1e-2 * rng.standard_normal((4, 4)); u1 = U0[:4] + 1e-2 * rng.standard_normal((4, 4))
+    u0[:, 3] = 0.0; u1[:, 3] = 0.0  # no roll torque (rocketQuat.cpp:141-142; with J_z = 4e-6 in these units 1e-2 of it would spin the body up to 240 rad/s)
+    dt = np.array([0.3, 0.8, 1.1, 0.05])
+    xd = ctx.simulate(dt, u0, u1, x0)
+    for b in range(4):
+        rhs = lambda t, x: np.asarray(fq(x, u0[b] + t / dt[b] * (u1[b] - u0[b]), sc["par"]), dtype=float).ravel()  # noqa: E731
+        xe = solve_ivp(rhs, [0, dt[b]], x0[b], method="DOP853", rtol=1e-13, atol=1e-16).y[:, -1]
+        assert np.abs(xe - xd[b]).max() <= 1e-10 * max(1.0, np.abs(xe).max()), ("RocketQuat", b, float(np.abs(xe - xd[b]).max()))
+    ctx.close()
+    # Rocket2D, SI units as shipped
+    s2 = R.scenario(False)
+    f2 = R.flow_map()
+    ctx = scpp_amd.Context(scpp_amd.MODEL_ROCKET2D, K=K, batch_max=3, library=emu_lib)
+    ctx.set_flow_params(np.tile(s2["par"], (3, 1)))
+    x0 = np.array([s2["x_init"]] * 3) * (1 + 1e-2 * rng.standard_normal((3, 6)))
+    u0 = np.array([[0.05, 2.0e5], [-0.1, 3.0e5], [0.0, 1.0e5]]); u1 = np.array([[-0.05, 2.5e5], [0.1, 1.0e5], [0.2, 4.0e5]])
+    dt = np.array([0.4, 1.0, 0.01])
+    xd = ctx.simulate(dt, u0, u1, x0)
+    for b in range(3):
+        rhs = lambda t, x: np.asarray(f2(x, u0[b] + t / dt[b] * (u1[b] - u0[b]), s2["par"])[0], dtype=float).ravel()  # noqa: E731
+        xe = solve_ivp(rhs, [0, dt[b]], x0[b], method="DOP853", rtol=1e-13, atol=1e-16).y[:, -1]
+        assert np.abs(xe - xd[b]).max() <= 1e-10 * max(1.0, np.abs(xe).max()), ("Rocket2D", b, float(np.abs(xe - xd[b]).max()))
+    ctx.close()
