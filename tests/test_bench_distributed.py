@@ -83,3 +83,35 @@ def test_bench_force_gather_single_rank(model, emu_lib, tmp_path):
     assert lp["config"]["gather"] is None and lp["n_gpus"] == lg["n_gpus"] == 1
     assert rg.shape == rp.shape == (steps * B, K * 18 + 10)
     assert np.array_equal(rg.view(np.uint64), rp.view(np.uint64))
+
+
+def test_bench_line_contract(emu_lib):
+    """The ONE JSON line the driver parses: every key of the bench contract with the right type, the metric of BASELINE.json, the roofline and
+    cpu_baseline objects, weak scaling, value = converged / time."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--library", emu_lib,
+           "--K", "6", "--batch", "2", "--max-iterations", "3", "--no-extras"]  # (cpu_baseline bounds itself: ~12 s per solver)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # exactly one JSON line
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"]
+    for key, typ in (("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float), ("higher_is_better", bool),
+                     ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
+        assert isinstance(d[key], typ), (key, type(d[key]))
+    assert "vs_baseline" in d and d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    r_ = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r_, key
+    assert r_["bound"] in ("hbm", "mfma") and r_["unit"] in ("GB/s", "TFLOP/s") and abs(r_["frac"] - r_["achieved"] / r_["peak"]) <= 1e-12
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - d["config"]["converged_fraction"] * d["config"]["instances_timed"]) <= 1e-6
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, (key, c)
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
