@@ -17,8 +17,10 @@ Secondary numbers (rank 0, outside the timed region) under `config`: the SC-mode
 trajectories TERMINATED per second -- with the shipped weights none of them meets SCAlgorithm's convergence test at K=50,
 see DESIGN.md -- an isolated single-batch SCvx solve, un-overlapped (single-pool) kernel times, and the linear-MPC leg.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run; --backend gloo + --library
-<emulation build> drives the same N>1 code path on CPU in tests/test_bench_distributed.py)
+Usage: python bench.py --gpus N --steps K --warmup W.  N > 1 without a launcher: the script starts its N ranks itself (one process per
+GPU under torch.distributed.run on 127.0.0.1, `_self_launch`) and refuses when fewer than N GPUs are visible; under an external
+torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  --backend gloo + --library <emulation build> drives the same N > 1
+code path on CPU in tests/test_bench_distributed.py, with and without the launcher.
 """
 import argparse
 import glob
@@ -182,6 +184,32 @@ def parity_summary():
     return out
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-run this very command line as N ranks (one process per GPU) under
+    torch.distributed.run on the loopback interface; the children see WORLD_SIZE / RANK / LOCAL_RANK and take the distributed path of
+    main(), rank 0 prints the JSON line to the inherited stdout.  Fails before anything is started when the node has fewer GPUs."""
+    import socket
+    import subprocess
+
+    if args.backend != "gloo":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; one rank per GPU, no oversubscription")
+    with socket.socket() as s:  # a free loopback port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,10 +233,22 @@ def main():
     ap.add_argument("--mpc-batch", type=int, default=32768)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run, loopback
+        # rendezvous on a free port) and hand its exit code back.  Under an external launcher WORLD_SIZE is set and this is skipped.
+        return _self_launch(args)
+
     import torch
     import scpp_amd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a launcher that started a different number of ranks than --gpus names would silently mislabel the line
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or omit the launcher)")
+    if args.backend != "gloo" and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible; one rank per GPU, no oversubscription")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = args.backend != "gloo"

@@ -59,6 +59,56 @@ def test_bench_world_n_gloo_matches_single_process(model, emu_lib, tmp_path, wor
     assert (got["instance"].reshape(world, steps * B) == np.arange(steps * B)[None, :]).all()
 
 
+def test_bench_gpus_flag_launches_the_ranks_itself(model, emu_lib, tmp_path):
+    """plain `python bench.py --gpus 2` -- NO launcher around it, the form the driver uses -- must start two ranks by
+    itself: n_gpus == 2, twice the instances, and the gathered rows bitwise equal to what one process computes for the same instance ids."""
+    world, K, B, steps, warm, maxit, seed = 2, 6, 2, 3, 1, 3, 20260927
+    dump = str(tmp_path / "rows.npy")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warm), "--backend", "gloo",
+           "--library", emu_lib, "--K", str(K), "--batch", str(B), "--max-iterations", str(maxit), "--no-cpu-baseline", "--no-extras", "--dump", dump]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints, once
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["steps"] == steps and line["warmup"] == warm and line["scaling"] == "weak"
+    assert line["config"]["instances_timed"] == world * steps * B
+    assert line["config"]["gather"]["gathered_equals_local_bitwise"] is True
+    rows = np.load(dump)
+    assert rows.shape == (world * steps * B, K * 18 + 10)
+    got = scpp_amd.Context.unpack_stream_rows(rows, K)
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    at = 0
+    for rank in range(world):
+        for i in range(steps):
+            x0 = model.randomized_initial_states(B, seed=seed, first=((warm + i) * world + rank) * B)
+            alg.solve(x0)
+            ref = alg.getSolution()
+            for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "solves", "converged", "status", "ipm_iters"):
+                assert np.array_equal(got[key][at:at + B], ref[key]), (rank, i, key)
+            at += B
+
+
+def test_bench_gpus_flag_refuses_more_ranks_than_gpus(emu_lib):
+    """--gpus N on a node with fewer than N GPUs (here: none) fails loudly before anything starts, and so does a launcher whose world size
+    disagrees with --gpus: a mislabelled line would be worse than no line."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    import torch
+
+    if torch.cuda.device_count() < 64:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "--gpus 64" in r.stderr and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo",
+                        "--library", emu_lib], capture_output=True, text=True, timeout=600, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
 def test_bench_force_gather_single_rank(model, emu_lib, tmp_path):
     """--force-gather: ONE process creates a world-1 process group and runs the whole multi-GPU result path (view of the
     library's rows -> staging tensor -> chunked all_gather_into_tensor) inside the timed region; the dumped gathered rows are,
