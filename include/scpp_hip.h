@@ -154,6 +154,16 @@ extern "C"
     int scpp_hip_create(scpp_hip_ctx **ctx, int device_id, int model_id, int K, int batch_max, unsigned flags);
     int scpp_hip_destroy(scpp_hip_ctx *ctx);
     const char *scpp_hip_version(void);
+    /* Build-defined constants of THIS library, so that a binding never hard-codes them (ABI revision 5, round 5: the per-instance status
+       SCPP_STATUS_REJECTION_CAP moved from -4 to -5 in revision 4 without a way to ask).  Returns SCPP_E_ARG for an unknown `what` or a NULL
+       `value`.  Bindings compare SCPP_Q_ABI_REVISION with the header they were written against and refuse a different library. */
+#define SCPP_ABI_REVISION 5
+#define SCPP_Q_ABI_REVISION 0          /* SCPP_ABI_REVISION of the build */
+#define SCPP_Q_STATUS_REJECTION_CAP 1  /* the per-instance status of an SCvx run retired in the reject loop */
+#define SCPP_Q_SCVX_SOLVE_CAP 2        /* sub-problem solves per configured SCvx iteration before that happens (csrc/scvx_kernels.h) */
+#define SCPP_Q_MAX_K 3                 /* largest K of scpp_hip_create (lane = stage: one wavefront) */
+#define SCPP_Q_MPC_MAX_K 4             /* largest horizon of scpp_hip_mpc_setup */
+    int scpp_hip_query(int what, long long *value);
 
     /* ---- multipleShooting / simulate boundary (any model) ---- */
     int scpp_hip_set_flow_params(scpp_hip_ctx *ctx, const double *par /* [B][np] */, int B);

@@ -8,8 +8,12 @@ MODEL_ROCKETQUAT, MODEL_ROCKET2D = 0, 1
 MODE_FOH, MODE_VT = 1, 2
 # include/scpp_hip.h: return codes, and the per-instance status of an SCvx run retired in the reference's exit-less reject loop
 E_ARG, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4
+# What this binding was written against.  load_library() asks the library for ITS values (scpp_hip_query) and refuses one that disagrees: the
+# status moved from -4 to -5 between two builds once, and a constant that is only written down on both sides is how that goes unnoticed.
+ABI_REVISION = 5
 STATUS_REJECTION_CAP = -5
 SCVX_SOLVE_CAP = 64  # csrc/scvx_kernels.h: sub-problem solves per configured iteration before an instance is retired
+Q_ABI_REVISION, Q_STATUS_REJECTION_CAP, Q_SCVX_SOLVE_CAP, Q_MAX_K, Q_MPC_MAX_K = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -119,7 +123,7 @@ _lib = None
 _lib_path = None
 
 SYMBOLS = [
-    "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_set_flow_params", "scpp_hip_upload_traj", "scpp_hip_upload_traj_zoh",
+    "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_query", "scpp_hip_set_flow_params", "scpp_hip_upload_traj", "scpp_hip_upload_traj_zoh",
     "scpp_hip_discretize", "scpp_hip_set_discretization_steps", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
@@ -151,8 +155,22 @@ def load_library(path=None):
         if not hasattr(lib, s):
             raise ScppHipError(f"{path} does not export {s}")
     lib.scpp_hip_version.restype = C.c_char_p
+    for what, name, mine in ((Q_ABI_REVISION, "ABI revision", ABI_REVISION), (Q_STATUS_REJECTION_CAP, "SCPP_STATUS_REJECTION_CAP", STATUS_REJECTION_CAP),
+                             (Q_SCVX_SOLVE_CAP, "SCVX_SOLVE_CAP", SCVX_SOLVE_CAP)):
+        theirs = query(what, lib)
+        if theirs != mine:
+            raise ScppHipError(f"{path}: {name} is {theirs}, this binding was written against {mine} ({lib.scpp_hip_version().decode()}); rebuild")
     _lib, _lib_path = lib, path
     return lib
+
+
+def query(what, lib=None):
+    """scpp_hip_query: a build-defined constant of the loaded library"""
+    v = C.c_longlong()
+    rc = (lib or load_library()).scpp_hip_query(int(what), C.byref(v))
+    if rc != 0:
+        raise ScppHipError(f"scpp_hip_query({what}) failed with code {rc}")
+    return int(v.value)
 
 
 def _p(a):

@@ -497,11 +497,26 @@ static_assert(IPM_WAVES_PER_SIMD <= 2 && DISC_WAVES_PER_SIMD <= 2,
 const char *scpp_hip_version(void)
 {
 #ifdef SCPP_HIP_EMU
-    return "scpp_hip 0.3 (CPU emulation build: TEST ONLY)";
+    return "scpp_hip 0.4 (CPU emulation build: TEST ONLY)";
 #else
-    return "scpp_hip 0.3 (gfx950; clang " __clang_version__ "; HIP " SCPP_STR(HIP_VERSION_MAJOR) "." SCPP_STR(HIP_VERSION_MINOR) "." SCPP_STR(
+    return "scpp_hip 0.4 (gfx950; clang " __clang_version__ "; HIP " SCPP_STR(HIP_VERSION_MAJOR) "." SCPP_STR(HIP_VERSION_MINOR) "." SCPP_STR(
         HIP_VERSION_PATCH) "; ipm_kernel " SCPP_STR(IPM_WAVES_PER_SIMD) " waves/SIMD, discretize_kernel " SCPP_STR(DISC_WAVES_PER_SIMD) " waves/SIMD; " SCPP_TOOLCHAIN_NOTE ")";
 #endif
+}
+
+int scpp_hip_query(int what, long long *value)
+{
+    if (!value)
+        return SCPP_E_ARG;
+    switch (what)
+    {
+    case SCPP_Q_ABI_REVISION: *value = SCPP_ABI_REVISION; return SCPP_OK;
+    case SCPP_Q_STATUS_REJECTION_CAP: *value = SCPP_STATUS_REJECTION_CAP; return SCPP_OK;
+    case SCPP_Q_SCVX_SOLVE_CAP: *value = SCVX_SOLVE_CAP; return SCPP_OK;
+    case SCPP_Q_MAX_K: *value = WAVE; return SCPP_OK;
+    case SCPP_Q_MPC_MAX_K: *value = 8; return SCPP_OK;
+    }
+    return SCPP_E_ARG;
 }
 
 int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int batch_max, unsigned)

@@ -110,3 +110,39 @@ def test_empty_jobs_are_refused_not_ignored(model, emu_lib):
     sc = scpp_amd.SCAlgorithm(model, K=8, batch_max=2, library=emu_lib).initialize()
     with pytest.raises(scpp_amd.ScppHipError, match="code -1"):
         sc.ctx.sc_setup(model.p, sc.opts, none)
+
+
+def test_roll_control_is_refused_by_every_entry_point(raw, model):
+    """rocketQuat.cpp:135-138 (`enable_roll_control`): a reference code path this engine permanently does not run (include/scpp_hip.h:
+    18 free variables per node against one 16-wide tile).  All THREE entry points that take the model parameters say so with
+    SCPP_E_UNSUPPORTED instead of solving a different problem: scpp_hip_sc_setup, scpp_hip_scvx_setup, scpp_hip_scvx_solve_stream."""
+    rc, h = _create(raw, K=8, B=4)
+    assert rc == 0
+    rollp = type(model.p).from_buffer_copy(model.p)
+    rollp.enable_roll_control = 1
+    x0 = np.ascontiguousarray(model.randomized_initial_states(4))
+    xp = x0.ctypes.data_as(C.c_void_p)
+    sc = scpp_amd.load_sc_opts(model.getParameterFolder(), 8)
+    vx = scpp_amd.load_scvx_opts(model.getParameterFolder(), 8)
+    n = C.c_int(-7)
+    assert raw.scpp_hip_sc_setup(h, C.byref(rollp), C.byref(sc), xp, 4, 0) == E_UNSUPPORTED
+    assert raw.scpp_hip_scvx_setup(h, C.byref(rollp), C.byref(vx), xp, 4, 0) == E_UNSUPPORTED
+    assert raw.scpp_hip_scvx_solve_stream(h, C.byref(rollp), C.byref(vx), xp, 4, 4, 1, C.byref(n)) == E_UNSUPPORTED
+    # nothing was set up by the refused calls
+    assert raw.scpp_hip_scvx_solve(h, C.byref(n)) == E_STATE and raw.scpp_hip_sc_solve(h, C.byref(n)) == E_STATE
+    # ... and the same parameters with roll control off are accepted
+    assert raw.scpp_hip_scvx_setup(h, C.byref(model.p), C.byref(vx), xp, 4, 0) == 0
+    assert raw.scpp_hip_destroy(h) == 0
+
+
+def test_query_reports_the_build_constants(raw):
+    """scpp_hip_query: a binding asks the library for its build-defined constants instead of hard-coding them (the rejection-cap
+    status moved from -4 to -5 with no way to notice); load_library refuses a library whose answers differ from the binding's."""
+    v = C.c_longlong(0)
+    for what, want in ((_lib.Q_ABI_REVISION, _lib.ABI_REVISION), (_lib.Q_STATUS_REJECTION_CAP, scpp_amd.STATUS_REJECTION_CAP),
+                       (_lib.Q_SCVX_SOLVE_CAP, scpp_amd.SCVX_SOLVE_CAP), (_lib.Q_MAX_K, 64), (_lib.Q_MPC_MAX_K, 8)):
+        assert raw.scpp_hip_query(what, C.byref(v)) == 0 and v.value == want
+    assert raw.scpp_hip_query(99, C.byref(v)) == E_ARG and raw.scpp_hip_query(0, None) == E_ARG
+    assert scpp_amd.STATUS_REJECTION_CAP not in (0, E_ARG, E_HIP, E_UNSUPPORTED, E_STATE)  # a status, distinct from every return code
+    h = C.c_void_p()
+    assert raw.scpp_hip_create(C.byref(h), 0, 0, _lib.query(_lib.Q_MAX_K, raw) + 1, 4, 0) == E_ARG

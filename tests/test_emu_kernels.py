@@ -317,7 +317,7 @@ def _rocket2d_scvx_case(oracle, lib, K, tmp_path, maxit=None):
         x0[1:] = m2.randomized_initial_states(1, first=1)
         n = alg.solve(x0)
         o = alg.getSolution()
-        assert np.isin(o["status"], (0, -4)).all() and o["status"][0] == 0 and n == int(o["converged"].sum())  # -4: rejection-loop cap
+        assert np.isin(o["status"], (0, scpp_amd.STATUS_REJECTION_CAP)).all() and o["status"][0] == 0 and n == int(o["converged"].sum())  # retired in the reject loop
         s = oracle.SCvx(K=K, model=oracle.ROCKET2D, config_root=root or oracle.CONFIG_ROOT); s.set_solver(0)
         if name == "shipped" and maxit:
             s.set_max_iterations(maxit)
