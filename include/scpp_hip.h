@@ -186,6 +186,21 @@ extern "C"
 
     /* ---- SCAlgorithm boundary (RocketQuat) ---- */
     int scpp_hip_set_socp_opts(scpp_hip_ctx *ctx, const scpp_socp_opts *opts);
+    /* How the interior-point solve (the replacement of ECOSSolver::solve, SCAlgorithm.cpp:78 / SCvxAlgorithm.cpp:81) is scheduled on the device.
+       The arithmetic is the same in every schedule -- the results are bitwise identical (tests) -- only the launch structure differs:
+         SCPP_IPM_RESIDENT     one kernel per solve, one resident wavefront per instance for all its interior-point iterations (2 waves/SIMD);
+         SCPP_IPM_SPLIT        two kernels per interior-point iteration, split by register budget (csrc/ipm_split.h): the factor sweep at two
+                               wavefronts per SIMD, everything else at three.  RocketQuat with first-order hold; other configurations run
+                               SCPP_IPM_RESIDENT whatever is set.  split_pairs: launch pairs per solve, 0 = the worst case 2 maxit + 1;
+         SCPP_IPM_RESIDENT_WS  SCPP_IPM_RESIDENT without the LDS-resident segment fields (diagnostic of that layout choice; CPU emulation build only,
+                               SCPP_E_UNSUPPORTED on the device). */
+#define SCPP_IPM_RESIDENT 0
+#define SCPP_IPM_SPLIT 1
+#define SCPP_IPM_RESIDENT_WS 2
+#ifndef SCPP_IPM_SCHEDULE_DEFAULT
+#define SCPP_IPM_SCHEDULE_DEFAULT SCPP_IPM_RESIDENT
+#endif
+    int scpp_hip_set_ipm_schedule(scpp_hip_ctx *ctx, int schedule, int split_pairs);
     int scpp_hip_sc_setup(scpp_hip_ctx *ctx, const scpp_rocketquat_params *model, const scpp_sc_opts *opts,
                           const double *x_init /* [B][14] dimensional */, int B, int warm_start);
     /* the same for a Rocket2d context (the reference's default active model, scpp_core/include/activeModel.hpp:10): the

@@ -151,6 +151,24 @@ struct ZeroOrderHold : P
 {
     static constexpr bool ZOH = true;
 };
+// Policy variant of a table (same problem, same record layout): the three most-travelled segment fields stay in the workspace instead of
+// living in LDS for the duration of a solve (ipm_kernel.h: SegLdsSlot).  The kernels that run more than two wavefronts per SIMD use it --
+// 12 wavefronts x (16.8 KB + 3 KB) do not fit the CU's 160 KB -- and so does every kernel that does not stay resident for a whole solve.
+template <class P>
+struct SegFieldsInWorkspace : P
+{
+    static constexpr bool SEG_FIELDS_IN_WORKSPACE = true;
+};
+template <class P, class = void>
+struct SegInLds
+{
+    static constexpr bool value = true;
+};
+template <class P>
+struct SegInLds<P, decltype(void(P::SEG_FIELDS_IN_WORKSPACE))>
+{
+    static constexpr bool value = !P::SEG_FIELDS_IN_WORKSPACE;
+};
 template <class P, class = void>
 struct IsZoh
 {

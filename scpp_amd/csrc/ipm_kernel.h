@@ -133,12 +133,13 @@ constexpr int LANES = 64;
 // instead of 64 keeps rows 16-byte aligned and cuts the record traffic by 1 - K/64 (22 % at K = 50).
 __host__ __device__ inline int recPitch(int K) { return (K + 1) & ~1; }
 constexpr int GSAVE = 16; // wave-uniform scalars of the last solve (sigma, delta_sigma, n1 and their slacks / duals): warm start
+constexpr int RSAVE = 112; // resume block of the split schedule (ipm_split.h): Glob + Iter + the loop's locals between two launches
 template <class P>
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
     using L = Lay<P>;
     // the exchange records come first so that they start on a 128-byte line; the total is a multiple of a line
-    const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE;
+    const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE + RSAVE;
     return (n + 15) & ~size_t(15);
 }
 
@@ -254,7 +255,7 @@ struct Ctx
 template <class P>
 __host__ __device__ inline unsigned segLdsBytes(int K)
 {
-    return unsigned(NSEGLDS * Lay<P>::NL * recPitch(K) * 8);
+    return SegInLds<P>::value ? unsigned(NSEGLDS * Lay<P>::NL * recPitch(K) * 8) : 0u;
 }
 
 // ---------------- the table, evaluated ----------------

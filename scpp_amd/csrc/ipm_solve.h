@@ -457,6 +457,24 @@ __device__ inline void forSegChunks(F &&f)
 #ifndef IPM_UPD_CHUNK
 #define IPM_UPD_CHUNK 7 // (5 until round 4: with the recomputing chunks 7 rows = two chunks measured +0.4 %)
 #endif
+// chunk size of a kernel variant: the workspace-resident variants run three wavefronts per SIMD (168 VGPRs) and take shorter chunks
+#ifndef IPM_DIR_CHUNK_W
+#define IPM_DIR_CHUNK_W 5
+#endif
+#ifndef IPM_RHS_CHUNK_W
+#define IPM_RHS_CHUNK_W 5
+#endif
+#ifndef IPM_RES_CHUNK_W
+#define IPM_RES_CHUNK_W 5
+#endif
+#ifndef IPM_UPD_CHUNK_W
+#define IPM_UPD_CHUNK_W 5
+#endif
+template <class P>
+constexpr int chunkFor(int resident, int split)
+{
+    return SegInLds<P>::value ? resident : split;
+}
 // Rows 1 .. NP of a vector that starts at the trust-region cone are STRUCTURAL ZEROS in SCvx mode (the state rows of the cone:
 // saff / Lmul produce 0 there, and every cone operation maps zero rows to zero rows).  They are accessed through a second view
 // `rz` of the same record whose lane offset lies beyond the record block in SCvx mode: the buffer hardware then returns 0 for
@@ -1077,26 +1095,56 @@ struct SegState
 {
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N];
 };
-// this lane's view of the LDS-resident segment fields (ipm_kernel.h: SegLdsSlot): rows [I0, I0 + N) of slot SLOT
+// this lane's view of the three most-travelled segment fields (ipm_kernel.h: SegLdsSlot): rows [I0, I0 + N) of slot SLOT -- in LDS, or
+// (SegFieldsInWorkspace<P>: kernels with more than two wavefronts per SIMD) their home in the field-major segment record of the workspace
 struct SegLds
 {
     LDSP double *p; // + segment index
     int pitch;
+    SV sg;          // the segment record of the same segment (workspace-resident variant)
 };
-__device__ inline SegLds makeSegLds(const Ctx &c, int seg) { return SegLds{c.segl + seg, c.pitch}; }
+template <int SLOT>
+constexpr int segLdsField()
+{
+    return SLOT == SL_LAM ? int(G_LAM) : SLOT == SL_NU ? int(G_NU) : int(G_NUB);
+}
+template <class P>
+__device__ inline SegLds makeSegLds(const Ctx &c, int seg)
+{
+    return SegLds{c.segl + seg, c.pitch, makeSV(c.sg, (G_NFIELDS * Lay<P>::NL), unsigned(seg), c.pitch)};
+}
+// one element (direct access of phResiduals)
+template <class P, int SLOT>
+__device__ inline double segLdsGet(const SegLds &l, int i)
+{
+    if constexpr (SegInLds<P>::value)
+        return l.p[(SLOT * Lay<P>::NL + i) * l.pitch];
+    else
+        return l.sg[segLdsField<SLOT>() * Lay<P>::NL + i];
+}
 template <class P, int SLOT, int I0, int N>
 __device__ inline void ldl(const SegLds &l, double (&v)[N])
 {
+    if constexpr (SegInLds<P>::value)
+    {
 #pragma unroll
-    for (int i = 0; i < N; i++)
-        v[i] = l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch];
+        for (int i = 0; i < N; i++)
+            v[i] = l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch];
+    }
+    else
+        ldf<N>(l.sg, segLdsField<SLOT>() * Lay<P>::NL + I0, v);
 }
 template <class P, int SLOT, int I0, int N>
 __device__ inline void stl(const SegLds &l, const double (&v)[N])
 {
+    if constexpr (SegInLds<P>::value)
+    {
 #pragma unroll
-    for (int i = 0; i < N; i++)
-        l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch] = v[i];
+        for (int i = 0; i < N; i++)
+            l.p[(SLOT * Lay<P>::NL + I0 + i) * l.pitch] = v[i];
+    }
+    else
+        stf<N>(l.sg, segLdsField<SLOT>() * Lay<P>::NL + I0, v);
 }
 template <class P, int I0, int N>
 __device__ inline void ldSegState(const SV &sg, const SegLds &sl, SegState<N> &q)
@@ -1256,13 +1304,13 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV stz = padView(v.st, scvx);
     const SV dyz = padView(v.dy, scvx); // for the S column only
     // LDS-resident segment fields of this lane's segment and of the previous one (lanes without a segment read segment 0, masked)
-    const SegLds sl = makeSegLds(c, v.vsg ? k : 0), slP = makeSegLds(c, (k > 0 && k < v.K) ? k - 1 : 0);
+    const SegLds sl = makeSegLds<P>(c, v.vsg ? k : 0), slP = makeSegLds<P>(c, (k > 0 && k < v.K) ? k - 1 : 0);
     ResAcc p;
     p.gap = p.rx = p.ry = p.rz = p.xx = p.yy = p.zz = p.ss = p.rxs = p.sumnb = 0.;
     double p_dl = 0.;
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RES_CHUNK>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, sl, dyz, g_z3, p); });
+        forSegChunks<P, chunkFor<P>(IPM_RES_CHUNK, IPM_RES_CHUNK_W)>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, sl, dyz, g_z3, p); });
     }
     if (v.vst)
     {
@@ -1321,9 +1369,9 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             (void)dyP;
             sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = prevLane(rc[decltype(jt)::value]); });
 #endif
-            const double l = mk * sl.p[(SL_LAM * L::NL + i) * sl.pitch], lp = mp * slP.p[(SL_LAM * L::NL + i) * slP.pitch];
+            const double l = mk * segLdsGet<P, SL_LAM>(sl, i), lp = mp * segLdsGet<P, SL_LAM>(slP, i);
             const int xi = L::XINV.v[i]; // stage variable of state i, -1: pinned
-            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dyz[L::DY_S + i] * g_sig - sl.p[(SL_NU * L::NL + i) * sl.pitch] - dy[L::DY_Z + i];
+            double rr = (xi >= 0 ? double(stN[L::F_W + (xi >= 0 ? xi : 0)]) : 0.) - dyz[L::DY_S + i] * g_sig - segLdsGet<P, SL_NU>(sl, i) - dy[L::DY_Z + i];
 #pragma unroll
             for (int j = 0; j < NXV; j++)
             {
@@ -1647,7 +1695,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     }
     if (v.vsg)
     {
-        forSegChunks<P, IPM_RHS_CHUNK>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value, PASS>(sg, makeSegLds(c, v.k), v.xs, om, sigmu, g_z3, g_dz3); });
+        forSegChunks<P, chunkFor<P>(IPM_RHS_CHUNK, IPM_RHS_CHUNK_W)>([&](auto i0, auto n) { rhsSegChunk<P, decltype(i0)::value, decltype(n)::value, PASS>(sg, makeSegLds<P>(c, v.k), v.xs, om, sigmu, g_z3, g_dz3); });
     }
     WAVE_SYNC();
 }
@@ -1715,7 +1763,7 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu,
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N, PASS>(sg, makeSegLds(c, k), xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
+        dirSegChunk<P, I0, N, PASS>(sg, makeSegLds<P>(c, k), xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
     }
     return o;
 }
@@ -1864,7 +1912,7 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     double ainv = ip_->part_ainv, finite_chk = ip_->part_fin;
     double sumdnb = 0.;
     const double sigmu = sigma_c * double(ip_->mu), z3 = gp->z3, dz3 = gp->dz3;
-    forSegChunks<P, IPM_DIR_CHUNK>([&](auto i0, auto n) {
+    forSegChunks<P, chunkFor<P>(IPM_DIR_CHUNK, IPM_DIR_CHUNK_W)>([&](auto i0, auto n) {
         const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, PASS>(cin, om, sigmu, z3, dz3, g.dsig, ainv, sumdnb);
         ainv = o.ainv;
         sumdnb = o.sumdnb;
@@ -2030,12 +2078,14 @@ template <class P, bool TO_LDS>
 PHASE_FN void phSegLdsCopy(const PRIV Ctx *cin)
 {
     using L = Lay<P>;
+    if constexpr (!SegInLds<P>::value)
+        return; // the fields never leave the workspace
     const Ctx c = uniformCtx(cin);
     const int k = c.lane;
     if (k < c.K - 1)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
-        const SegLds sl = makeSegLds(c, k);
+        const SegLds sl = makeSegLds<P>(c, k);
         double nu[L::NL], nub[L::NL], lam[L::NL];
         if (TO_LDS)
         {
@@ -2095,8 +2145,8 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         // block solve's multiplier direction) instead of being stored by it and loaded back: segRhsRow<1> / segDirRow
         const double sigma_c = ip_->sigma_c, om = 1. - sigma_c, sigmu = sigma_c * double(ip_->mu);
         const SV xsz = padView(v.xs, scvx);
-        forSegChunks<P, IPM_UPD_CHUNK>([&](auto i0, auto n) {
-            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, makeSegLds(c, v.k), v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
+        forSegChunks<P, chunkFor<P>(IPM_UPD_CHUNK, IPM_UPD_CHUNK_W)>([&](auto i0, auto n) {
+            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, makeSegLds<P>(c, v.k), v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
         });
     }
     g.sig += alpha * g.dsig;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "discretize_kernel.h"
 #include "ipm_solve.h"
+#include "ipm_split.h"
 #include "model_rocketquat.h"
 #include "sc_kernels.h"
 #include "scvx_kernels.h"
@@ -90,6 +91,8 @@ struct scpp_hip_ctx
     int last_active = 0;
     long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
     int stream_pools = 0;
+    int ipm_schedule = SCPP_IPM_SCHEDULE_DEFAULT; // SCPP_IPM_RESIDENT / SCPP_IPM_SPLIT / SCPP_IPM_RESIDENT_WS (scpp_hip_set_ipm_schedule)
+    int ipm_split_pairs = 0;                      // (factor, rest) launch pairs per solve of the split schedule; 0 = the worst case 2 maxit + 1
     int disc_steps = 5; // RKF78 steps per segment: 5 = the reference's fixed count (default since round 4), 1 .. 4 pinned, 0 = discretize_kernel.h's step-length rule (opt-in)
 };
 
@@ -372,7 +375,25 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
     // one instantiation of the solver per model table (csrc/constraint_table.h)
     const bool zoh = !(c->mode & SCPP_MODE_FOH); // zero-order hold: the table's ZeroOrderHold variant (same record layout)
-    if (rq && !zoh)
+    if (rq && !zoh && c->ipm_schedule == SCPP_IPM_SPLIT)
+    {
+        // split schedule (ipm_split.h): A(first) [F A] x pairs.  An instance asks for at most maxit factor sweeps per attempt plus one for the cold
+        // initialisation, and a warm attempt that breaks down is repeated cold: 2 maxit + 1 pairs cover every instance; one that has finished
+        // returns at the top of each later launch.
+        using W = ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>;
+        const int pairs = c->ipm_split_pairs > 0 ? c->ipm_split_pairs : 2 * a.opt.maxit + 1;
+        hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a, 1);
+        for (int i = 0; i < pairs; i++)
+        {
+            hipLaunchKernelGGL(ipm::ipm_factor_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a);
+            hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a, 0);
+        }
+    }
+#ifdef SCPP_HIP_EMU // (diagnostic of the layout policy; the device library does not carry a third instantiation of the solver for it)
+    else if (rq && !zoh && c->ipm_schedule == SCPP_IPM_RESIDENT_WS)
+        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+#endif
+    else if (rq && !zoh)
         hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
     else if (rq)
         hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
@@ -555,6 +576,13 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     c->K = K;
     c->Bmax = batch_max;
     c->B = 0;
+    // measurement hooks (A/B runs of one library): the schedule of a new context and its launch pairs per solve; scpp_hip_set_ipm_schedule overrides
+    if (const char *e = std::getenv("SCPP_IPM_SCHEDULE"))
+        if (std::atoi(e) >= SCPP_IPM_RESIDENT && std::atoi(e) <= SCPP_IPM_SPLIT)
+            c->ipm_schedule = std::atoi(e);
+    if (const char *e = std::getenv("SCPP_IPM_SPLIT_PAIRS"))
+        if (std::atoi(e) > 0)
+            c->ipm_split_pairs = std::atoi(e);
     if (model_id == SCPP_MODEL_ROCKETQUAT)
     {
         c->nx = RocketQuatModel::NX;
@@ -770,6 +798,19 @@ int scpp_hip_set_discretization_steps(scpp_hip_ctx *c, int steps)
     if (!c || steps < 0 || steps > DISC_STEPS_MAX) // 5 = the reference (default), 0 = the step-length rule (opt-in), 1 .. 4 pinned
         return SCPP_E_ARG;
     c->disc_steps = steps;
+    return SCPP_OK;
+}
+
+int scpp_hip_set_ipm_schedule(scpp_hip_ctx *c, int schedule, int split_pairs)
+{
+    if (!c || schedule < SCPP_IPM_RESIDENT || schedule > SCPP_IPM_RESIDENT_WS || split_pairs < 0)
+        return SCPP_E_ARG;
+#ifndef SCPP_HIP_EMU
+    if (schedule == SCPP_IPM_RESIDENT_WS)
+        return SCPP_E_UNSUPPORTED; // emulation build only
+#endif
+    c->ipm_schedule = schedule;
+    c->ipm_split_pairs = split_pairs;
     return SCPP_OK;
 }
 

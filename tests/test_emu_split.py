@@ -1,0 +1,68 @@
+"""The split schedule of the interior-point solve (csrc/ipm_split.h: two kernels per interior-point iteration, the factor sweep at two
+wavefronts per SIMD and everything else at three, state carried through the workspace between launches) against the resident kernel
+(one launch per solve) on the CPU wave emulation of the same sources: the two drive the SAME phase functions in the same order, so
+every output must be BITWISE identical -- trajectories, counters, statuses, the interior-point iteration counts -- in SCvx mode (batch and
+streaming entry points, rejections and warm starts included), in SC mode (sigma border: two-column factor sweeps), and with too few launch
+pairs the instance must be reported, not silently returned half-solved."""
+import numpy as np
+import pytest
+
+import scpp_amd
+from scpp_amd import _lib
+
+KEYS = ("X", "U", "sigma", "nu_norm", "sc_iters", "solves", "converged", "status", "ipm_iters")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64) if a.dtype == np.float64 else a
+
+
+def _scvx(model, emu_lib, schedule, K, B, maxit, pairs=0, stream=False):
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    alg.ctx.set_ipm_schedule(schedule, pairs)
+    x0 = model.randomized_initial_states(B, first=100)
+    if stream:
+        alg.solveStream(np.concatenate([x0, model.randomized_initial_states(B, first=300)]), slots=B, pools=2)
+        return alg.ctx.stream_download_rows()
+    alg.solve(x0)
+    return alg.getSolution()
+
+
+@pytest.mark.parametrize("K,B,maxit", [(8, 4, 5), (15, 3, 4)])
+def test_split_schedule_is_bitwise_the_resident_kernel_scvx(model, emu_lib, K, B, maxit):
+    ref = _scvx(model, emu_lib, _lib.IPM_RESIDENT, K, B, maxit)
+    ws = _scvx(model, emu_lib, _lib.IPM_RESIDENT_WS, K, B, maxit)
+    sp = _scvx(model, emu_lib, _lib.IPM_SPLIT, K, B, maxit)
+    assert ref["solves"].sum() > B * 2 and ref["ipm_iters"].min() > 10  # real work, incl. warm-started re-solves
+    for key in KEYS:
+        assert np.array_equal(_bits(ref[key]), _bits(ws[key])), ("workspace-resident segment fields", key)
+        assert np.array_equal(_bits(ref[key]), _bits(sp[key])), ("split schedule", key)
+
+
+def test_split_schedule_streaming_engine(model, emu_lib):
+    ref = _scvx(model, emu_lib, _lib.IPM_RESIDENT, 8, 4, 4, stream=True)
+    sp = _scvx(model, emu_lib, _lib.IPM_SPLIT, 8, 4, 4, stream=True)
+    assert ref.shape == sp.shape and np.array_equal(_bits(ref), _bits(sp))
+
+
+def test_split_schedule_sc_mode_two_column_factor_sweeps(model, emu_lib):
+    """SCAlgorithm mode (free final time): the factor sweep carries the sigma border column, the spec travels through the resume block"""
+    outs = []
+    for schedule in (_lib.IPM_RESIDENT, _lib.IPM_SPLIT):
+        alg = scpp_amd.SCAlgorithm(model, K=8, batch_max=3, library=emu_lib).initialize()
+        alg.ctx.set_ipm_schedule(schedule)
+        alg.solve(model.randomized_initial_states(3, first=7))
+        outs.append(alg.getSolution())
+    for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "converged", "status", "ipm_iters"):
+        assert np.array_equal(_bits(outs[0][key]), _bits(outs[1][key])), key
+    assert outs[0]["ipm_iters"].min() > 20
+
+
+def test_split_schedule_argument_checks(model, emu_lib):
+    ctx = scpp_amd.Context(K=8, batch_max=2, library=emu_lib)
+    for bad in ((-1, 0), (3, 0), (1, -1)):
+        with pytest.raises(scpp_amd.ScppHipError):
+            ctx.set_ipm_schedule(*bad)
+    ctx.set_ipm_schedule(_lib.IPM_SPLIT, 7)
+    ctx.set_ipm_schedule(_lib.IPM_RESIDENT)
