@@ -251,6 +251,20 @@ extern "C"
     int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_scvx_opts *opts,
                                             const double *x_init /* [N][6] dimensional */, int N, int slots, int pools,
                                             int *n_converged);
+    /* Engine of scpp_hip_scvx_solve_stream.  The result rows are bitwise the same with either (every instance's arithmetic is identical):
+         SCPP_STREAM_POOLS       rounds of four launches per slot pool (refill, multipleShooting, sub-problem solve, cost + accept / reject);
+         SCPP_STREAM_PERSISTENT  ONE launch: a wavefront per slot takes instance after instance through the whole of SCvxAlgorithm::solve
+                                 (csrc/scvx_persistent.h); `pools` is ignored.  RocketQuat with first-order hold; other configurations
+                                 run the pool engine whatever is set. */
+#define SCPP_STREAM_POOLS 0
+#define SCPP_STREAM_PERSISTENT 1
+#ifndef SCPP_STREAM_ENGINE_DEFAULT
+#define SCPP_STREAM_ENGINE_DEFAULT SCPP_STREAM_POOLS
+#endif
+    int scpp_hip_set_stream_engine(scpp_hip_ctx *ctx, int engine);
+    /* wavefront time of the last persistent job per step, summed over wavefronts (s_memtime ticks): refill, multipleShooting, sub-problem
+       solve, cost + accept / reject; zeros after a pool-engine job */
+    int scpp_hip_stream_profile(scpp_hip_ctx *ctx, double *ticks /* [4] */);
     int scpp_hip_stream_rows(scpp_hip_ctx *ctx, void **rows, int *row_doubles, int *n);
     int scpp_hip_stream_download(scpp_hip_ctx *ctx, double *rows /* [count][K*18+10] */, int first, int count);
     int scpp_hip_stream_info(scpp_hip_ctx *ctx, long long *rounds_enqueued, int *pools_used); /* diagnostics of the last job */

@@ -7,6 +7,7 @@ import numpy as np
 MODEL_ROCKETQUAT, MODEL_ROCKET2D = 0, 1
 MODE_FOH, MODE_VT = 1, 2
 IPM_RESIDENT, IPM_SPLIT, IPM_RESIDENT_WS = 0, 1, 2
+STREAM_POOLS, STREAM_PERSISTENT = 0, 1
 # include/scpp_hip.h: return codes, and the per-instance status of an SCvx run retired in the reference's exit-less reject loop
 E_ARG, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4
 # What this binding was written against.  load_library() asks the library for ITS values (scpp_hip_query) and refuses one that disagrees: the
@@ -125,7 +126,7 @@ _lib_path = None
 
 SYMBOLS = [
     "scpp_hip_create", "scpp_hip_destroy", "scpp_hip_version", "scpp_hip_query", "scpp_hip_set_flow_params", "scpp_hip_upload_traj", "scpp_hip_upload_traj_zoh",
-    "scpp_hip_discretize", "scpp_hip_set_discretization_steps", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_set_ipm_schedule", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
+    "scpp_hip_discretize", "scpp_hip_set_discretization_steps", "scpp_hip_download_dd", "scpp_hip_simulate", "scpp_hip_set_socp_opts", "scpp_hip_set_ipm_schedule", "scpp_hip_set_stream_engine", "scpp_hip_stream_profile", "scpp_hip_sc_setup", "scpp_hip_sc_setup_rocket2d",
     "scpp_hip_sc_set_active", "scpp_hip_sc_iterate", "scpp_hip_sc_solve", "scpp_hip_sc_finish", "scpp_hip_scvx_setup", "scpp_hip_scvx_solve", "scpp_hip_scvx_download_state", "scpp_hip_socp_solve", "scpp_hip_download", "scpp_hip_download_socp_info",
     "scpp_hip_get_timing", "scpp_hip_device_ptrs", "scpp_hip_synchronize",
     "scpp_hip_mpc_setup", "scpp_hip_mpc_get_model", "scpp_hip_mpc_solve", "scpp_hip_mpc_download", "scpp_hip_mpc_sim",
@@ -223,6 +224,16 @@ class Context:
         else:
             assert U.shape[1] == self.K
             _chk(self.lib.scpp_hip_upload_traj(self.h, _p(X), _p(U), _p(sigma), int(self.B)), "upload_traj")
+
+    def set_stream_engine(self, engine):
+        """scpp_hip_set_stream_engine: STREAM_POOLS (0: rounds of launches per slot pool) or STREAM_PERSISTENT (1: one launch, a wavefront per slot)"""
+        _chk(self.lib.scpp_hip_set_stream_engine(self.h, int(engine)), "set_stream_engine")
+
+    def stream_profile(self):
+        """per-step wavefront ticks of the last persistent job: refill, multipleShooting, sub-problem solve, cost + accept / reject"""
+        t = np.zeros(4)
+        _chk(self.lib.scpp_hip_stream_profile(self.h, _p(t)), "stream_profile")
+        return dict(zip(("refill", "discretize", "solve", "cost"), t.tolist()))
 
     def set_ipm_schedule(self, schedule, split_pairs=0):
         """scpp_hip_set_ipm_schedule: IPM_RESIDENT (0), IPM_SPLIT (1: two kernels per interior-point iteration), IPM_RESIDENT_WS (2)"""

@@ -86,13 +86,14 @@ struct DiscLayout
 
 // X [B][K][NX], U [B][K][NU] (FOH) , sigma [B], par [B][NP]  ->  A [B][K-1][NX][NX], Bm, C [B][K-1][NX][NU],
 // S, Z [B][K-1][NX]   (row-major blocks).  active[B] (may be null): skip instances with active == 0.
+// The integration of ONE segment by one wavefront: the body of discretize_kernel, and of the discretisation step of the persistent SCvx
+// kernel (scvx_persistent.h), where one wavefront walks through the K - 1 segments of its instance.
 template <class Model, bool FOH, bool VT>
-__global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
-    discretize_kernel(int B, int K, const double *__restrict__ X, const double *__restrict__ U,
-                      const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
-                      const int *__restrict__ active,
-                      double *__restrict__ Aout, double *__restrict__ Bout, double *__restrict__ Cout,
-                      double *__restrict__ Sout, double *__restrict__ Zout, int steps_opt)
+__device__ __forceinline__ void discretizeSegment(int B, int K, const double *__restrict__ X, const double *__restrict__ U,
+                                                  const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
+                                                  const int *__restrict__ active, double *__restrict__ Aout, double *__restrict__ Bout,
+                                                  double *__restrict__ Cout, double *__restrict__ Sout, double *__restrict__ Zout, int steps_opt,
+                                                  const long inst, const int k)
 {
     using L = DiscLayout<Model, FOH, VT>;
     constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
@@ -125,13 +126,7 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     const int lane = threadIdx.x;
     for (int i = lane; i < 32 * NX + 2; i += WAVE)
         Ys[i] = 0.;
-    // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
-    // give one XCD all K-1 segments of an instance (they re-read the same X/U/par lines).
     const int nseg = K - 1;
-    const long b = blockIdx.x;
-    const long xcd = b & 7, gb = b >> 3;
-    const long inst = (gb / nseg) * 8 + xcd;
-    const int k = int(gb % nseg);
     if (inst >= B)
         return;
     if (active && active[inst] == 0)
@@ -554,6 +549,24 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
             z -= Ys[L::COL_S * NX + lane] * sg;
         Zout[seg * NX + lane] = z;
     }
+}
+
+template <class Model, bool FOH, bool VT>
+__global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
+    discretize_kernel(int B, int K, const double *__restrict__ X, const double *__restrict__ U,
+                      const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
+                      const int *__restrict__ active,
+                      double *__restrict__ Aout, double *__restrict__ Bout, double *__restrict__ Cout,
+                      double *__restrict__ Sout, double *__restrict__ Zout, int steps_opt)
+{
+    // XCD-aware block -> (instance, segment) map: blocks b, b+8, b+16.. share an XCD (and its L2), so
+    // give one XCD all K-1 segments of an instance (they re-read the same X/U/par lines).
+    const int nseg = K - 1;
+    const long b = blockIdx.x;
+    const long xcd = b & 7, gb = b >> 3;
+    const long inst = (gb / nseg) * 8 + xcd;
+    const int k = int(gb % nseg);
+    discretizeSegment<Model, FOH, VT>(B, K, X, U, sigma, par, par_stride, active, Aout, Bout, Cout, Sout, Zout, steps_opt, inst, k);
 }
 
 // Batched nonlinear propagation  x <- x(dt)  under first-order-hold input: replaces

@@ -2174,8 +2174,11 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     PUT_END();
 }
 
+// `late`: where the tail re-reads the KernelArgs from -- the kernel-argument segment (constant memory).  The builtin that returns that
+// segment's address is only valid in the KERNEL function (in a callee the compiler folds it to null): kernels pass kernelArgsLate() down.
 #ifdef SCPP_HIP_EMU
-#define KERNEL_TAIL_ARGS(t, a) const KernelArgs &t = a
+typedef const KernelArgs ConstKernelArgs;
+#define KERNEL_TAIL_ARGS(t, a, late) const KernelArgs &t = a
 #else
 typedef const __attribute__((address_space(4))) KernelArgs ConstKernelArgs;
 __device__ inline ConstKernelArgs *kernelArgsLate()
@@ -2184,7 +2187,12 @@ __device__ inline ConstKernelArgs *kernelArgsLate()
     asm volatile("" : "+s"(p));                                                      // opaque: the loads stay where they are used
     return p;
 }
-#define KERNEL_TAIL_ARGS(t, a) ConstKernelArgs &t = *kernelArgsLate()
+__device__ inline ConstKernelArgs *opaqueArgs(ConstKernelArgs *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define KERNEL_TAIL_ARGS(t, a, late) ConstKernelArgs &t = *opaqueArgs(late)
 #endif
 #ifndef IPM_WAVES_PER_SIMD
 #define IPM_WAVES_PER_SIMD 2
@@ -2196,8 +2204,11 @@ __device__ inline ConstKernelArgs *kernelArgsLate()
 #define PROF_T(var)
 #define PROF_ADD(slot, t0, t1)
 #endif
+// One whole sub-problem solve of instance `inst` by the calling wavefront: the body of ipm_kernel and of the solve step of the persistent
+// SCvx kernel (scvx_persistent.h).  The tail re-reads its arguments from the kernel-argument segment (KERNEL_TAIL_ARGS): every kernel that
+// calls this takes its KernelArgs as the FIRST kernel parameter.
 template <class P>
-__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disable_tail_calls)) ipm_kernel(KernelArgs a)
+__device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int inst, ConstKernelArgs *late)
 {
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;
@@ -2205,7 +2216,6 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
     double prof[12] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
     const long long t_kernel0 = clock64();
 #endif
-    const int inst = blockIdx.x;
     if (inst >= a.B)
         return;
     if (a.active && a.active[inst] == 0)
@@ -2430,7 +2440,7 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
     // =============== outputs: readSolution + SC bookkeeping ===============
     // The output pointers are re-read from the kernel-argument segment here instead of being carried (as spilled SGPRs) across
     // the whole solve: nothing below the main loop keeps a kernel argument alive above it.
-    KERNEL_TAIL_ARGS(t, a);
+    KERNEL_TAIL_ARGS(t, a, late);
     const bool vst = k < K;
     const SV st = makeSV(c.st, L::STREC, unsigned(vst ? k : 0), c.pitch);
     // W / delta to report: the current iterate, or the restored best one (use_backup)
@@ -2526,6 +2536,15 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         else
             t.status[inst] = status;
     }
+}
+template <class P>
+__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disable_tail_calls)) ipm_kernel(KernelArgs a)
+{
+#ifdef SCPP_HIP_EMU
+    ipmSolveInstance<P>(a, blockIdx.x, &a);
+#else
+    ipmSolveInstance<P>(a, blockIdx.x, kernelArgsLate());
+#endif
 }
 
 } // namespace ipm

@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
     }
     iter = iter_total;
     // =============== outputs: readSolution + SC bookkeeping (ipm_kernel's tail, statement for statement) ===============
-    KERNEL_TAIL_ARGS(t, a);
+    KERNEL_TAIL_ARGS(t, a, kernelArgsLate());
     const bool vst = k < K;
     const SV st = makeSV(c.st, L::STREC, unsigned(vst ? k : 0), c.pitch);
     const int fW = use_backup ? int(L::F_WBK) : int(L::F_W);

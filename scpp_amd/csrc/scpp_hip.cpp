@@ -19,6 +19,7 @@
 #include "model_rocketquat.h"
 #include "sc_kernels.h"
 #include "scvx_kernels.h"
+#include "scvx_persistent.h"
 #include "mpc_kernel.h"
 #include "mpc_setup.h"
 
@@ -91,6 +92,9 @@ struct scpp_hip_ctx
     int last_active = 0;
     long long stream_rounds = 0; // rounds enqueued by the last streaming job (diagnostics)
     int stream_pools = 0;
+    int stream_engine = SCPP_STREAM_ENGINE_DEFAULT; // SCPP_STREAM_POOLS / SCPP_STREAM_PERSISTENT (scpp_hip_set_stream_engine)
+    double *persist_shares = nullptr;               // [8] device: per-step wavefront ticks of the last persistent job
+    unsigned long long stream_ticks[4] = {0, 0, 0, 0};
     int ipm_schedule = SCPP_IPM_SCHEDULE_DEFAULT; // SCPP_IPM_RESIDENT / SCPP_IPM_SPLIT / SCPP_IPM_RESIDENT_WS (scpp_hip_set_ipm_schedule)
     int ipm_split_pairs = 0;                      // (factor, rest) launch pairs per solve of the split schedule; 0 = the worst case 2 maxit + 1
     int disc_steps = 5; // RKF78 steps per segment: 5 = the reference's fixed count (default since round 4), 1 .. 4 pinned, 0 = discretize_kernel.h's step-length rule (opt-in)
@@ -330,7 +334,7 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
     return b;
 }
 
-int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0, bool snapshot = false)
+ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r, bool snapshot)
 {
     ipm::KernelArgs a;
     const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1, nx = size_t(c->nx), nu = size_t(c->nu);
@@ -371,6 +375,12 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
     a.opt.maxit = c->socp.maxit;
     a.opt.use_mfma = c->socp.use_mfma;
     a.dbg = c->dbg + f * 32;
+    return a;
+}
+int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0, bool snapshot = false)
+{
+    const ipm::KernelArgs a = ipmArgs(c, do_sc_update, masked, r, snapshot);
+    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
     const bool timed = spanBegin(c, 1, ninst, r.stream);
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
     // one instantiation of the solver per model table (csrc/constraint_table.h)
@@ -580,6 +590,9 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     if (const char *e = std::getenv("SCPP_IPM_SCHEDULE"))
         if (std::atoi(e) >= SCPP_IPM_RESIDENT && std::atoi(e) <= SCPP_IPM_SPLIT)
             c->ipm_schedule = std::atoi(e);
+    if (const char *e = std::getenv("SCPP_STREAM_ENGINE"))
+        if (std::atoi(e) == SCPP_STREAM_POOLS || std::atoi(e) == SCPP_STREAM_PERSISTENT)
+            c->stream_engine = std::atoi(e);
     if (const char *e = std::getenv("SCPP_IPM_SPLIT_PAIRS"))
         if (std::atoi(e) > 0)
             c->ipm_split_pairs = std::atoi(e);
@@ -657,7 +670,7 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
                     c->mpc_iters, c->mpc_steps, c->mpc_failed, c->mpc_ipm, c->mpc_reached};
     delete c->mpc_host;
     c->mpc_host = nullptr;
-    for (void *p : {(void *)c->q_xinit, (void *)c->q_rows, (void *)c->q_counters, (void *)c->q_slot_inst})
+    for (void *p : {(void *)c->q_xinit, (void *)c->q_rows, (void *)c->q_counters, (void *)c->q_slot_inst, (void *)c->persist_shares})
         if (p)
             (void)hipFree(p);
     if (c->h_poll)
@@ -798,6 +811,23 @@ int scpp_hip_set_discretization_steps(scpp_hip_ctx *c, int steps)
     if (!c || steps < 0 || steps > DISC_STEPS_MAX) // 5 = the reference (default), 0 = the step-length rule (opt-in), 1 .. 4 pinned
         return SCPP_E_ARG;
     c->disc_steps = steps;
+    return SCPP_OK;
+}
+
+int scpp_hip_set_stream_engine(scpp_hip_ctx *c, int engine)
+{
+    if (!c || (engine != SCPP_STREAM_POOLS && engine != SCPP_STREAM_PERSISTENT))
+        return SCPP_E_ARG;
+    c->stream_engine = engine;
+    return SCPP_OK;
+}
+
+int scpp_hip_stream_profile(scpp_hip_ctx *c, double *ticks)
+{
+    if (!c || !ticks)
+        return SCPP_E_ARG;
+    for (int i = 0; i < 4; i++)
+        ticks[i] = double(c->stream_ticks[i]);
     return SCPP_OK;
 }
 
@@ -1287,6 +1317,28 @@ int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scv
 {
     return scpp_hip_scvx_setup_rocket2d(c, mp, so, x, B, 0);
 }
+// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
+struct PersistRocketQuat : ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>
+{
+};
+// Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
+// caller runs the pool engine.
+int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
+                     const scpp_rocketquat_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
+{
+    if (!(c->mode & SCPP_MODE_FOH))
+        return -1;
+    const PersistentArgs<RefillRocketQuat> args{a, b, v, q, mp, sc, so, o};
+    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE), 0, c->stream,
+                       args);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+int launchPersistent(scpp_hip_ctx *, const ipm::KernelArgs &, const SCBuffers &, const SCvxBuffers &, const StreamQueue &,
+                     const scpp_rocket2d_params &, const scpp_sc_opts &, const scpp_scvx_opts &, const PersistentOut &, int)
+{
+    return -1;
+}
+
 template <class T>
 int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_scvx_opts *so, const double *x_init, int N, int slots,
                     int pools, int *n_converged)
@@ -1381,6 +1433,58 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     q.done = c->q_counters + 1;
     q.nconv = c->q_counters + 2;
     scpp_sc_opts sc = c->sc; // as built by scvx_setup
+    for (int i = 0; i < 4; i++)
+        c->stream_ticks[i] = 0;
+    if (c->stream_engine == SCPP_STREAM_PERSISTENT && so->max_iterations > 0)
+    {
+        // ONE launch: a wavefront per slot takes instance after instance through the whole SCvx loop (scvx_persistent.h)
+        if (!c->persist_shares && devAlloc(&c->persist_shares, 8))
+            return SCPP_E_HIP;
+        CHECK_HIP(hipMemsetAsync(c->persist_shares, 0, 8 * sizeof(double), c->stream));
+        Range r = fullRange(c);
+        r.count = S;
+        SCBuffers b = scBuffersRange(c, r);
+        b.B = S;
+        const SCvxBuffers v = scvxBuffersRange(c, r);
+        StreamQueue qp = q;
+        qp.slot_inst = c->q_slot_inst;
+        qp.warm = c->ipm_warm;
+        const ipm::KernelArgs a = ipmArgs(c, 0, true, r, true);
+        PersistentOut o;
+        o.A = c->A;
+        o.Bm = c->Bm;
+        o.C = c->C;
+        o.S = c->S;
+        o.Z = c->Z;
+        o.disc_steps = c->disc_steps;
+        o.shares = c->persist_shares;
+        const bool timed = spanBegin(c, 1, N, c->stream);
+        const int prc = launchPersistent(c, a, b, v, qp, *mp, sc, *so, o, S);
+        spanEnd(c, timed, c->stream);
+        if (prc >= 0)
+        {
+            int counters[4] = {0, 0, 0, 0};
+            auto bad = [&](int rc) {
+                (void)hipStreamSynchronize(c->stream);
+                c->q_N = 0;
+                return rc;
+            };
+            if (prc != 0)
+                return bad(prc);
+            if (hipMemcpyAsync(counters, c->q_counters, sizeof counters, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(c->stream_ticks, c->persist_shares, sizeof c->stream_ticks, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess)
+                return bad(SCPP_E_HIP);
+            c->stream_rounds = 1;
+            c->stream_pools = 0; // no pools: one persistent launch
+            c->last_active = 0;
+            if (n_converged)
+                *n_converged = counters[2];
+            if (counters[1] != N)
+                return bad(SCPP_E_STATE);
+            return SCPP_OK;
+        }
+    }
     // an instance needs at most max_iterations accepted + ~log2 rejected solves each; the queue drains in ceil(N/S) waves
     const long per_instance = long(so->max_iterations) * (SCVX_SOLVE_CAP + 1) + 8; // retired at the cap on a rejection (scvxDecide) + the accepted solves after it
     const long max_rounds = per_instance * ((N + S - 1) / S + 1);

@@ -161,11 +161,10 @@ __device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const
 #define COST_WAVES_PER_SIMD 1
 #endif
 template <class Model>
-__global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
+__device__ __forceinline__ void scvxCostUpdate(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, const long i)
 {
     using namespace ipm;
     constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP;
-    const long i = blockIdx.x;
     if (i >= b.B || b.active[i] == 0)
         return;
     const int K = b.K, k = threadIdx.x;
@@ -237,6 +236,11 @@ __global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_ke
             b.U[i * K * NU + e] = v.Uold[i * K * NU + e];
     }
 }
+template <class Model>
+__global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
+{
+    scvxCostUpdate<Model>(b, v, so, blockIdx.x);
+}
 
 // ---------------------------------------------------------------- streaming engine
 // result row of one instance (doubles): X [K][nx], U [K][nu] (dimensional), then the scalars below
@@ -297,12 +301,11 @@ struct RefillRocket2d
 // One wavefront per slot, at the top of every round: harvest a terminated instance (redimensionalised row -> rows[inst]),
 // then pull the next instance id off the queue and run its cold start (the model's set-up + scvxSetupOne).
 template <class T>
-__global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, SCvxBuffers v, StreamQueue q, typename T::Params mp,
-                                                                   scpp_sc_opts sc, scpp_scvx_opts so)
+__device__ __forceinline__ void scvxStreamRefill(const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q, const typename T::Params &mp,
+                                                 const scpp_sc_opts &sc, const scpp_scvx_opts &so, const long slot)
 {
     using namespace ipm;
     constexpr int NX = T::NX, NU = T::NU;
-    const long slot = blockIdx.x;
     if (slot >= b.B || b.active[slot] != 0)
         return;
     const int K = b.K, lane = threadIdx.x;
@@ -361,6 +364,12 @@ __global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, S
         __threadfence();
         atomicAdd(q.done, 1); // after the row is complete
     }
+}
+template <class T>
+__global__ void __launch_bounds__(WAVE) scvx_stream_refill_kernel(SCBuffers b, SCvxBuffers v, StreamQueue q, typename T::Params mp,
+                                                                   scpp_sc_opts sc, scpp_scvx_opts so)
+{
+    scvxStreamRefill<T>(b, v, q, mp, sc, so, blockIdx.x);
 }
 
 } // namespace scpp

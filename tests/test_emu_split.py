@@ -66,3 +66,27 @@ def test_split_schedule_argument_checks(model, emu_lib):
             ctx.set_ipm_schedule(*bad)
     ctx.set_ipm_schedule(_lib.IPM_SPLIT, 7)
     ctx.set_ipm_schedule(_lib.IPM_RESIDENT)
+
+
+@pytest.mark.parametrize("K,N,S,maxit", [(8, 7, 3, 4), (15, 5, 2, 3)])
+def test_persistent_stream_engine_rows_are_bitwise_the_pool_engine(model, emu_lib, K, N, S, maxit):
+    """scpp_hip_set_stream_engine(SCPP_STREAM_PERSISTENT): ONE launch, a wavefront per slot walks its instances through refill ->
+    multipleShooting of every segment -> sub-problem solve -> cost / accept / reject (csrc/scvx_persistent.h).  Same bodies, same order, same
+    buffers as the pool engine's four kernels per round: every result row must be bitwise the pool engine's, and the batch entry point's."""
+    x0 = model.randomized_initial_states(N, first=40)
+    rows = []
+    for engine in (_lib.STREAM_POOLS, _lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=emu_lib, max_iterations=maxit).initialize()
+        alg.ctx.set_stream_engine(engine)
+        n = alg.solveStream(x0, slots=S, pools=2)
+        r = alg.ctx.stream_download_rows()
+        assert n == int(scpp_amd.Context.unpack_stream_rows(r, K)["converged"].sum())
+        rows.append(r)
+    assert rows[0].shape == rows[1].shape == (N, K * 18 + 10) and np.array_equal(_bits(rows[0]), _bits(rows[1]))
+    got = scpp_amd.Context.unpack_stream_rows(rows[1], K)
+    assert (got["instance"] == np.arange(N)).all() and got["solves"].sum() > 2 * N
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=emu_lib, max_iterations=maxit).initialize()
+    alg.solve(x0)
+    ref = alg.getSolution()
+    for key in KEYS:
+        assert np.array_equal(_bits(got[key]), _bits(ref[key])), key

@@ -43,7 +43,7 @@ def short(name):
 
 def stats(path, flt):
     for name, body in functions(path).items():
-        if "3ipm" not in name or (flt and flt not in name):
+        if ("3ipm" not in name and "--all" not in sys.argv) or (flt and flt not in name):
             continue
         ins = instructions(body)
         st = ld = issued = done = last_rt = rts = 0
