@@ -42,6 +42,7 @@ FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border (cold s
 IPM_ALGO_BYTES_PER_SOLVE = 131712 + 7208 + 7200  # read dd + td, write X, U: what one sub-problem solve must move
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
 DISC_FLOP_PER_RHS = 18.6e3        # one evaluation of the augmented right-hand side (J V on the matrix core + flow map + Jacobian rows)
+COST_FLOP_PER_SOLVE = 3.3e6       # getNonlinearCost of one candidate: 49 segments x 20 RKF78 steps x 13 stages x (flow map ~150 flop + stage combination)
 DISC_MAX_STEP = 12.0 / (14.0 * 5.0)  # csrc/discretize_kernel.h, opt-in rule: n = clamp(ceil(segment seconds / this), 1, 5) RKF78 steps per segment
 PEAK_FP64_TFLOPS = 78.6           # MI355X FP64 vector == FP64 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
@@ -333,6 +334,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = ctx.timing(reset=True)
     rounds = ctx.stream_rounds() if hasattr(ctx, "stream_rounds") else None
+    stream_profile = ctx.stream_profile()  # per-step wavefront ticks of the persistent engine (zeros after a pool-engine job)
 
     total = x_timed.shape[0]
     local = np.array([nconv, total, int(out["sc_iters"].sum()), int(out["solves"].sum()), int(out["ipm_iters"].sum()),
@@ -364,6 +366,45 @@ def main():
             np.save(args.dump, gathered.cpu().numpy() if gathered is not None else ctx.stream_download_rows())
 
     extras = {}
+    if rank == 0:
+        # ---- what "converged" buys (north_star: "final virtual-control norm reported").  The reference's test is |dL| < change_threshold
+        # (SCvxAlgorithm.cpp:125) and nothing else: it does NOT ask for nu -> 0, and a shrinking trust radius makes dL small.  Reported: how many converged
+        # runs also meet the SC mode's nu_tol (1e-5), where the radius ended, and -- on the product's own simulate kernel, in SI units -- how far the
+        # nonlinear propagation of a returned trajectory lands from its own next node. ----
+        try:
+            cv = out["converged"] == 1
+            nu_c = out["nu_norm"][cv]
+            tr_c = out["trust_region"][cv]
+            meaning = {
+                "convergence_test": "|dL| < change_threshold = 1e-3 (SCvxAlgorithm.cpp:125), the reference's only test",
+                "converged_with_final_nu_norm1_below_1e-5": float((nu_c < 1e-5).mean()) if nu_c.size else None,
+                "final_nu_norm1_percentiles_5_50_95": [float(v) for v in np.percentile(nu_c, [5, 50, 95])] if nu_c.size else None,
+                "final_trust_radius_percentiles_5_50_95": [float(v) for v in np.percentile(tr_c, [5, 50, 95])] if tr_c.size else None,
+                "initial_trust_radius": float(alg.opts.trust_region),
+                "median_scvx_iterations_of_converged": float(np.median(out["sc_iters"][cv])) if cv.any() else None,
+            }
+            ns = int(min(128, cv.sum(), max(1, B // (K - 1))))
+            if ns > 0 and on_gpu:
+                idx = np.flatnonzero(cv)[:ns]
+                Xs, Us = out["X"][idx], out["U"][idx]           # dimensional (SI) trajectories as returned
+                sim = scpp_amd.Context(K=K, batch_max=ns * (K - 1), device=dev_index, library=args.library)
+                sim.set_flow_params(np.tile(model.flow_params(nondimensionalize=False), (ns * (K - 1), 1)))
+                dts = np.repeat(out["sigma"][idx] / (K - 1), K - 1)
+                xp = sim.simulate(dts, Us[:, :-1].reshape(-1, 4), Us[:, 1:].reshape(-1, 4), Xs[:, :-1].reshape(-1, 14)).reshape(ns, K - 1, 14)
+                sim.close()
+                d = xp - Xs[:, 1:]
+                pos = np.linalg.norm(d[:, :, 1:4], axis=2).max(axis=1)
+                vel = np.linalg.norm(d[:, :, 4:7], axis=2).max(axis=1)
+                meaning["dimensional_defect_of_returned_trajectories"] = {
+                    "sample": f"the first {ns} converged instances, every segment propagated with scpp_hip_simulate (RKF78 x 20, first-order hold) in SI units",
+                    "median_over_instances_of_max_position_defect_m": float(np.median(pos)),
+                    "p95_max_position_defect_m": float(np.percentile(pos, 95)),
+                    "median_over_instances_of_max_velocity_defect_m_per_s": float(np.median(vel)),
+                    "median_descent_distance_m": float(np.median(np.linalg.norm(Xs[:, 0, 1:4], axis=1))),
+                }
+            extras["what_converged_means"] = meaning
+        except Exception as e:
+            extras["what_converged_means"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_extras:  # (single-GPU runs only: at N > 1 the other ranks would idle behind these legs)
         # ---- un-overlapped kernel times: the same engine with ONE slot pool (one stream), a 2-batch job ----
         try:
@@ -484,13 +525,35 @@ def main():
         ipm_iters0 = float(out["ipm_iters"].sum())
         socp_flops = ipm_iters0 * FLOP_PER_IPM_ITER + total * FLOP_PER_SOCP_INIT
         launches = max(tm["n_socp"], 1)
+        # engine of the timed job: the persistent kernel (ONE launch: refill + multipleShooting + solve + cost of every instance; the library's
+        # default for this configuration since round 5) reports no pools
+        persistent = bool(rounds) and rounds.get("pools", 1) == 0
+        disc_steps = 5  # the library default since round 4: the reference's fixed count (scpp_hip_set_discretization_steps)
+        DISC_FLOP_PER_INSTANCE = (K - 1) * 13 * disc_steps * DISC_FLOP_PER_RHS
+        disc_flops0 = float(out["sc_iters"].sum()) * DISC_FLOP_PER_INSTANCE
+        cost_flops0 = float(out["solves"].sum()) * COST_FLOP_PER_SOLVE
+        step_view = None
+        if persistent:
+            ticks = dict(stream_profile)
+            tsum = sum(ticks.values()) or 1.0
+            ksec = tm["ms_socp"] * 1e-3
+            step_view = {"definition": "share = the step's wavefront time (s_memtime ticks summed over wavefronts) / all steps'; a step's TFLOP/s = its algorithmic "
+                                       "flops / (kernel time x share): the rate it runs at while the chip's wavefront slots hold the measured mix of steps"}
+            for name, fl in (("solve", socp_flops), ("discretize", disc_flops0), ("cost", cost_flops0), ("refill", 0.0)):
+                sh = ticks.get(name, 0.0) / tsum
+                step_view[name] = {"share_of_wavefront_time": sh, "flops": fl, "Mcycles_per_trajectory": ticks.get(name, 0.0) / max(total, 1) / 1e6,
+                                   "fp64_TFLOPs_in_its_share": (fl / (ksec * sh) / 1e12) if (sh > 0 and ksec > 0) else None,
+                                   "fp64_frac_in_its_share": (fl / (ksec * sh) / 1e12 / PEAK_FP64_TFLOPS) if (sh > 0 and ksec > 0) else None}
+            socp_flops_all = socp_flops + disc_flops0 + cost_flops0
+        else:
+            socp_flops_all = socp_flops
         # kernel time = length of the UNION of the launches' hipEvent spans on a common time axis (launches of the slot pools
         # overlap in time: the plain sum of spans exceeds the wall clock).  By construction <= the timed region; asserted.
         span_sum_s = tm["ms_socp"] * 1e-3
         socp_s = tm.get("ms_socp_union", 0.0) * 1e-3 or span_sum_s
         assert socp_s <= dt * 1.001, f"ipm_kernel time {socp_s:.3f} s exceeds the timed region {dt:.3f} s"
-        achieved_tf = socp_flops / socp_s / 1e12 if socp_s > 0 else 0.0
-        achieved_tf_span_sum = socp_flops / span_sum_s / 1e12 if span_sum_s > 0 else 0.0
+        achieved_tf = socp_flops_all / socp_s / 1e12 if socp_s > 0 else 0.0
+        achieved_tf_span_sum = socp_flops_all / span_sum_s / 1e12 if span_sum_s > 0 else 0.0
         pmc = measured_traffic()
         traffic = None
         traffic_source = None
@@ -520,9 +583,9 @@ def main():
         limiting = ("hbm traffic of the workspace (measured bytes): %.0f GB/s = %.1f %% of peak, against %.1f %% of the FP64 matrix peak"
                     % (measured_gbs, 100 * hbm_frac, 100 * mfma_frac)) if (hbm_frac is not None and hbm_frac > mfma_frac) else "fp64 mfma"
         disc_s = tm.get("ms_discretize_union", 0.0) * 1e-3 or tm["ms_discretize"] * 1e-3
+        if persistent:  # no launches of its own: the step's share of the persistent kernel
+            disc_s = tm["ms_socp"] * 1e-3 * step_view["discretize"]["share_of_wavefront_time"]
         # flops the kernel EXECUTES: 13 stages x n steps per segment (the reference's scheme is n = 5 whatever K: 5.9e7 flop at K = 50)
-        disc_steps = 5  # the library default since round 4: the reference's fixed count (scpp_hip_set_discretization_steps)
-        DISC_FLOP_PER_INSTANCE = (K - 1) * 13 * disc_steps * DISC_FLOP_PER_RHS
         # discretize launches are masked (needs_disc): instances that re-solve after a rejection skip it, so count solves
         line = {
             "metric": "converged SCvx trajectories/sec (RocketQuat, K=50) at 1/2/4/8 MI355X",
@@ -543,7 +606,10 @@ def main():
                             f"Falcon-9 model.info + SCvx.info",
                 "algorithm": "SCvxAlgorithm::solve, cold start per instance; converged = |dL| < change_threshold (SCvxAlgorithm.cpp:125); "
                              "multipleShooting with the reference's 5 RKF78 steps per segment (discretizationImplementation.hpp:141,154)",
-                "engine": f"scpp_hip_scvx_solve_stream: continuous batching over {B} resident slots per GPU, steps x batch instances queued",
+                "engine": (f"scpp_hip_scvx_solve_stream, persistent kernel (csrc/scvx_persistent.h): ONE launch per job, a wavefront per slot ({B} slots, "
+                           f"2048 resident) takes instance after instance through refill -> multipleShooting -> sub-problem solve -> cost / accept / reject; "
+                           f"steps x batch instances queued") if persistent else
+                          f"scpp_hip_scvx_solve_stream, pool engine: continuous batching over {B} resident slots per GPU in rounds of launches, steps x batch instances queued",
                 "global_batch": int(B * world),
                 "instances_timed": int(g_total),
                 "parallelism": (f"instance-sharded x{world}, no collective in the loop, {args.backend} all-gather of the result rows "
@@ -558,11 +624,15 @@ def main():
                 "median_final_virtual_control_norm1": float(np.median(out["nu_norm"])),
                 "median_final_nonlinear_defect": float(np.median(out["nonlinear_cost"])),
                 "rounds": rounds,
+                "stream_profile_ticks": stream_profile,
                 "parity": parity_summary(),
                 **extras,
             },
             "roofline": {
-                "kernel": "ipm_kernel (batched structured IPM, one wavefront per instance, block factorisations on v_mfma_f64_16x16x4_f64)",
+                "kernel": ("scvx_persistent_kernel (one launch per job; per instance and SCvx iteration: multipleShooting of 49 segments, the batched structured "
+                           "interior-point solve with block factorisations on v_mfma_f64_16x16x4_f64, the nonlinear cost of the candidate)") if persistent else
+                          "ipm_kernel (batched structured IPM, one wavefront per instance, block factorisations on v_mfma_f64_16x16x4_f64)",
+                "steps": step_view,
                 "bound": "mfma",  # the roof north_star prices the KKT factorisation against; see limiting_resource
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_TFLOPS,
@@ -573,14 +643,17 @@ def main():
                 "traffic_source": traffic_source,
                 "traffic_note": traffic_note,
                 "kernel_time_s": socp_s,
-                "kernel_time_definition": "union of the launches' hipEvent spans (exclusive wall time with >= 1 ipm_kernel in flight)",
+                "kernel_time_definition": "hipEvent span of the one persistent launch" if persistent else
+                                          "union of the launches' hipEvent spans (exclusive wall time with >= 1 ipm_kernel in flight)",
                 "timed_region_s": dt,
                 "exclusive_ms_per_launch": 1e3 * socp_s / launches,
                 "avg_launch_ms": tm["ms_socp"] / launches,  # average hipEvent span of one launch = what rocprofv3 --stats averages
                 "frac_of_span_sum": achieved_tf_span_sum / PEAK_FP64_TFLOPS,
                 "launches": tm["n_socp"],
                 "flop_model": f"{FLOP_PER_IPM_ITER:.2e} flop per IPM iteration x {ipm_iters0:.0f} measured IPM iterations + "
-                              f"{FLOP_PER_SOCP_INIT:.2e} per cold start x {total} instances (rank 0)",
+                              f"{FLOP_PER_SOCP_INIT:.2e} per cold start x {total} instances (rank 0)" +
+                              (f" + {DISC_FLOP_PER_INSTANCE:.2e} per multipleShooting call x {float(out['sc_iters'].sum()):.0f} calls + "
+                               f"{COST_FLOP_PER_SOLVE:.1e} per candidate cost x {float(out['solves'].sum()):.0f} solves" if persistent else ""),
                 "hbm_view": {
                     "algorithmic_bytes_per_launch": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / launches,
                     "algorithmic_GBs": IPM_ALGO_BYTES_PER_SOLVE * float(out["solves"].sum()) / socp_s / 1e9 if socp_s > 0 else None,
@@ -591,7 +664,8 @@ def main():
             },
             "kernels": {
                 "discretize": {
-                    "kernel": "discretize_kernel<RocketQuat,FOH,fixed time>",
+                    "kernel": "multipleShooting step of scvx_persistent_kernel (discretizeSegment<RocketQuat,FOH,fixed time>, the body of discretize_kernel)" if persistent
+                              else "discretize_kernel<RocketQuat,FOH,fixed time>",
                     "avg_launch_ms": tm["ms_discretize"] / max(tm["n_discretize"], 1),
                     "launches": tm["n_discretize"],
                     "instance_calls": g_iters / world,

@@ -253,13 +253,13 @@ extern "C"
                                             int *n_converged);
     /* Engine of scpp_hip_scvx_solve_stream.  The result rows are bitwise the same with either (every instance's arithmetic is identical):
          SCPP_STREAM_POOLS       rounds of four launches per slot pool (refill, multipleShooting, sub-problem solve, cost + accept / reject);
-         SCPP_STREAM_PERSISTENT  ONE launch: a wavefront per slot takes instance after instance through the whole of SCvxAlgorithm::solve
-                                 (csrc/scvx_persistent.h); `pools` is ignored.  RocketQuat with first-order hold; other configurations
-                                 run the pool engine whatever is set. */
+         SCPP_STREAM_PERSISTENT  (default) ONE launch: a wavefront per slot takes instance after instance through the whole of
+                                 SCvxAlgorithm::solve (csrc/scvx_persistent.h).  RocketQuat with first-order hold and `pools` = 0; an
+                                 explicit pool count, and every other configuration, runs the pool engine whatever is set. */
 #define SCPP_STREAM_POOLS 0
 #define SCPP_STREAM_PERSISTENT 1
 #ifndef SCPP_STREAM_ENGINE_DEFAULT
-#define SCPP_STREAM_ENGINE_DEFAULT SCPP_STREAM_POOLS
+#define SCPP_STREAM_ENGINE_DEFAULT SCPP_STREAM_PERSISTENT
 #endif
     int scpp_hip_set_stream_engine(scpp_hip_ctx *ctx, int engine);
     /* wavefront time of the last persistent job per step, summed over wavefronts (s_memtime ticks): refill, multipleShooting, sub-problem

@@ -86,6 +86,26 @@ struct DiscLayout
 
 // X [B][K][NX], U [B][K][NU] (FOH) , sigma [B], par [B][NP]  ->  A [B][K-1][NX][NX], Bm, C [B][K-1][NX][NU],
 // S, Z [B][K-1][NX]   (row-major blocks).  active[B] (may be null): skip instances with active == 0.
+// LDS of one segment integration (one wavefront): stage values, the per-stage-time table of the input, the operand vector of the Jacobian
+// table, the wave-uniform constants.  A struct, so that its home can be chosen by the caller: a __shared__ object of its own in
+// discretize_kernel, the dynamic LDS region it shares with the solver's LDS-resident segment fields in the persistent SCvx kernel (the two are
+// never live at the same time; 9.9 + 16.8 KB next to each other would cost that kernel three of its eight wavefronts per CU).
+template <class Model, bool FOH, bool VT>
+struct DiscLds
+{
+    using L = DiscLayout<Model, FOH, VT>;
+    __attribute__((aligned(16))) double Ys[32 * L::NX + 2];
+#ifdef DISC_AD_JACOBIAN
+    __attribute__((aligned(16))) double Jm[L::NX * L::NJP]; // [sigma*A | sigma*B] row-major
+    double fv[L::NX];                                       // f(x,u) (unscaled)
+    double cst[L::NP + 2 * L::NU + 1];
+#else
+    double uh[DISC_STEPS_MAX * RK_S * (Model::JacobianRows::NUAUX + 1 + L::NU)];
+    __attribute__((aligned(16))) double Wt[Model::JacobianTable::NW];
+    double cst[L::NP + 2 * L::NU + Model::JacobianRows::NAUX + 1];
+#endif
+};
+
 // The integration of ONE segment by one wavefront: the body of discretize_kernel, and of the discretisation step of the persistent SCvx
 // kernel (scvx_persistent.h), where one wavefront walks through the K - 1 segments of its instance.
 template <class Model, bool FOH, bool VT>
@@ -93,7 +113,7 @@ __device__ __forceinline__ void discretizeSegment(int B, int K, const double *__
                                                   const double *__restrict__ sigma, const double *__restrict__ par, int par_stride,
                                                   const int *__restrict__ active, double *__restrict__ Aout, double *__restrict__ Bout,
                                                   double *__restrict__ Cout, double *__restrict__ Sout, double *__restrict__ Zout, int steps_opt,
-                                                  const long inst, const int k)
+                                                  const long inst, const int k, DiscLds<Model, FOH, VT> *lds)
 {
     using L = DiscLayout<Model, FOH, VT>;
     constexpr int NX = L::NX, NU = L::NU, NP = L::NP, NJ = L::NJ, NJP = L::NJP, NCOLS = L::NCOLS, NG = L::NG, EPL = L::EPL;
@@ -102,9 +122,7 @@ __device__ __forceinline__ void discretizeSegment(int B, int K, const double *__
     // tiles; the contraction index runs to 16, so Ys is zero-filled once and padded to 32 columns), J' the B operand, taken
     // from the Jacobian row each lane holds in registers.  No staging, no extra synchronisation.
     static_assert(NX <= 16 && NCOLS + NG <= 32 && NG == 4, "one 16-row tile of states, two 16-column tiles of V");
-    __shared__ __attribute__((aligned(16))) double Ys[32 * NX + 2];
-    __shared__ __attribute__((aligned(16))) double Jm[NX * NJP];           // [sigma*A | sigma*B] row-major (-DDISC_AD_JACOBIAN only)
-    __shared__ double fv[NX];                                              // f(x,u) (unscaled)            (-DDISC_AD_JACOBIAN only)
+    auto &Ys = lds->Ys;
     // flow-map parameters and the segment's two input nodes: wave-uniform values that the 13x5 row evaluations need.
     // Kept in LDS and re-read inside every evaluation: held in registers across the stage loop they were
     // spilled to scratch, and their serialised reloads (11 round trips per evaluation) dominated the evaluation phase.
@@ -112,16 +130,18 @@ __device__ __forceinline__ void discretizeSegment(int B, int K, const double *__
     constexpr int NAUX = Model::JacobianRows::NAUX;   // parameter-only sub-expressions of the analytic rows
     constexpr int NUAUX = Model::JacobianRows::NUAUX; // input-only sub-expressions, tabulated per (step, stage)
     constexpr int UHP = NUAUX + 1 + NU;           // per stage time: input-only sub-expressions, t / dt, u(t)
-    __shared__ double uh[DISC_STEPS_MAX * RK_S * UHP];
+    auto &uh = lds->uh;
 #define DISC_TABLE_ROWS 1
     // Jacobian entries as a lane-parallel table (Model::JacobianTable): one output per lane per pass instead of one divergent
     // `case` per row; W holds the operands, the partial sums and the outputs [J | f]
     using TB = typename Model::JacobianTable;
-    __shared__ __attribute__((aligned(16))) double Wt[TB::NW];
+    auto &Wt = lds->Wt;
 #else
     constexpr int NAUX = 0;
+    auto &Jm = lds->Jm;
+    auto &fv = lds->fv;
 #endif
-    __shared__ double cst[NP + 2 * NU + NAUX + 1];
+    auto &cst = lds->cst;
 
     const int lane = threadIdx.x;
     for (int i = lane; i < 32 * NX + 2; i += WAVE)
@@ -566,7 +586,8 @@ __global__ void __launch_bounds__(WAVE, DISC_WAVES_PER_SIMD)
     const long xcd = b & 7, gb = b >> 3;
     const long inst = (gb / nseg) * 8 + xcd;
     const int k = int(gb % nseg);
-    discretizeSegment<Model, FOH, VT>(B, K, X, U, sigma, par, par_stride, active, Aout, Bout, Cout, Sout, Zout, steps_opt, inst, k);
+    __shared__ DiscLds<Model, FOH, VT> lds;
+    discretizeSegment<Model, FOH, VT>(B, K, X, U, sigma, par, par_stride, active, Aout, Bout, Cout, Sout, Zout, steps_opt, inst, k, &lds);
 }
 
 // Batched nonlinear propagation  x <- x(dt)  under first-order-hold input: replaces

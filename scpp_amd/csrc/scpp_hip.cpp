@@ -1318,7 +1318,7 @@ int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scv
     return scpp_hip_scvx_setup_rocket2d(c, mp, so, x, B, 0);
 }
 // the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
-struct PersistRocketQuat : ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>
+struct PersistRocketQuat : ipm::RocketQuatSC
 {
 };
 // Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
@@ -1329,8 +1329,10 @@ int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers 
     if (!(c->mode & SCPP_MODE_FOH))
         return -1;
     const PersistentArgs<RefillRocketQuat> args{a, b, v, q, mp, sc, so, o};
-    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE), 0, c->stream,
-                       args);
+    // dynamic LDS: the solver's LDS-resident segment fields during a solve, the integration's stage values / tables during multipleShooting
+    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, false>);
+    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE),
+                       seg_b > disc_b ? seg_b : disc_b, c->stream, args);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 int launchPersistent(scpp_hip_ctx *, const ipm::KernelArgs &, const SCBuffers &, const SCvxBuffers &, const StreamQueue &,
@@ -1435,7 +1437,8 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     scpp_sc_opts sc = c->sc; // as built by scvx_setup
     for (int i = 0; i < 4; i++)
         c->stream_ticks[i] = 0;
-    if (c->stream_engine == SCPP_STREAM_PERSISTENT && so->max_iterations > 0)
+    // (an explicit pool count -- argument or SCPP_STREAM_POOLS -- asks for the pool engine)
+    if (c->stream_engine == SCPP_STREAM_PERSISTENT && pools == 0 && !std::getenv("SCPP_STREAM_POOLS") && so->max_iterations > 0)
     {
         // ONE launch: a wavefront per slot takes instance after instance through the whole SCvx loop (scvx_persistent.h)
         if (!c->persist_shares && devAlloc(&c->persist_shares, 8))

@@ -129,9 +129,17 @@ PERSIST_STEP_FN void persistDiscretize(long slot)
     const int B = A.b.B, K = A.b.K, steps = A.o.disc_steps;
     const double *X = A.a.X, *U = A.a.U, *sigma = A.a.sigma, *par = A.b.ip + ipm::IP_PAR;
     double *Ao = A.o.A, *Bo = A.o.Bm, *Co = A.o.C, *So = A.o.S, *Zo = A.o.Z;
+    // the integration's LDS is the dynamic region the solver's LDS-resident segment fields use during a solve (never live together)
+#ifdef SCPP_HIP_EMU
+    static DiscLds<Model, FOH, false> lds_obj;
+    DiscLds<Model, FOH, false> *lds = &lds_obj;
+#else
+    extern __shared__ double seg_lds[];
+    DiscLds<Model, FOH, false> *lds = reinterpret_cast<DiscLds<Model, FOH, false> *>(seg_lds);
+#endif
     for (int k = 0; k < K - 1; k++)
     {
-        discretizeSegment<Model, FOH, false>(B, K, X, U, sigma, par, ipm::IP_N, nullptr, Ao, Bo, Co, So, Zo, steps, slot, k);
+        discretizeSegment<Model, FOH, false>(B, K, X, U, sigma, par, ipm::IP_N, nullptr, Ao, Bo, Co, So, Zo, steps, slot, k, lds);
         WAVE_SYNC(); // the segment's last LDS reads before the next segment's first writes
     }
     stepFence();

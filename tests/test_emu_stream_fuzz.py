@@ -86,6 +86,15 @@ def _stream_case(emu_lib, tmp_path, case):
     assert n == nref and (o["instance"] == np.arange(N)).all()
     for key in KEYS:
         assert np.array_equal(o[key], r[key]), (case, key)
+    # pools = 0: the default engine -- the persistent kernel (csrc/scvx_persistent.h: one launch, a wavefront per slot) where it is
+    # instantiated (RocketQuat, first-order hold), the pool engine with its default pool count elsewhere -- on the same context, after the
+    # pool job: the same rows again
+    n0 = alg.solveStream(x0, slots=slots, pools=0)
+    o0 = alg.getStreamSolution()
+    assert alg.ctx.stream_rounds()["pools"] == (0 if (model == "RocketQuat" and foh) else 1)
+    assert n0 == nref and (o0["instance"] == np.arange(N)).all()
+    for key in KEYS:
+        assert np.array_equal(o0[key], r[key]), (case, key, "default engine")
     # a second job on the same context (buffers re-used, queue counters reset) gives the same rows again
     if i % 3 == 0:
         n2 = alg.solveStream(x0[::-1].copy(), slots=slots, pools=pools)

@@ -345,6 +345,7 @@ def test_scvx_stream_default_pools_at_bench_size_on_gpu(model, hip_lib):
     K, N, S = 50, 4608, 4096
     x0 = model.randomized_initial_states(N, first=40_000)
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=hip_lib).initialize()
+    alg.ctx.set_stream_engine(scpp_amd._lib.STREAM_POOLS)  # (the default engine, the persistent kernel: next test)
     n = alg.solveStream(x0, slots=S, pools=0)
     o = alg.getStreamSolution()
     assert alg.ctx.stream_rounds()["pools"] == 3
@@ -359,18 +360,23 @@ def test_scvx_stream_default_pools_at_bench_size_on_gpu(model, hip_lib):
     alg.ctx.close()
 
 
-def test_scvx_stream_bench_configuration_on_gpu(model, hip_lib):
-    """the configuration bench.py TIMES -- 8192 resident slots, pools = 0 -> six pools (4 x 1368 + 2 x 1360
-    slots) on their own HIP streams, refill kernels of six streams sharing the queue atomics, more instances than slots so that
-    every pool refills -- against the batch entry point: 10240 instances; 640 sampled rows (the first 256, 256 spread over the job,
-    the last 128 = refilled slots) must be bitwise what scpp_hip_scvx_solve computes for them; every row is checked for order,
-    status and the converged count."""
+@pytest.mark.parametrize("engine", ["persistent", "pools"])
+def test_scvx_stream_bench_configuration_on_gpu(model, hip_lib, engine):
+    """the configuration bench.py TIMES -- 8192 resident slots, pools = 0, more instances than slots so that every slot
+    refills -- against the batch entry point, for BOTH engines: the persistent kernel (round 5, the default: one launch, a wavefront per slot
+    walks its instances through refill -> multipleShooting -> solve -> cost / accept / reject, csrc/scvx_persistent.h) and the pool engine
+    (six pools of 1368 / 1360 slots on their own HIP streams).  10240 instances; 640 sampled rows (the first 256, 256 spread over the job, the
+    last 128 = refilled slots) must be bitwise what scpp_hip_scvx_solve computes for them; every row is checked for order, status and the
+    converged count."""
     K, N, S = 50, 10240, 8192
     x0 = model.randomized_initial_states(N, first=700_000)
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=hip_lib).initialize()
+    alg.ctx.set_stream_engine(scpp_amd._lib.STREAM_PERSISTENT if engine == "persistent" else scpp_amd._lib.STREAM_POOLS)
     n = alg.solveStream(x0, slots=S, pools=0)
     o = alg.getStreamSolution()
-    assert alg.ctx.stream_rounds()["pools"] == 6
+    assert alg.ctx.stream_rounds()["pools"] == (0 if engine == "persistent" else 6)
+    prof = alg.ctx.stream_profile()
+    assert (prof["solve"] > prof["discretize"] > prof["cost"] > 0) if engine == "persistent" else (sum(prof.values()) == 0)
     assert (o["instance"] == np.arange(N)).all() and (o["status"] == 0).all()
     assert n == int(o["converged"].sum()) and n >= 0.95 * N
     sample = np.unique(np.concatenate([np.arange(256), np.linspace(256, N - 129, 256).astype(int), np.arange(N - 128, N)]))
@@ -379,9 +385,30 @@ def test_scvx_stream_bench_configuration_on_gpu(model, hip_lib):
     assert nb == int(o["converged"][sample].sum())
     for key in ("X", "U", "sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status", "ipm_iters"):
         assert np.array_equal(o[key][sample], r[key]), key
-    print("bench configuration (8192 slots, six pools, 10240 instances): %d sampled rows bitwise equal to the batch entry point; %d converged"
-          % (len(sample), n))
+    print("bench configuration (8192 slots, %s engine, 10240 instances): %d sampled rows bitwise equal to the batch entry point; %d converged"
+          % (engine, len(sample), n))
     alg.ctx.close()
+
+
+def test_persistent_engine_rows_equal_pool_engine_on_gpu(model, hip_lib):
+    """Every row of a job, not a sample: 3000 instances through 1024 slots, persistent kernel against pool engine, the whole row block bitwise
+    (trajectories, scalars, counters); and a second job on the same context (stale queue / slot state of the first must not leak)."""
+    K, N, S = 50, 3000, 1024
+    x0 = model.randomized_initial_states(N, first=5000)
+    rows = {}
+    for engine in (scpp_amd._lib.STREAM_POOLS, scpp_amd._lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=hip_lib).initialize()
+        alg.ctx.set_stream_engine(engine)
+        alg.solveStream(x0, slots=S)
+        rows[engine] = alg.ctx.stream_download_rows()
+        if engine == scpp_amd._lib.STREAM_PERSISTENT:
+            alg.solveStream(x0[::-1].copy(), slots=S // 2)
+            again = alg.ctx.stream_download_rows()
+            assert np.array_equal(again[::-1, :K * 18].view(np.uint64), rows[engine][:, :K * 18].view(np.uint64))  # same instances, reversed order
+        alg.ctx.close()
+    a, b = rows[scpp_amd._lib.STREAM_POOLS], rows[scpp_amd._lib.STREAM_PERSISTENT]
+    assert a.shape == b.shape == (N, K * 18 + 10) and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    print("persistent kernel == pool engine, bitwise: %d rows of %d doubles" % (N, K * 18 + 10))
 
 
 def test_rocket2d_stream_multi_pool_equals_batch_on_gpu(hip_lib, tmp_path):

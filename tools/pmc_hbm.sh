@@ -30,7 +30,7 @@ def load(name):
     for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            k = ("ipm_kernel" if "ipm_kernel" in k else "discretize_kernel" if "discretize_kernel" in k else
+            k = ("scvx_persistent_kernel" if "scvx_persistent_kernel" in k else "ipm_kernel" if "ipm_kernel" in k else "discretize_kernel" if "discretize_kernel" in k else
                  "scvx_cost_update_kernel" if "scvx_cost_update" in k else "refill" if "refill" in k else
                  k.split("(")[0].split("::")[-1][:40])
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -67,24 +67,33 @@ S["calibration"] = f"FETCH_SIZE x{1/rf:.3f}, WRITE_SIZE x{1/wf:.3f} (8 B/lane 40
 af, nf = load("fetch"); aw, nw = load("write")
 bf, bw = bench("fetch"), bench("write")
 K = {}
-for k in ("ipm_kernel", "discretize_kernel", "scvx_cost_update_kernel"):
+for k in ("scvx_persistent_kernel", "ipm_kernel", "discretize_kernel", "scvx_cost_update_kernel"):
+    if k not in af and k not in aw:
+        continue
     K[k] = {"dispatches": nf.get(k, 0), "fetch_bytes_raw": af[k]["FETCH_SIZE"] * 1024, "write_bytes_raw": aw[k]["WRITE_SIZE"] * 1024,
             "fetch_bytes": af[k]["FETCH_SIZE"] * 1024 / rf, "write_bytes": aw[k]["WRITE_SIZE"] * 1024 / wf}
 S["kernels"] = K
 if bf:
     inst = bf["config"]["instances_timed"]; it = bf["config"]["mean_ipm_iterations_per_trajectory"] * inst
     solves = bf["config"]["mean_subproblem_solves"] * inst; calls = bf["config"]["mean_scvx_iterations"] * inst
-    tot = K["ipm_kernel"]["fetch_bytes"] + K["ipm_kernel"]["write_bytes"]
-    S["ipm_iterations"] = it; S["ipm_solves"] = solves
-    S["ipm_bytes_per_instance_iteration"] = tot / it
-    S["ipm_bytes_per_instance_iteration_raw"] = (K["ipm_kernel"]["fetch_bytes_raw"] + K["ipm_kernel"]["write_bytes_raw"]) / it
+    # the kernel that carries the interior-point solves: the persistent SCvx kernel (one launch per job: refill + multipleShooting + solve + cost
+    # of every instance, the default engine since round 5) or ipm_kernel (pool engine)
+    main = "scvx_persistent_kernel" if "scvx_persistent_kernel" in K else "ipm_kernel"
+    S["engine"] = "persistent" if main == "scvx_persistent_kernel" else "pools"
+    tot = K[main]["fetch_bytes"] + K[main]["write_bytes"]
+    S["ipm_iterations"] = it; S["ipm_solves"] = solves; S["trajectories"] = inst
+    S["ipm_bytes_per_instance_iteration"] = tot / it  # (persistent engine: ALL steps' bytes over the interior-point iterations; the other steps move < 1 %)
+    S["ipm_bytes_per_instance_iteration_raw"] = (K[main]["fetch_bytes_raw"] + K[main]["write_bytes_raw"]) / it
     S["ipm_bytes_per_instance_solve"] = tot / solves
-    S["discretize_bytes_per_instance_call"] = (K["discretize_kernel"]["fetch_bytes"] + K["discretize_kernel"]["write_bytes"]) / calls
-    S["discretize_write_bytes_per_instance_call"] = K["discretize_kernel"]["write_bytes"] / calls
+    S["bytes_per_trajectory"] = tot / inst
+    if "discretize_kernel" in K:
+        S["discretize_bytes_per_instance_call"] = (K["discretize_kernel"]["fetch_bytes"] + K["discretize_kernel"]["write_bytes"]) / calls
+        S["discretize_write_bytes_per_instance_call"] = K["discretize_kernel"]["write_bytes"] / calls
 # ---- matrix core ----
 am, _ = load("mfma")
-if "ipm_kernel" in am:
-    d = am["ipm_kernel"]; S["ipm_mfma"] = dict(d)
+mk = "scvx_persistent_kernel" if "scvx_persistent_kernel" in am else "ipm_kernel"
+if mk in am:
+    d = am[mk]; S["ipm_mfma"] = dict(d)
     bm = bench("mfma")
     if bm and d.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
         it = bm["config"]["mean_ipm_iterations_per_trajectory"] * bm["config"]["instances_timed"]
@@ -93,9 +102,10 @@ if "ipm_kernel" in am:
         S["ipm_mfma"]["mfma_busy_over_cu_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CU_CYCLES"]
 for name in ("tcc", "sq"):
     a, _ = load(name)
-    S[name] = {k: dict(v) for k, v in a.items() if k in ("ipm_kernel", "discretize_kernel", "scvx_cost_update_kernel")}
-if "ipm_kernel" in S.get("tcc", {}):
-    t = S["tcc"]["ipm_kernel"]
+    S[name] = {k: dict(v) for k, v in a.items() if k in ("scvx_persistent_kernel", "ipm_kernel", "discretize_kernel", "scvx_cost_update_kernel")}
+mk = "scvx_persistent_kernel" if "scvx_persistent_kernel" in S.get("tcc", {}) else "ipm_kernel"
+if mk in S.get("tcc", {}):
+    t = S["tcc"][mk]
     if t.get("TCC_HIT_sum", 0) + t.get("TCC_MISS_sum", 0) > 0:
         S["ipm_l2_hit_rate"] = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
 json.dump(S, open(f"{out}/summary.json", "w"), indent=1)
