@@ -300,6 +300,8 @@ class SocpSolver
     detail::SparseLDL ldl;
     std::vector<int> psign; // expected pivot signs in permuted order
     double delta_cur = 7e-8, eps_dyn = 1e-13, delta_dyn = 2e-7;
+    double reg_scale = 1.;       // escalation factor of every regularisation (main loop safeguard)
+    double worst_kkt_err = 0.;   // largest relative residual of the kktSolve calls since it was last reset
 
     // scaling state
     std::vector<double> wlp;                // LP: w_i = sqrt(s_i/z_i)
@@ -666,7 +668,7 @@ inline bool SocpSolver::factor()
     // Regularisation: cone rows are eliminated FIRST (pivots -W^2, definite by construction) and the
     // variables next (pivots G'W^-2G > 0), so neither block needs ECOS' static delta; only the equality
     // block (rank-deficient in the reference problems: duplicated rows) is shifted by -delta_eq.
-    const double dx_ = opt.delta_x, dy_ = opt.delta_eq, dz_ = opt.delta_cone;
+    const double dx_ = opt.delta_x * reg_scale, dy_ = opt.delta_eq * reg_scale, dz_ = opt.delta_cone * reg_scale;
     std::fill(Kx.begin(), Kx.end(), 0.);
     for (int j = 0; j < n; j++)
         Kx[posDiag[j]] += dx_;
@@ -727,6 +729,7 @@ inline void SocpSolver::kktSolve(const std::vector<double> &rx, const std::vecto
     for (double v : rz)
         bnorm = std::max(bnorm, std::fabs(v));
     double prev_err = 1e300;
+    double accepted_err = 1e300;
     for (int it = 0; it <= opt.nitref; it++)
     {
         for (int j = 0; j < n; j++)
@@ -769,6 +772,7 @@ inline void SocpSolver::kktSolve(const std::vector<double> &rx, const std::vecto
         dx = nx;
         dy = ny;
         dz = nz;
+        accepted_err = err;
         if (err < 1e-14 * (1. + bnorm))
             break;
         if (it > 0 && err > prev_err / 6.)
@@ -778,6 +782,9 @@ inline void SocpSolver::kktSolve(const std::vector<double> &rx, const std::vecto
         by = ey;
         bz = ez;
     }
+    // relative residual of the accepted solution against the UN-regularised system: what the caller's safeguard looks at
+    const double rel = std::isfinite(accepted_err) ? accepted_err / (1. + bnorm) : 1e300;
+    worst_kkt_err = std::max(worst_kkt_err, rel);
 }
 
 inline double SocpSolver::maxStep(const std::vector<double> &ds, const std::vector<double> &dz) const
@@ -927,7 +934,7 @@ inline SocpResult SocpSolver::solve()
             break;
         }
         pres_prev = pres;
-        if ((-cx > 0. || -by - hz >= -opt.abstol) && pres < opt.feastol && dres < opt.feastol &&
+        if (tau > 0. && pres >= 0. && dres >= 0. && (-cx > 0. || -by - hz >= -opt.abstol) && pres < opt.feastol && dres < opt.feastol &&
             (gap < opt.abstol || relgap < opt.reltol))
         {
             R.exitflag = 0;
@@ -968,7 +975,7 @@ inline SocpResult SocpSolver::solve()
         // ECOS's reduced-accuracy exit (feastol_inacc 1e-4, abstol_inacc = reltol_inacc = 5e-5): when the iteration limit or a
         // numerical breakdown is hit at an iterate that already satisfies the relaxed tolerances, ECOS returns it as
         // "close to optimal" (exitflag ECOS_OPTIMAL + ECOS_INACC_OFFSET = 10) instead of failing
-        const bool inacc_ok = (-cx > 0. || -by - hz >= -5e-5) && pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
+        const bool inacc_ok = tau > 0. && (-cx > 0. || -by - hz >= -5e-5) && pres < 1e-4 && dres < 1e-4 && (gap < 5e-5 || relgap < 5e-5);
         if (inacc_ok)
         {
             best.x = x;
@@ -1002,14 +1009,28 @@ inline SocpResult SocpSolver::solve()
             R.exitflag = inacc_ok ? 10 : -2;
             break;
         }
-        delta_dyn = 2 * 1e-9;
-        eps_dyn = 1e-3 * 1e-9;
+        // ---- factorisation + the three solves + step length, SAFEGUARDED (round 5: the literal checker failed on ~5 % of the SCvx runs) ----
+        // Near the optimum of a degenerate sub-problem the scalings span 1e+-9, a pivot of the quasi-definite factor falls to the
+        // dynamic-regularisation floor and the directions come back with entries of 1e50: one such step took tau NEGATIVE, after which every
+        // residual quotient was negative and passed the `< tolerance` tests -- "optimal" at a cost of 3.7e13.  Now: the directions must be
+        // finite, their KKT residual against the un-regularised system small, and the step must keep tau and kappa positive; otherwise the
+        // regularisations are escalated (x 30 per attempt, five attempts) and the iteration is recomputed; only then is it a numerical
+        // failure (exit -2, or 10 from a reduced-accuracy iterate).
+        double alpha = 0., dtau = 0., dkap = 0.;
+        bool step_ok = false;
+        reg_scale = 1.; // (every iteration starts from the nominal regularisation: an escalation is a repair of ONE factorisation)
+        for (int attempt = 0; attempt < 6 && !step_ok; attempt++)
+        {
+        if (attempt > 0)
+            reg_scale *= 30.;
+        worst_kkt_err = 0.;
+        delta_dyn = 2 * 1e-9 * reg_scale;
+        eps_dyn = 1e-3 * 1e-9 * reg_scale;
         if (!factor())
         {
             if (opt.verbose)
-                std::printf("numerics: factorisation failed\n");
-            R.exitflag = inacc_ok ? 10 : -2;
-            break;
+                std::printf("numerics: factorisation failed (regularisation x %.0e)\n", reg_scale);
+            continue;
         }
 
         // v1 = K^-1 [-c; b; h]
@@ -1079,14 +1100,14 @@ inline SocpResult SocpSolver::solve()
         }
         g2 = dot(c, x2) + dot(b, y2) + dot(h, z2);
         const double dkap_rhs = -tau * kap - dtau_a * dkap_a + sigma * mu;
-        const double dtau = (dkap_rhs - tau * (1. - sigma) * rt + tau * g2) / denom;
+        dtau = (dkap_rhs - tau * (1. - sigma) * rt + tau * g2) / denom;
         for (int j = 0; j < m; j++)
             dz[j] = z2[j] + dtau * z1[j];
         for (int j = 0; j < n; j++)
             dx[j] = x2[j] + dtau * x1[j];
         for (int j = 0; j < p; j++)
             dy[j] = y2[j] + dtau * y1[j];
-        const double dkap = -(dot(c, dx) + dot(b, dy) + dot(h, dz)) + (1. - sigma) * rt;
+        dkap = -(dot(c, dx) + dot(b, dy) + dot(h, dz)) + (1. - sigma) * rt;
         // ds = W(lambda\ds) - W^2 dz ; scaled: W^-1 ds = lds - W dz
         applyW(dz, dza_s);
         for (int j = 0; j < m; j++)
@@ -1096,9 +1117,31 @@ inline SocpResult SocpSolver::solve()
             ainv = std::max(ainv, -dtau / tau);
         if (dkap < 0.)
             ainv = std::max(ainv, -dkap / kap);
-        double alpha = ainv > 0. ? opt.gamma / ainv : 1.;
+        alpha = ainv > 0. ? opt.gamma / ainv : 1.;
         alpha = std::min(alpha, 0.999);
         alpha = std::max(alpha, 1e-6);
+        {
+            bool finite = std::isfinite(dtau) && std::isfinite(dkap) && std::isfinite(alpha) && std::isfinite(ainv);
+            double dmax = 0.;
+            for (int j = 0; j < n && finite; j++)
+            {
+                finite = std::isfinite(dx[j]);
+                dmax = std::max(dmax, std::fabs(dx[j]));
+            }
+            for (int j = 0; j < m && finite; j++)
+                finite = std::isfinite(dz[j]) && std::isfinite(dsa_s[j]);
+            // (the residual bound is a sanity bound -- a healthy solve sits at 1e-9 .. 1e-6 late in the path, a broken one at 1e0 .. 1e20)
+            step_ok = finite && worst_kkt_err < 1e-3 && tau + alpha * dtau > 0. && kap + alpha * dkap > 0. && dmax < 1e30;
+            if (!step_ok && opt.verbose)
+                std::printf("numerics: step refused (finite %d, kkt residual %.1e, tau' %.2e, kappa' %.2e, |dx| %.1e), regularisation x %.0e\n", int(finite),
+                            worst_kkt_err, tau + alpha * dtau, kap + alpha * dkap, dmax, reg_scale);
+        }
+        } // attempts
+        if (!step_ok)
+        {
+            R.exitflag = inacc_ok ? 10 : -2;
+            break;
+        }
         applyW(dsa_s, ds);
         for (int j = 0; j < n; j++)
             x[j] += alpha * dx[j];

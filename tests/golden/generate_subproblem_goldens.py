@@ -47,8 +47,9 @@ def euler_xyz(rpy):  # common.hpp:30-38: AngleAxis(x, X) * AngleAxis(y, Y) * Ang
     return quat_mul(quat_mul(qx, qy), qz)
 
 
-def scenario():
-    """model.info:109-213 -> Parameters::loadFromFile -> nondimensionalize (rocketQuat.cpp:234-311)"""
+def scenario(x_init_dimensional=None):
+    """model.info:109-213 -> Parameters::loadFromFile -> nondimensionalize (rocketQuat.cpp:234-311).  x_init_dimensional (SI units, [m, r, v, q, w]):
+    another initial state of the same vehicle (the randomised instances of the bench), scaled by ITS mass and distance (rocketQuat.cpp:293-294)"""
     g_I = np.array([0.0, 0.0, -9.81]); J_B = np.array([5e6, 5e6, 7e4]); r_T_B = np.array([0.0, 0.0, -15.0])
     m_init, m_dry = 24000.0, 22000.0
     r_init = np.array([200.0, 200.0, 800.0]); v_init = np.array([-40.0, -40.0, -80.0])
@@ -58,6 +59,8 @@ def scenario():
     final_time = 12.0
     alpha_m = 1.0 / (I_sp * abs(g_I[2]))
     x_init = np.concatenate([[m_init], r_init, v_init, euler_xyz(rpy_init), np.zeros(3)])
+    if x_init_dimensional is not None:
+        x_init = np.array(x_init_dimensional, dtype=float).copy()
     x_final = np.concatenate([[m_dry], np.zeros(3), np.zeros(3), euler_xyz(np.zeros(3)), np.zeros(3)])
     ms, rs = x_init[0], np.linalg.norm(x_init[1:4])
     alpha_m *= rs; r_T_B = r_T_B / rs; g_I = g_I / rs; J_B = J_B / (ms * rs * rs)

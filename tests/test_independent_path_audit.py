@@ -33,7 +33,7 @@ def _nondim(X, U, ms, rs):
     return X, U
 
 
-def _nonlinear_cost(G, sc, X, U, t):
+def _nonlinear_cost(G, sc, X, U, t, K=K):
     """SCvxAlgorithm.cpp:262-278 + simulation.cpp:25-42 with the restated flow map, first-order-hold inputs, DOP853 instead of RKF78"""
     import sympy as sp
     from scipy.integrate import solve_ivp
@@ -73,44 +73,76 @@ def test_scvx_path_sub_problems_against_independent_cutting_planes_on_gpu(hip_li
     _path_audit(hip_lib, 4)
 
 
-def _path_audit(emu_lib, n_it):
+@pytest.mark.gpu
+@pytest.mark.parametrize("instance", [None, 3, 11])
+def test_scvx_path_at_the_size_of_the_metric_against_independent_cutting_planes_on_gpu(hip_lib, instance):
+    """the independent audit at the size the metric is quoted on -- K = 50 -- on the GPU, for the nominal instance and two of
+    the bench's randomised instances (their own mass / distance scaling): five accepted sub-problems each, rejected candidates on the way
+    included, the nonlinear cost, rho and the radius rule recomputed independently.  Solved at test time (a cutting-plane run over HiGHS per
+    sub-problem): the device path is deterministic per BUILD only -- a recompilation moves it at rounding level, which golden optima keyed
+    on device iterates would not survive."""
+    _path_audit(hip_lib, 5, K=50, instance=instance, workers=5)
+
+
+def _audit_one(task):
+    """One accepted sub-problem of a device path, checked with code that shares nothing with the repository's solvers (pure CPU; runs in a worker
+    process when several are audited at once).  Returns (gap, J, L) after asserting feasibility and the objective bars."""
     import generate_subproblem_cut_goldens as C
     import generate_subproblem_goldens as G
 
-    G.K = K
-    sc = G.scenario()
-    ms, rs = sc["m_scale"], sc["r_scale"]
+    Kn, x_dim, j, Xb, Ub, r_used, Xc, Uc = task
+    G.K = Kn
+    sc = G.scenario(x_dim)
+    dd = G.discretize(sc, Xb, Ub, sc["final_time"], False)
+    pb = G.SubProblem(sc, Xb, Ub, sc["final_time"], dd, "scvx", dict(vc=W_VC, tr=r_used))
+    _, info = C.solve_cuts(pb, verbose=False)
+    assert max(info["cone_violation"], info["eq_violation"], info["lin_violation"]) <= 1e-9
+    # the device's candidate as a point of the restated problem: nu := its defect in the restated dynamics
+    A, B, Cm, S, Z = dd
+    nu = np.array([Xc[k + 1] - (A[k] @ Xc[k] + B[k] @ Uc[k] + Cm[k] @ Uc[k + 1] + Z[k]) for k in range(Kn - 1)])
+    v = np.concatenate([Xc.ravel(), Uc.ravel(), np.maximum(nu, 0).ravel(), np.maximum(-nu, 0).ravel()])
+    assert np.abs(pb.eq(v)).max() <= 1e-9, ("equalities", j + 1, float(np.abs(pb.eq(v)).max()))
+    assert pb.ineq(v).min() >= -1e-9, ("rows / cones", j + 1, float(pb.ineq(v).min()))
+    gap = (pb.cost(v) - info["objective"]) / info["objective"]
+    assert -1e-6 <= gap <= 5e-5, ("objective", j + 1, pb.cost(v), info["objective"])
+    J = _nonlinear_cost(G, sc, Xc, Uc, sc["final_time"], Kn)
+    return gap, J, pb.cost(v) / W_VC
+
+
+def _path_audit(emu_lib, n_it, K=K, instance=None, workers=1):
     m = scpp_amd.RocketQuat().loadParameters()
+    x_init = m.x_init if instance is None else m.randomized_initial_states(1, first=instance)[0]
+    ms, rs = float(x_init[0]), float(np.linalg.norm(x_init[1:4]))  # rocketQuat.cpp:293-294
     alg = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=1, library=emu_lib).initialize()
     o_ = alg.opts
     alpha, beta, rho_1, rho_2 = float(o_.alpha), float(o_.beta), float(o_.rho_1), float(o_.rho_2)
-    path = _device_path(alg, m.x_init[None], n_it)
+    path = _device_path(alg, x_init[None], n_it)
     alg.ctx.close()
     Xb, Ub = _nondim(path[0]["X"], path[0]["U"], ms, rs)
-    r_prev, solves_prev, J_prev = float(path[0]["trust_region"]), 0, None
-    gaps, rejected, rho_checked = [], 0, 0
+    r_prev, solves_prev = float(path[0]["trust_region"]), 0
+    tasks, meta = [], []
+    rejected = 0
     for j, st in enumerate(path[1:]):
         n_rej = int(st["solves"] - solves_prev) - 1
         assert st["sc_iters"] == j + 1 and n_rej >= 0 and st["converged"] == 0
         rejected += n_rej
         r_used = r_prev / alpha ** n_rej
         Xc, Uc = _nondim(st["X"], st["U"], ms, rs)
-        dd = G.discretize(sc, Xb, Ub, sc["final_time"], False)
-        pb = G.SubProblem(sc, Xb, Ub, sc["final_time"], dd, "scvx", dict(vc=W_VC, tr=r_used))
-        _, info = C.solve_cuts(pb, verbose=False)
-        assert max(info["cone_violation"], info["eq_violation"], info["lin_violation"]) <= 1e-9
-        # the device's candidate as a point of the restated problem: nu := its defect in the restated dynamics
-        A, B, Cm, S, Z = dd
-        nu = np.array([Xc[k + 1] - (A[k] @ Xc[k] + B[k] @ Uc[k] + Cm[k] @ Uc[k + 1] + Z[k]) for k in range(K - 1)])
-        v = np.concatenate([Xc.ravel(), Uc.ravel(), np.maximum(nu, 0).ravel(), np.maximum(-nu, 0).ravel()])
-        assert np.abs(pb.eq(v)).max() <= 1e-9, ("equalities", j + 1, float(np.abs(pb.eq(v)).max()))
-        assert pb.ineq(v).min() >= -1e-9, ("rows / cones", j + 1, float(pb.ineq(v).min()))
-        gap = (pb.cost(v) - info["objective"]) / info["objective"]
-        assert -1e-6 <= gap <= 5e-5, ("objective", j + 1, pb.cost(v), info["objective"])
+        tasks.append((K, None if instance is None else x_init.copy(), j, Xb, Ub, r_used, Xc, Uc))
+        meta.append((n_rej, r_used))
+        Xb, Ub, r_prev, solves_prev = Xc, Uc, float(st["trust_region"]), int(st["solves"])
+    if workers > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+
+        with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:  # (spawn: the parent holds a HIP context)
+            results = list(ex.map(_audit_one, tasks))
+    else:
+        results = [_audit_one(t) for t in tasks]
+    gaps, rho_checked, J_prev = [], 0, None
+    for j, (st, (n_rej, r_used), (gap, J, L)) in enumerate(zip(path[1:], meta, results)):
         gaps.append(gap)
         # the nonlinear cost of the candidate, and the accept / radius rule where the previous J is known (no rejection in between)
-        J = _nonlinear_cost(G, sc, Xc, Uc, sc["final_time"])
-        L = pb.cost(v) / W_VC
         assert abs(J - float(st["nonlinear_cost"])) <= 1e-8 * J, ("J", j + 1, J, float(st["nonlinear_cost"]))
         assert abs(L - float(st["nu_norm"])) <= 1e-6 * L, ("L", j + 1, L, float(st["nu_norm"]))  # (the solver's norm1_nu: tight to its 1e-8 tolerances)
         rho_dev, dJ_dev, dL_dev, code = [float(x) for x in st["last_decision"]]
@@ -123,10 +155,11 @@ def _path_audit(emu_lib, n_it):
             r_next = r_used / alpha if rho < rho_1 else (r_used * beta if rho >= rho_2 else r_used)
             assert min(abs(rho - rho_1), abs(rho - rho_2)) > 1e-4 and abs(float(st["trust_region"]) - r_next) <= 1e-12 * r_next, ("radius", j + 1, rho)
             rho_checked += 1
-        Xb, Ub, r_prev, solves_prev, J_prev = Xc, Uc, float(st["trust_region"]), int(st["solves"]), J
+        J_prev = J
     assert rejected >= 1 and rho_checked >= 1  # the path exercises both: rejected candidates and first-attempt acceptances
-    print("independent audit of %d sub-problems along the device path (K = %d, %d rejected candidates on the way, rho and the radius rule checked "
-          "on %d iterations): relative objective gaps %s" % (len(gaps), K, rejected, rho_checked, ["%.1e" % g for g in gaps]))
+    print("independent audit of %d sub-problems along the device path (%s instance, K = %d, %d rejected candidates on the way, rho and the radius rule "
+          "checked on %d iterations): relative objective gaps %s" % (len(gaps), "nominal" if instance is None else "randomised #%d" % instance, K, rejected,
+                                                                     rho_checked, ["%.1e" % g for g in gaps]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -462,3 +495,16 @@ def test_emu_simulate_against_dop853_of_the_restated_flow_maps(emu_lib):
         xe = solve_ivp(rhs, [0, dt[b]], x0[b], method="DOP853", rtol=1e-13, atol=1e-16).y[:, -1]
         assert np.abs(xe - xd[b]).max() <= 1e-10 * max(1.0, np.abs(xe).max()), ("Rocket2D", b, float(np.abs(xe - xd[b]).max()))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_sc_rocket2d_and_zero_order_hold_paths_against_independent_cutting_planes_on_gpu(hip_lib, tmp_path):
+    """the path audits that ran on the CPU wave emulator only -- the SC mode (free final time, soft trust region), the second
+    model in both modes, SCvx with zero-order-hold inputs -- on the device the product runs on: the same functions, the HIP library."""
+    _sc_path_audit(hip_lib, 4)
+    test_emu_rocket2d_sc_path_sub_problems_against_independent_cutting_planes(hip_lib)
+    for name, fn in (("r2d", test_emu_rocket2d_scvx_path_sub_problems_against_independent_cutting_planes),
+                     ("zoh", test_emu_scvx_zero_order_hold_path_against_independent_cutting_planes)):
+        d = tmp_path / name
+        d.mkdir()
+        fn(hip_lib, d)

@@ -1,6 +1,6 @@
 """The WHOLE SCAlgorithm loop on the shipped RocketQuat scenario against a solver the build did not write.
 
-tests/golden/rocketquat_sc_loop_K{5,15}.npz hold ||nu||_1, sum(delta), sigma per SC iteration from scipy `trust-constr` driving
+tests/golden/rocketquat_sc_loop_K5.npz holds ||nu||_1, sum(delta), sigma per SC iteration from scipy `trust-constr` driving
 the loop of SCAlgorithm::solve (SCAlgorithm.cpp:66-189) on an NLP restatement that shares no code with the oracle, the kernels or
 scpp_amd (tests/golden/generate_sc_loop_goldens.py).  What they pin:
   * the iteration does NOT meet the convergence test (sum(delta) < 1e-3 and ||nu||_1 < 1e-5, SCAlgorithm.cpp:131): it stalls at a
@@ -28,6 +28,11 @@ def _golden(K):
 
 
 NU_TOL, DELTA_TOL = 1e-5, 1e-3  # SC.info
+# K = 5 only.  A K = 15 record of the scipy loop was planned in round 2 and never generated (trust-constr needs hours there), so its tests were
+# skipped for three rounds: removed in round 5.  The SC loop at K = 15 is pinned differently and more sharply since round 4 -- every sub-problem
+# along the device's own path against Kelley cutting planes over HiGHS (tests/test_independent_path_audit.py: _sc_path_audit, CPU emulator
+# and, since round 5, the GPU).
+KS = [5]
 
 
 def _check(g, nu, sd, sigma, what):
@@ -50,7 +55,7 @@ def _check(g, nu, sd, sigma, what):
             assert (sd[it] < DELTA_TOL) == (g["sum_delta"][it] < DELTA_TOL) or abs(sd[it] - g["sum_delta"][it]) <= 0.1 * g["sum_delta"][it], (what, it)
 
 
-@pytest.mark.parametrize("K", [5, 15])
+@pytest.mark.parametrize("K", KS)
 def test_scipy_loop_stalls_without_converging(K):
     g = _golden(K)
     n = int(g["iterations"])
@@ -67,7 +72,7 @@ def test_scipy_loop_stalls_without_converging(K):
         assert abs(g["norm1_nu"][n - 1] - g["norm1_nu"][n - 2]) < 1e-3 * g["norm1_nu"][n - 1]
 
 
-@pytest.mark.parametrize("K", [5, 15])
+@pytest.mark.parametrize("K", KS)
 @pytest.mark.parametrize("solver", [0, 1])
 def test_oracle_solvers_follow_the_scipy_loop(oracle, K, solver):
     g = _golden(K)
@@ -91,7 +96,7 @@ def _device_loop(model, K, lib):
     return nu, sd, sg, conv
 
 
-@pytest.mark.parametrize("K", [5, 15])
+@pytest.mark.parametrize("K", KS)
 def test_device_path_follows_the_scipy_loop_emulated(model, emu_lib, K):
     g = _golden(K)
     nu, sd, sg, conv = _device_loop(model, K, emu_lib)
@@ -100,7 +105,7 @@ def test_device_path_follows_the_scipy_loop_emulated(model, emu_lib, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K", [5, 15])
+@pytest.mark.parametrize("K", KS)
 def test_device_path_follows_the_scipy_loop_on_gpu(model, hip_lib, K):
     g = _golden(K)
     nu, sd, sg, conv = _device_loop(model, K, hip_lib)
