@@ -1238,6 +1238,86 @@ int ensurePools(scpp_hip_ctx *c, int pools)
 }
 } // namespace
 
+extern "C++"
+{
+namespace
+{
+// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
+struct PersistRocketQuat : ipm::RocketQuatSC
+{
+};
+// Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
+// caller runs the pool engine.
+int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
+                     const scpp_rocketquat_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
+{
+    if (!(c->mode & SCPP_MODE_FOH))
+        return -1;
+    const PersistentArgs<RefillRocketQuat> args{a, b, v, q, mp, sc, so, o};
+    // dynamic LDS: the solver's LDS-resident segment fields during a solve, the integration's stage values / tables during multipleShooting
+    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, false>);
+    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE),
+                       seg_b > disc_b ? seg_b : disc_b, c->stream, args);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+int launchPersistent(scpp_hip_ctx *, const ipm::KernelArgs &, const SCBuffers &, const SCvxBuffers &, const StreamQueue &,
+                     const scpp_rocket2d_params &, const scpp_sc_opts &, const scpp_scvx_opts &, const PersistentOut &, int)
+{
+    return -1;
+}
+
+// queue arrays of the streaming engine (also used, with an empty queue, by the persistent batch solve)
+int ensureQueue(scpp_hip_ctx *c)
+{
+    if (c->q_counters)
+        return 0;
+    int a = 0;
+    a |= devAlloc(&c->q_counters, 4);
+    a |= devAlloc(&c->q_slot_inst, size_t(c->Bmax));
+    return a ? SCPP_E_HIP : 0;
+}
+// scpp_hip_scvx_solve on the persistent kernel: the batch is the slots, the queue is empty -- every wavefront takes its one instance through the
+// whole of SCvxAlgorithm::solve and leaves; no rounds, no host polling.  -1: not available for this configuration.
+int scvxSolvePersistent(scpp_hip_ctx *c)
+{
+    if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->model != SCPP_MODEL_ROCKETQUAT || !(c->mode & SCPP_MODE_FOH) || c->scvx.max_iterations <= 0)
+        return -1;
+    if (int rc = ensureQueue(c))
+        return rc;
+    if (!c->persist_shares && devAlloc(&c->persist_shares, 8))
+        return SCPP_E_HIP;
+    CHECK_HIP(hipMemsetAsync(c->persist_shares, 0, 8 * sizeof(double), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->q_counters, 0, 4 * sizeof(int), c->stream));
+    CHECK_HIP(hipMemsetAsync(c->q_slot_inst, 0xFF, size_t(c->Bmax) * sizeof(int), c->stream));
+    const Range r = fullRange(c);
+    const SCBuffers b = scBuffersRange(c, r);
+    const SCvxBuffers v = scvxBuffersRange(c, r);
+    StreamQueue q;
+    q.N = 0; // nothing to pull: a slot whose instance has terminated finds the queue empty and its wavefront leaves
+    q.x_init = nullptr;
+    q.rows = nullptr;
+    q.head = c->q_counters;
+    q.done = c->q_counters + 1;
+    q.nconv = c->q_counters + 2;
+    q.slot_inst = c->q_slot_inst;
+    q.warm = c->ipm_warm;
+    const ipm::KernelArgs a = ipmArgs(c, 0, true, r, true);
+    PersistentOut o;
+    o.A = c->A;
+    o.Bm = c->Bm;
+    o.C = c->C;
+    o.S = c->S;
+    o.Z = c->Z;
+    o.disc_steps = c->disc_steps;
+    o.shares = c->persist_shares;
+    const bool timed = spanBegin(c, 1, c->B, c->stream);
+    const int rc = launchPersistent(c, a, b, v, q, c->mp, c->sc, c->scvx, o, c->B);
+    spanEnd(c, timed, c->stream);
+    return rc;
+}
+} // namespace
+} // extern "C++"
+
 int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
 {
     DeviceGuard guard(c);
@@ -1250,7 +1330,14 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
     // an instance is retired at the cap (scvxDecide); max_iterations <= 0: no iteration at all (the initial trajectory comes back)
     // (retired on a REJECTION with solves >= CAP x max_iterations: up to max_iterations accepted solves can follow the last rejection
     // below the cap, hence CAP + 1)
-    const long max_rounds = c->scvx.max_iterations > 0 ? long(c->scvx.max_iterations) * (SCVX_SOLVE_CAP + 1) + 8 : 0;
+    long max_rounds = c->scvx.max_iterations > 0 ? long(c->scvx.max_iterations) * (SCVX_SOLVE_CAP + 1) + 8 : 0;
+    {
+        const int prc = scvxSolvePersistent(c); // one launch where the persistent kernel exists (RocketQuat, first-order hold) ...
+        if (prc > 0 || prc < -1)
+            return prc;
+        if (prc == 0)
+            max_rounds = 0; // ... the rounds below are the pool-style loop of every other configuration
+    }
     // One stream (measured: the two-stream skewed pipeline of scpp_hip_sc_solve loses here, rounds late in the run have few
     // active instances and are latency-bound either way).  The host does not wait for a round before enqueueing the next:
     // the active count is read back asynchronously every POLL rounds and looked at one poll later, so the device never
@@ -1317,30 +1404,6 @@ int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scv
 {
     return scpp_hip_scvx_setup_rocket2d(c, mp, so, x, B, 0);
 }
-// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
-struct PersistRocketQuat : ipm::RocketQuatSC
-{
-};
-// Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
-// caller runs the pool engine.
-int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
-                     const scpp_rocketquat_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
-{
-    if (!(c->mode & SCPP_MODE_FOH))
-        return -1;
-    const PersistentArgs<RefillRocketQuat> args{a, b, v, q, mp, sc, so, o};
-    // dynamic LDS: the solver's LDS-resident segment fields during a solve, the integration's stage values / tables during multipleShooting
-    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, false>);
-    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE),
-                       seg_b > disc_b ? seg_b : disc_b, c->stream, args);
-    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
-}
-int launchPersistent(scpp_hip_ctx *, const ipm::KernelArgs &, const SCBuffers &, const SCvxBuffers &, const StreamQueue &,
-                     const scpp_rocket2d_params &, const scpp_sc_opts &, const scpp_scvx_opts &, const PersistentOut &, int)
-{
-    return -1;
-}
-
 template <class T>
 int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_scvx_opts *so, const double *x_init, int N, int slots,
                     int pools, int *n_converged)
@@ -1368,14 +1431,8 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
             return SCPP_E_HIP;
         c->q_cap = size_t(N);
     }
-    if (!c->q_counters)
-    {
-        int a = 0;
-        a |= devAlloc(&c->q_counters, 4);
-        a |= devAlloc(&c->q_slot_inst, size_t(c->Bmax));
-        if (a)
-            return SCPP_E_HIP;
-    }
+    if (int rc = ensureQueue(c))
+        return rc;
     (void)K;
     CHECK_HIP(hipMemcpyAsync(c->q_xinit, x_init, size_t(N) * NX * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CHECK_HIP(hipMemsetAsync(c->q_counters, 0, 4 * sizeof(int), c->stream));

@@ -242,6 +242,135 @@ __global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_ke
     scvxCostUpdate<Model>(b, v, so, blockIdx.x);
 }
 
+// The same step for a kernel with a 256-register budget (the persistent SCvx kernel, scvx_persistent.h).  scvxCostUpdate gives a lane one
+// whole segment: 13 stage slopes of NX doubles = 364 VGPRs for RocketQuat -- fine at one wavefront per SIMD, but inside the persistent kernel
+// they went to scratch memory and one candidate cost 2.0 M cycles against 0.25 M stand-alone (measured, round 5).  Here TWO lanes share a
+// segment: lane (pair p, half h) keeps half h of the state and of every stage slope (91 doubles), both evaluate the whole flow map on the stage
+// value they assemble with one exchange between neighbours per stage, and the K - 1 segments go through in two passes of up to 32 pairs.
+// BITWISE the result of scvxCostUpdate: every component goes through the same operations in the same order (the stage combination and the
+// step update are per component; the flow map sees the same stage value), the segment's defect sum continues from half 0 to half 1 in component
+// order, and the per-segment sums are reduced in the lane = segment arrangement the one-lane-per-segment code has (through `seg_sum`, LDS).
+template <class Model>
+__device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, const long i, double *seg_sum /* [64] LDS */)
+{
+    using namespace ipm;
+    constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NH = NX / 2;
+    static_assert(NX % 2 == 0, "two lanes share a segment: an even number of states");
+    if (i >= b.B || b.active[i] == 0)
+        return;
+    const int K = b.K, lane = threadIdx.x;
+    const int foh = so.interpolate_input;
+    const int half = lane & 1, pair = lane >> 1;
+    const bool solved = b.status[i] == 0;
+    if (lane < WAVE)
+        seg_sum[lane] = 0.;
+    WAVE_SYNC();
+    for (int pass = 0; pass * 32 < K - 1; pass++)
+    {
+        const int k = pass * 32 + pair; // this pair's segment
+        const bool on = k < K - 1 && solved;
+        const int kc = on ? k : 0;
+        double p[NP], u0[NU], u1[NU], y[NH], kk[RK_S][NH];
+        const double *ip = b.ip + i * IP_N;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            p[j] = ip[IP_PAR + j];
+        const double *X = b.X + (i * K + kc) * NX, *U = b.U + (i * K + kc) * NU;
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+        {
+            u0[j] = U[j];
+            u1[j] = foh ? U[NU + j] : U[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+            y[j] = X[half * NH + j];
+        const double dt = b.sigma[i] / double(K - 1);
+        const double h = dt / 20.;
+        for (int step = 0; step < 20; step++)
+        {
+            const double t0 = double(step) * h;
+#pragma unroll
+            for (int s = 0; s < RK_S; s++)
+            {
+                double mine[NH], ys[NX], u[NU], f[NX];
+                const double ts = t0 + RK_C[s] * h;
+#pragma unroll
+                for (int j = 0; j < NH; j++)
+                {
+                    double a = 0.;
+#pragma unroll
+                    for (int q = 0; q < s; q++)
+                        if (RK_A[s][q] != 0.)
+                            a += RK_A[s][q] * kk[q][j];
+                    mine[j] = y[j] + h * a;
+                }
+                // the other half of the stage value from the neighbour lane
+#pragma unroll
+                for (int j = 0; j < NH; j++)
+                {
+                    const double other = __shfl_xor(mine[j], 1);
+                    ys[j] = half ? other : mine[j];
+                    ys[NH + j] = half ? mine[j] : other;
+                }
+#pragma unroll
+                for (int j = 0; j < NU; j++)
+                    u[j] = u0[j] + ts / dt * (u1[j] - u0[j]);
+                Model::template systemFlowMap<double>(ys, u, p, f);
+#pragma unroll
+                for (int j = 0; j < NH; j++)
+                    kk[s][j] = half ? f[NH + j] : f[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NH; j++)
+            {
+                double a = 0.;
+#pragma unroll
+                for (int s = 0; s < RK_S; s++)
+                    if (RK_B[s] != 0.)
+                        a += RK_B[s] * kk[s][j];
+                y[j] += h * a;
+            }
+        }
+        // defect of the segment: components 0 .. NX-1 in order -- half 0 sums its components, half 1 continues from that partial sum
+        double part = 0.;
+        if (!half)
+        {
+#pragma unroll
+            for (int j = 0; j < NH; j++)
+                part += fabs(y[j] - X[NX + j]);
+        }
+        const double from0 = __shfl_xor(part, 1);
+        if (half)
+        {
+            part = from0;
+#pragma unroll
+            for (int j = 0; j < NH; j++)
+                part += fabs(y[j] - X[NX + NH + j]);
+            if (on)
+                seg_sum[k] = part;
+        }
+    }
+    WAVE_SYNC();
+    double acc = (lane < K - 1) ? seg_sum[lane] : 0.; // lane = segment, as in scvxCostUpdate: the same reduction order
+    acc = wave_sum(acc);
+    WAVE_SYNC();
+    int restore = 0;
+    if (lane == 0)
+    {
+        v.cost[i] = acc;
+        restore = scvxDecide(b, v, so, i, acc);
+    }
+    restore = __shfl(restore, 0);
+    if (restore)
+    {
+        for (int e = lane; e < K * NX; e += WAVE)
+            b.X[i * K * NX + e] = v.Xold[i * K * NX + e];
+        for (int e = lane; e < K * NU; e += WAVE)
+            b.U[i * K * NU + e] = v.Uold[i * K * NU + e];
+    }
+}
+
 // ---------------------------------------------------------------- streaming engine
 // result row of one instance (doubles): X [K][nx], U [K][nu] (dimensional), then the scalars below
 enum StreamRow

@@ -25,6 +25,9 @@
 namespace scpp
 {
 
+#ifndef PERSIST_COST_SPLIT
+#define PERSIST_COST_SPLIT 1 // 1: scvxCostUpdateSplit (two lanes per segment) ; 0: the stand-alone kernel's one lane per segment (spills at 256 registers)
+#endif
 struct PersistentOut
 {
     double *A, *Bm, *C, *S, *Z; // dd of the slots (the non-const view of KernelArgs' A .. Z)
@@ -159,7 +162,19 @@ PERSIST_STEP_FN void persistCost(long slot)
     const SCBuffers b = argCopy(A.b);
     const SCvxBuffers v = argCopy(A.v);
     const scpp_scvx_opts so = argCopy(A.so);
+    // two lanes per segment (half the stage slopes per lane: they fit this kernel's 256 registers); the per-segment sums pass through 64 doubles of
+    // the dynamic LDS region, which is idle during this step
+#if PERSIST_COST_SPLIT
+#ifdef SCPP_HIP_EMU
+    static double seg_sum[WAVE];
+#else
+    extern __shared__ double seg_lds[];
+    double *seg_sum = seg_lds;
+#endif
+    scvxCostUpdateSplit<Model>(b, v, so, slot, seg_sum);
+#else
     scvxCostUpdate<Model>(b, v, so, slot);
+#endif
     stepFence();
 }
 
