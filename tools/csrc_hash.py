@@ -16,6 +16,10 @@ def csrc_sha():
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
+    # the floating-point flags the library is built with are part of its identity (round 5: -ffp-contract=on changes every result at rounding level)
+    for line in open(os.path.join(ROOT, "__graft_entry__.py")):
+        if line.startswith("HIP_FP_FLAGS ="):
+            h.update(line.strip().encode())
     return h.hexdigest()[:16]
 
 

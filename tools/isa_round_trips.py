@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static ISA statistics of the ipm_kernel phases and sweeps (gfx950 assembly of scpp_hip.cpp).
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip --cuda-device-only -S -o /tmp/scpp.s scpp_amd/csrc/scpp_hip.cpp
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip -ffp-contract=on --cuda-device-only -S -o /tmp/scpp.s scpp_amd/csrc/scpp_hip.cpp
   python tools/isa_round_trips.py /tmp/scpp.s [name-filter]
 
 Per function: instructions, scratch dwords stored / loaded (callee-saved-register saves + spills), vector-memory operations, and
