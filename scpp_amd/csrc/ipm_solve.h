@@ -1168,6 +1168,9 @@ struct SegRhsRow
 // 5 instructions, within 1 ulp) and multiplications, instead of an IEEE division (11 instructions, two of them quarter rate) each: a
 // row takes 8 .. 12 divisions per phase, 44 per interior-point iteration, i.e. ~600 per lane.  The operands are slacks and duals of an
 // interior point: positive, normal.
+#ifndef RES_PREVLANE_MEMORY
+#define RES_PREVLANE_MEMORY 0
+#endif
 #ifndef SEG_FAST_RCP
 #define SEG_FAST_RCP 1
 #endif
@@ -1363,7 +1366,9 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             sfor<NUV>([&](auto jt) { rc[decltype(jt)::value] = dy[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
             // C of the PREVIOUS segment = what lane k - 1 just loaded as its own C row: one wavefront shift instead of a second load
             // (the fiber emulator cannot exchange inside a divergent region: it reads the same value from memory)
-#ifdef SCPP_HIP_EMU
+            // (-DRES_PREVLANE_MEMORY=1 builds the memory-load form for the device too: tests/tools/lib_equal.py compares the two libraries bitwise on
+            // the GPU -- the shift is a data path the CPU suite never runs)
+#if defined(SCPP_HIP_EMU) || RES_PREVLANE_MEMORY
             sfor<NUV>([&](auto jt) { rcp[decltype(jt)::value] = dyP[L::DY_C + i * NU + P::UMAP[decltype(jt)::value]]; });
 #else
             (void)dyP;

@@ -1016,7 +1016,13 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
     if (!c->stream2)
     {
         if (const char *e = std::getenv("SCPP_IPM_LDS_PAD"))
-            c->ipm_lds_pad = unsigned(std::atoi(e));
+        {
+            // a measurement knob: never-touched dynamic LDS that limits the ipm workgroups per CU.  Clamped so that pad + the LDS-resident segment
+            // fields (up to 21.5 KB at K = 64) + the kernel's 3 KB of static LDS stay inside the 64 KB a workgroup may ask for -- an unclamped
+            // value surfaced only as SCPP_E_HIP from the launch
+            const long want = std::atol(e), room = 65536 - 4096 - long(ipm::segLdsBytes<ipm::RocketQuatSC>(c->K));
+            c->ipm_lds_pad = unsigned(want < 0 ? 0 : (want > room ? room : want));
+        }
         CHECK_HIP(hipStreamCreate(&c->stream2));
         CHECK_HIP(hipEventCreate(&c->ev_skew));
         CHECK_HIP(hipEventCreate(&c->ev_join));
