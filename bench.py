@@ -163,7 +163,7 @@ def measured_traffic():
 
 def parity_summary():
     """Counts of the at-scale parity test of the headline mode (tests/test_gpu_parity.py::test_scvx_at_scale_parity_and_literal_audit writes
-    gpurun_out/r04_parity_at_scale.json; the committed copy under profiles/ is what is reported here, with the kernel-source hash it was
+    gpurun_out/r05_parity_at_scale.json; the committed copy under profiles/ is what is reported here, with the kernel-source hash it was
     taken on): identical records, instances beyond 1e-5 in states / inputs, certified instances."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_at_scale*.json")))
     if not files:
@@ -603,7 +603,10 @@ def main():
             "config": {
                 "workload": f"RocketQuat SCvx (SCvxAlgorithm: fixed final time, hard input trust region, FOH), K={K}, {args.steps} steps x "
                             f"batch={B} randomised initial states per GPU (BASELINE configs[2]/[4]: 8192 per GPU, 65536 on 8), shipped "
-                            f"Falcon-9 model.info + SCvx.info",
+                            f"Falcon-9 model.info + SCvx.info" +
+                            (f"; the literal one-shot batch of configs[2] (ONE batch of {B} through scpp_hip_scvx_solve, its own tail included): "
+                             f"{extras['single_batch']['converged_trajectories_per_s']:.0f} converged/s (config.single_batch)"
+                             if isinstance(extras.get("single_batch"), dict) and "converged_trajectories_per_s" in extras["single_batch"] else ""),
                 "algorithm": "SCvxAlgorithm::solve, cold start per instance; converged = |dL| < change_threshold (SCvxAlgorithm.cpp:125); "
                              "multipleShooting with the reference's 5 RKF78 steps per segment (discretizationImplementation.hpp:141,154)",
                 "engine": (f"scpp_hip_scvx_solve_stream, persistent kernel (csrc/scvx_persistent.h): ONE launch per job, a wavefront per slot ({B} slots, "
