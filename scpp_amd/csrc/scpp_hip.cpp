@@ -334,6 +334,10 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
     return b;
 }
 
+// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
+struct PersistRocketQuat : ipm::RocketQuatSC
+{
+};
 ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r, bool snapshot)
 {
     ipm::KernelArgs a;
@@ -991,11 +995,58 @@ int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
     return SCPP_OK;
 }
 
+extern "C++"
+{
+namespace
+{
+// the whole SCAlgorithm::solve loop of every instance in ONE launch (scvx_persistent.h: sc_persistent_kernel) for the configuration the kernel is
+// instantiated for: RocketQuat, first-order hold, free final time (the shipped SC.info).  -1: not available.
+int scSolvePersistent(scpp_hip_ctx *c)
+{
+    if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->model != SCPP_MODEL_ROCKETQUAT || c->mode != (SCPP_MODE_FOH | SCPP_MODE_VT) || c->sc.max_iterations <= 0)
+        return -1;
+    const Range r = fullRange(c);
+    ScPersistentArgs args;
+    args.a = ipmArgs(c, 1, false, r, false);
+    args.B = c->B;
+    args.K = c->K;
+    args.max_iterations = c->sc.max_iterations;
+    args.disc_steps = c->disc_steps;
+    args.ip = c->ip;
+    args.A = c->A;
+    args.Bm = c->Bm;
+    args.C = c->C;
+    args.S = c->S;
+    args.Z = c->Z;
+    args.active = c->active;
+    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, true>);
+    const bool timed = spanBegin(c, 1, c->B, c->stream);
+    hipLaunchKernelGGL((sc_persistent_kernel<RocketQuatModel, PersistRocketQuat, true, true>), dim3(unsigned(c->B)), dim3(WAVE), seg_b > disc_b ? seg_b : disc_b,
+                       c->stream, args);
+    spanEnd(c, timed, c->stream);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+} // namespace
+} // extern "C++"
+
 int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
 {
     DeviceGuard guard(c);
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
+    {
+        const int prc = scSolvePersistent(c);
+        if (prc > 0 || prc < -1)
+            return prc;
+        if (prc == 0)
+        {
+            int n = 0;
+            if (int rc = countActive(c, &n))
+                return rc;
+            c->last_active = n;
+            return scpp_hip_sc_finish(c, n_converged);
+        }
+    }
     const int B = c->B;
     if (B < 1024 || c->last_active != B)
     {
@@ -1248,10 +1299,6 @@ extern "C++"
 {
 namespace
 {
-// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
-struct PersistRocketQuat : ipm::RocketQuatSC
-{
-};
 // Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
 // caller runs the pool engine.
 int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,

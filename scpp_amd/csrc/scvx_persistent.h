@@ -51,6 +51,24 @@ struct PersistentArgs
     PersistentOut o;
 };
 
+// ---- the SC mode (SCAlgorithm::solve, scpp_core/src/SCAlgorithm.cpp:134-189) on the same pattern: a wavefront takes its instance through up to
+// max_iterations rounds of multipleShooting + sub-problem solve (ipmSolveInstance with do_sc_update = 1 applies readSolution, the weight doubling and
+// the convergence test, and clears `active`); no cost step, no queue ----
+struct ScPersistentArgs
+{
+    ipm::KernelArgs a; // FIRST (ipmSolveInstance's tail)
+    int B, K, max_iterations, disc_steps;
+    const double *ip;            // [B][IP_N]
+    double *A, *Bm, *C, *S, *Z;  // dd of the instances
+    const int *active;
+};
+#ifdef SCPP_HIP_EMU
+struct ScPersistentArgsHolder
+{
+    static inline const ScPersistentArgs *p = nullptr;
+};
+#endif
+
 #ifdef SCPP_HIP_EMU
 #define PERSIST_STEP_FN inline
 template <class T>
@@ -59,6 +77,7 @@ struct PersistentArgsHolder
     static inline const PersistentArgs<T> *p = nullptr; // the emulator runs one kernel at a time on one host thread
 };
 #define PERSIST_ARGS(T, A) const PersistentArgs<T> &A = *PersistentArgsHolder<T>::p
+#define SC_PERSIST_ARGS(A) const ScPersistentArgs &A = *ScPersistentArgsHolder::p
 template <class S>
 inline S argCopy(const S &src)
 {
@@ -70,17 +89,18 @@ inline S argCopy(const S &src)
 // callee -- found as a memory fault at address 0 on the first hardware run): the kernel leaves it in LDS, the steps pick it up from there and
 // make it wave-uniform again (scalar loads from constant memory).
 __shared__ unsigned long long persist_kernarg_address;
-template <class T>
-__device__ inline const __attribute__((address_space(4))) PersistentArgs<T> *persistentArgsLate()
+template <class ARGS>
+__device__ inline const __attribute__((address_space(4))) ARGS *persistentArgsLateOf()
 {
-    typedef const __attribute__((address_space(4))) PersistentArgs<T> CA;
+    typedef const __attribute__((address_space(4))) ARGS CA;
     const unsigned long long v = persist_kernarg_address;
     const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
     CA *p = (CA *)((unsigned long long)lo | ((unsigned long long)hi << 32));
     asm volatile("" : "+s"(p));
     return p;
 }
-#define PERSIST_ARGS(T, A) const __attribute__((address_space(4))) PersistentArgs<T> &A = *persistentArgsLate<T>()
+#define PERSIST_ARGS(T, A) const __attribute__((address_space(4))) PersistentArgs<T> &A = *persistentArgsLateOf<PersistentArgs<T>>()
+#define SC_PERSIST_ARGS(A) const __attribute__((address_space(4))) ScPersistentArgs &A = *persistentArgsLateOf<ScPersistentArgs>()
 // a member struct of the kernel-argument segment, copied word by word (scalar loads from constant memory)
 template <class S>
 __device__ __forceinline__ S argCopy(const __attribute__((address_space(4))) S &src)
@@ -226,6 +246,60 @@ __global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disab
         }
     }
 #endif
+}
+
+// ---- SC mode ----
+template <class Model, bool FOH, bool VT>
+PERSIST_STEP_FN void scPersistDiscretize(long slot)
+{
+    SC_PERSIST_ARGS(A);
+    const int B = A.B, K = A.K, steps = A.disc_steps;
+    const double *X = A.a.X, *U = A.a.U, *sigma = A.a.sigma, *par = A.ip + ipm::IP_PAR;
+    double *Ao = A.A, *Bo = A.Bm, *Co = A.C, *So = A.S, *Zo = A.Z;
+#ifdef SCPP_HIP_EMU
+    static DiscLds<Model, FOH, VT> lds_obj;
+    DiscLds<Model, FOH, VT> *lds = &lds_obj;
+#else
+    extern __shared__ double seg_lds[];
+    DiscLds<Model, FOH, VT> *lds = reinterpret_cast<DiscLds<Model, FOH, VT> *>(seg_lds);
+#endif
+    for (int k = 0; k < K - 1; k++)
+    {
+        discretizeSegment<Model, FOH, VT>(B, K, X, U, sigma, par, ipm::IP_N, nullptr, Ao, Bo, Co, So, Zo, steps, slot, k, lds);
+        WAVE_SYNC();
+    }
+    stepFence();
+}
+template <class P>
+PERSIST_STEP_FN void scPersistSolve(long slot)
+{
+    SC_PERSIST_ARGS(A);
+    const ipm::KernelArgs a = argCopy(A.a);
+    ipm::ipmSolveInstance<P>(a, int(slot), &A.a);
+    stepFence();
+}
+template <class Model, class P, bool FOH, bool VT>
+__global__ void __launch_bounds__(WAVE, IPM_WAVES_PER_SIMD) __attribute__((disable_tail_calls)) sc_persistent_kernel(ScPersistentArgs args)
+{
+#ifdef SCPP_HIP_EMU
+    ScPersistentArgsHolder::p = &args;
+#else
+    if (threadIdx.x == 0)
+        persist_kernarg_address = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    WAVE_SYNC();
+#endif
+    const long slot = blockIdx.x;
+    if (slot >= args.B)
+        return;
+    const int max_iterations = args.max_iterations;
+    for (int it = 0; it < max_iterations; it++)
+    {
+        SC_PERSIST_ARGS(A);
+        if (uniformLoad(A.active + slot) == 0)
+            break; // converged, failed, or at its iteration limit (the solve's tail clears the flag)
+        scPersistDiscretize<Model, FOH, VT>(slot);
+        scPersistSolve<P>(slot);
+    }
 }
 
 } // namespace scpp

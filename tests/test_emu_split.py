@@ -90,3 +90,23 @@ def test_persistent_stream_engine_rows_are_bitwise_the_pool_engine(model, emu_li
     ref = alg.getSolution()
     for key in KEYS:
         assert np.array_equal(_bits(got[key]), _bits(ref[key])), key
+
+
+def test_persistent_sc_loop_is_bitwise_the_launch_loop(model, emu_lib):
+    """scpp_hip_sc_solve on the persistent kernel (one launch: every wavefront takes its instance through up to max_iterations rounds of
+    multipleShooting + solve, csrc/scvx_persistent.h: sc_persistent_kernel) against the loop of launches (scpp_hip_set_stream_engine(POOLS) selects
+    it): same bodies, same order -- bitwise, incl. a partially masked batch and a warm-started second solve (the SC_sim pattern)."""
+    outs = []
+    for engine in (_lib.STREAM_POOLS, _lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCAlgorithm(model, K=8, batch_max=4, library=emu_lib).initialize()
+        alg.ctx.set_stream_engine(engine)
+        x0 = model.randomized_initial_states(4, first=21)
+        alg.solve(x0)
+        a = alg.getSolution()
+        alg.solve(x0 * (1.0 + 1e-3 * np.arange(4)[:, None] * (np.arange(14) == 3)), warm_start=True)
+        b = alg.getSolution()
+        outs.append((a, b))
+    for i in range(2):
+        for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "converged", "status", "ipm_iters"):
+            assert np.array_equal(_bits(outs[0][i][key]), _bits(outs[1][i][key])), (i, key)
+    assert outs[0][0]["ipm_iters"].min() > 20

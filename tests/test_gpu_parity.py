@@ -948,3 +948,31 @@ def test_emulator_and_gpu_agree_to_rounding_not_bitwise(model, hip_lib, emu_lib)
             bitwise &= bool(np.array_equal(g[key], e[key]))
             print("emulator vs GPU, %s %s: max relative difference %.1e" % (mode, key, rel))
     print("emulator == GPU bitwise: %s" % bitwise)
+
+
+def test_persistent_sc_loop_equals_launch_loop_on_gpu(model, hip_lib):
+    """scpp_hip_sc_solve (what SC_oneshot / SC_sim run) on the persistent kernel -- ONE launch, every wavefront takes its instance through the 15
+    SCAlgorithm iterations -- against the two-stream loop of launches of rounds 1 - 4 (scpp_hip_set_stream_engine(POOLS)): 2048 instances at K = 50, a
+    cold solve and a warm-started one, every output bitwise; and the time of each."""
+    import time
+
+    B = 2048
+    x0 = model.randomized_initial_states(B, first=90_000)
+    outs, secs = [], []
+    for engine in (scpp_amd._lib.STREAM_POOLS, scpp_amd._lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCAlgorithm(model, K=50, batch_max=B, library=hip_lib).initialize()
+        alg.ctx.set_stream_engine(engine)
+        alg.solve(x0[:64])  # module load
+        t0 = time.time()
+        alg.solve(x0)
+        secs.append(time.time() - t0)
+        a = alg.getSolution()
+        alg.solve(x0, warm_start=True)
+        b = alg.getSolution()
+        alg.ctx.close()
+        outs.append((a, b))
+    for i in range(2):
+        for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "converged", "status", "ipm_iters"):
+            assert np.array_equal(outs[0][i][key], outs[1][i][key]), (i, key)
+    assert (outs[0][0]["status"] == 0).all() and (outs[0][0]["sc_iters"] == 15).all()
+    print("SC mode, %d instances: loop of launches %.3f s, persistent kernel %.3f s; cold and warm-started results bitwise equal" % (B, secs[0], secs[1]))

@@ -8,7 +8,7 @@ g++ -O1 -g -std=c++17 -fPIC -DSCPP_HIP_EMU -fsanitize=address,undefined -fno-omi
     -o $OUT/libscpp_emu_asan.so -x c++ scpp_amd/csrc/scpp_hip.cpp 2> $OUT/build.log || { tail $OUT/build.log; exit 1; }
 export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" SCPP_EMU_LIBRARY=$OUT/libscpp_emu_asan.so \
-    python -m pytest tests/test_emu_kernels.py tests/test_emu_stream_fuzz.py tests/test_emu_batch_independence.py tests/test_mpc.py tests/test_abi_errors.py tests/test_sc_loop_pin.py tests/test_subproblem_pin.py \
+    python -m pytest tests/test_emu_kernels.py tests/test_emu_split.py tests/test_emu_stream_fuzz.py tests/test_emu_batch_independence.py tests/test_mpc.py tests/test_abi_errors.py tests/test_sc_loop_pin.py tests/test_subproblem_pin.py \
     -q -m "not gpu" > $OUT/run.log 2>&1
 echo "pytest rc=$?"; grep -c "ERROR: AddressSanitizer\|runtime error" $OUT/run.log; tail -2 $OUT/run.log
 # the oracle (test infrastructure) under the same sanitizers
