@@ -77,6 +77,8 @@ struct scpp_hip_ctx
     scpp_rocket2d_params mp2{};
     scpp_socp_opts socp{1e-8, 1e-7, 1e-7, 60, 1};
     bool sc_ready = false, par_from_ip = false;
+    bool sc_warm = false; // the last scpp_hip_sc_setup was a warm start
+    int sc_persistent_min = 3072; // smallest cold batch scpp_hip_sc_solve gives to the persistent kernel (SCPP_SC_PERSISTENT_MIN: tests)
     int mode = SCPP_MODE_FOH | SCPP_MODE_VT;
     // timing
     struct Span
@@ -597,6 +599,9 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     if (const char *e = std::getenv("SCPP_STREAM_ENGINE"))
         if (std::atoi(e) == SCPP_STREAM_POOLS || std::atoi(e) == SCPP_STREAM_PERSISTENT)
             c->stream_engine = std::atoi(e);
+    if (const char *e = std::getenv("SCPP_SC_PERSISTENT_MIN"))
+        if (std::atoi(e) > 0)
+            c->sc_persistent_min = std::atoi(e);
     if (const char *e = std::getenv("SCPP_IPM_SPLIT_PAIRS"))
         if (std::atoi(e) > 0)
             c->ipm_split_pairs = std::atoi(e);
@@ -888,6 +893,7 @@ int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const s
     SCBuffers b = scBuffers(c);
     hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
     c->sc_ready = true;
+    c->sc_warm = warm_start != 0;
     c->par_from_ip = true;
     c->last_active = B;
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
@@ -923,6 +929,7 @@ int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, 
     SCBuffers b = scBuffers(c);
     hipLaunchKernelGGL(sc_setup_r2d_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp2, c->sc, warm_start);
     c->sc_ready = true;
+    c->sc_warm = warm_start != 0;
     c->par_from_ip = true;
     c->last_active = B;
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
@@ -1004,6 +1011,13 @@ namespace
 int scSolvePersistent(scpp_hip_ctx *c)
 {
     if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->model != SCPP_MODEL_ROCKETQUAT || c->mode != (SCPP_MODE_FOH | SCPP_MODE_VT) || c->sc.max_iterations <= 0)
+        return -1;
+    // Where it pays (measured, same box, alternating: profiles/r05_ab_persistent_batch_sizes.json): a COLD solve of a batch that fills the chip more than
+    // once.  A wavefront integrates its instance's 49 segments one after the other here, where discretize_kernel spreads them over 49 wavefronts: below
+    // ~3000 instances the chip is not full and the serial integration shows (cold solve of 256 / 1024 / 2048 instances: -29 % / -8 % / +-0, 4096 / 8192:
+    // +4.6 % / +4.0 %), and in a warm-started solve (SC_sim: 7 interior-point iterations per sub-problem instead of 22) the integration is half of the
+    // work (4096 instances: -3 %, 1024: -12 %).
+    if (c->sc_warm || c->B < c->sc_persistent_min)
         return -1;
     const Range r = fullRange(c);
     ScPersistentArgs args;

@@ -102,6 +102,13 @@ public:
         if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
             throw std::invalid_argument("setDiscretizationSteps: 0 (adaptive) or 1 .. 5");
     }
+    // How the device schedules the loop (include/scpp_hip.h): SCPP_STREAM_PERSISTENT (default: one kernel launch, a wavefront takes its instance through
+    // the whole algorithm) or SCPP_STREAM_POOLS (rounds of launches); the results are bitwise the same.  Call after initialize().
+    void setStreamEngine(int engine)
+    {
+        if (scpp_hip_set_stream_engine(ctx, engine) != SCPP_OK)
+            throw std::invalid_argument("setStreamEngine: SCPP_STREAM_POOLS or SCPP_STREAM_PERSISTENT");
+    }
 
     // ---- the reference's single-problem interface (instance = model->p.x_init) ----
     void solve(bool warm_start = false)
@@ -283,6 +290,13 @@ public:
     {
         if (scpp_hip_set_discretization_steps(ctx, steps) != SCPP_OK)
             throw std::invalid_argument("setDiscretizationSteps: 0 (adaptive) or 1 .. 5");
+    }
+    // How the device schedules the loop (include/scpp_hip.h): SCPP_STREAM_PERSISTENT (default: one kernel launch, a wavefront takes its instance through
+    // the whole algorithm) or SCPP_STREAM_POOLS (rounds of launches); the results are bitwise the same.  Call after initialize().
+    void setStreamEngine(int engine)
+    {
+        if (scpp_hip_set_stream_engine(ctx, engine) != SCPP_OK)
+            throw std::invalid_argument("setStreamEngine: SCPP_STREAM_POOLS or SCPP_STREAM_PERSISTENT");
     }
     void solve(bool warm_start = false)
     {

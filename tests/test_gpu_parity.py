@@ -952,11 +952,12 @@ def test_emulator_and_gpu_agree_to_rounding_not_bitwise(model, hip_lib, emu_lib)
 
 def test_persistent_sc_loop_equals_launch_loop_on_gpu(model, hip_lib):
     """scpp_hip_sc_solve (what SC_oneshot / SC_sim run) on the persistent kernel -- ONE launch, every wavefront takes its instance through the 15
-    SCAlgorithm iterations -- against the two-stream loop of launches of rounds 1 - 4 (scpp_hip_set_stream_engine(POOLS)): 2048 instances at K = 50, a
-    cold solve and a warm-started one, every output bitwise; and the time of each."""
+    SCAlgorithm iterations; the library uses it for cold solves of >= 3072 instances, where it is faster -- against the two-stream loop of launches
+    of rounds 1 - 4 (scpp_hip_set_stream_engine(POOLS)): 4096 instances at K = 50, a cold solve (persistent vs loop) and a warm-started one on the state
+    it left (the loop on both sides), every output bitwise; and the time of each."""
     import time
 
-    B = 2048
+    B = 4096
     x0 = model.randomized_initial_states(B, first=90_000)
     outs, secs = [], []
     for engine in (scpp_amd._lib.STREAM_POOLS, scpp_amd._lib.STREAM_PERSISTENT):
