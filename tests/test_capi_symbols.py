@@ -31,3 +31,21 @@ def test_python_binding_covers_header():
 def test_library_contains_gfx950_code_object(hip_lib):
     blob = open(hip_lib, "rb").read()
     assert b"gfx950" in blob and b"ipm_kernel" in blob and b"discretize_kernel" in blob
+
+
+def test_committed_profiles_are_of_these_sources():
+    """The PMC and parity summaries bench.py imports (roofline.traffic, config.parity) carry the content hash of the kernel sources + floating-point
+    build flags they were measured on (tools/csrc_hash.py).  The newest committed ones must be of THESE sources: a kernel change without a new
+    measurement session would otherwise ship a bench line that says `"stale": true`."""
+    import glob
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import csrc_hash
+
+    here = csrc_hash.csrc_sha()
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_pmc_hbm_v*.json")))[-1]
+    assert json.load(open(pmc))["csrc_sha"] == here, (pmc, here)
+    par = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_parity_at_scale*.json")))[-1]
+    assert json.load(open(par))["csrc_sha"] == here, (par, here)
