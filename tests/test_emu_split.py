@@ -113,3 +113,21 @@ def test_persistent_sc_loop_is_bitwise_the_launch_loop(model, emu_lib, monkeypat
         for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "converged", "status", "ipm_iters"):
             assert np.array_equal(_bits(outs[0][i][key]), _bits(outs[1][i][key])), (i, key)
     assert outs[0][0]["ipm_iters"].min() > 20
+
+
+def test_persistent_cost_step_with_two_passes_of_segment_pairs(model, emu_lib):
+    """K = 34: 33 segments = one full pass of 32 lane pairs + a second pass with a single pair (scvxCostUpdateSplit takes the K - 1 segments through in
+    passes of 32 pairs; the BASELINE's K = 50 is two passes as well, but only the GPU suite runs it).  Persistent kernel against the pool engine, rows
+    bitwise."""
+    K, N, S, maxit = 34, 3, 2, 3
+    x0 = model.randomized_initial_states(N, first=60)
+    rows = []
+    for engine in (_lib.STREAM_POOLS, _lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=S, library=emu_lib, max_iterations=maxit).initialize()
+        alg.ctx.set_stream_engine(engine)
+        alg.solveStream(x0, slots=S)
+        rows.append(alg.ctx.stream_download_rows())
+        assert alg.ctx.stream_rounds()["pools"] == (0 if engine == _lib.STREAM_PERSISTENT else 1)
+    assert np.array_equal(_bits(rows[0]), _bits(rows[1]))
+    got = scpp_amd.Context.unpack_stream_rows(rows[1], K)
+    assert (got["status"] == 0).all() and got["solves"].sum() >= N * maxit and (got["nonlinear_cost"] > 0).all()
