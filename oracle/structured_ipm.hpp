@@ -1273,7 +1273,8 @@ class RQStructuredSocp
             if (opt.verbose)
                 std::printf("%3d  pcost %+.8e gap %.2e pres %.2e dres %.2e mu %.2e sigma %.6f n1 %.3e\n", iter, pcost, gap,
                             pres, dres, mu, sig, n1);
-            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) ||
+            // (1e30: csrc/ipm_solve.h IPM_BLOWN -- a blown-up iterate has pres ~ 0 in these RELATIVE measures and would pass as optimal)
+            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) || std::fabs(pcost) > 1e30 || gap > 1e30 ||
                 (bk_valid && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
             {
                 if (!bk_valid)

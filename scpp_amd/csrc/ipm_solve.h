@@ -11,6 +11,14 @@ namespace scpp
 namespace ipm
 {
 
+// Magnitude beyond which the primal cost or the complementarity gap marks an iterate as numerically broken (treated like a non-finite residual: the last
+// iterate that met the reduced tolerances is returned, or the solve fails and a warm-started attempt is repeated cold).  Why it exists (round 5, instance
+// 8392 of the bench's randomised states): one step of a warm-started solve came back with entries of 1e154 -- a broken factorisation, finite -- and
+// because every residual is measured RELATIVE to the iterate's norm, the blown-up point showed pres = 0, passed the convergence test as "optimal" and
+// handed inputs of 1e154 N to the next discretisation.  The sub-problems are nondimensional (costs 1e-2 .. 1e3; Rocket2D in SI units: 1e5, gaps up to
+// 1e9 at the cold start): 1e30 is never a value of a working iterate.
+#define IPM_BLOWN 1e30
+
 // wave-uniform scalars (every lane holds the same values)
 struct Glob
 {
@@ -1425,6 +1433,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     p_dl = waveSumDpp(p_dl);
     const Glob g = reloadPriv(gp);
     Iter it = reloadPriv(ip_);
+    const double pres_before = it.pres; // the previous iteration's (meaningful while a backup of THIS solve exists: bk_valid is cleared at the solve's start)
     const double sas = g.sig - 0.001, sa3 = g.n1 - p.sumnb;
     const double sac[3] = {0.5 + 0.5 * g.dsg, 0.5 - 0.5 * g.dsg, g.sig - g.sigbar};
     it.rzs = g.ss - sas;
@@ -1462,7 +1471,14 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     {
         // keep the iterate if it already meets ECOS's reduced tolerances (returned if the path breaks down later)
         const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
-        const bool inacc = it.pres < 1e-4 && it.dres < 1e-4 && (it.gap < 5e-5 || it.gap / apc < 5e-5);
+        // ... unless it is BROKEN by the very test the solver's loop applies next (ipmSolveInstance: non-finite, blown up, or the residuals exploded / the
+        // gap went negative after a backup existed).  The scalar twin runs that test BEFORE it saves (oracle/structured_ipm.hpp); here the save comes
+        // first, and until round 5 a blown-up iterate -- pres = 0 in these relative measures, gap = -2.3e303 < 5e-5 -- OVERWROTE the good backup it
+        // was about to be replaced by: instance 8392 returned inputs of 1e154 N with status 0 (bench line: solver_failures 1 of 32768).
+        const bool broken = !(it.pres == it.pres) || !(it.dres == it.dres) || !(it.gap == it.gap) || fabs(it.pres) > 1e300 || fabs(it.dres) > 1e300 ||
+                            fabs(it.gap) > IPM_BLOWN || fabs(it.pcost) > IPM_BLOWN ||
+                            (it.bk_valid != 0 && (it.pres > 500. * pres_before || it.gap < 0.));
+        const bool inacc = !broken && it.pres < 1e-4 && it.dres < 1e-4 && (it.gap < 5e-5 || it.gap / apc < 5e-5);
         if (inacc)
         {
             if (v.vst)
@@ -2343,7 +2359,8 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
             const double pres = it.pres, dres = it.dres, gap = it.gap;
             const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
             const double relgap = gap / apc;
-            const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300;
+            const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300 ||
+                                   fabs(it.pcost) > IPM_BLOWN || gap > IPM_BLOWN; // a BLOWN-UP iterate is a broken one: see IPM_BLOWN
             // ECOS-style safeguarding: residual explosion after an acceptable iterate -> return that iterate
             if (nonfinite || (bk_prev && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
             {

@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
                 const double pres = it.pres, dres = it.dres, gap = it.gap;
                 const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
                 const double relgap = gap / apc;
-                const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300;
+                const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300 ||
+                                   fabs(it.pcost) > IPM_BLOWN || gap > IPM_BLOWN; // a BLOWN-UP iterate is a broken one: see IPM_BLOWN
                 if (nonfinite || (bk_prev && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
                 {
                     status = bk_prev ? 0 : -2;
