@@ -977,3 +977,27 @@ def test_persistent_sc_loop_equals_launch_loop_on_gpu(model, hip_lib):
             assert np.array_equal(outs[0][i][key], outs[1][i][key]), (i, key)
     assert (outs[0][0]["status"] == 0).all() and (outs[0][0]["sc_iters"] == 15).all()
     print("SC mode, %d instances: loop of launches %.3f s, persistent kernel %.3f s; cold and warm-started results bitwise equal" % (B, secs[0], secs[1]))
+
+
+def test_broken_iterate_does_not_replace_the_fallback_on_gpu(oracle, model, hip_lib):
+    """Round 5 regression: instance 8392 of the bench's randomised states.  In its second sub-problem one interior-point step of the warm-started solve
+    comes back with entries of 1e154 (finite).  Every residual measure is RELATIVE to the iterate's norm, so the blown-up point has pres = 0 and
+    gap = -2.3e303 < 5e-5 -- it met the "reduced tolerances" under which phResiduals keeps a fall-back iterate, OVERWROTE the good fall-back of the
+    iteration before, and came back as that fall-back with status 0: inputs of 1e154 N, a NaN discretisation and a solver failure one solve later
+    (bench line: solver_failures 1 of 32768; the scalar twin applies the breakdown test before it saves and never had the hole).  Now the save is
+    skipped for an iterate the loop's own test rejects.  The instance must converge with the twin's counts (19 iterations, 27 solves), on both
+    engines and inside a batch."""
+    s = oracle.SCvx(K=50); s.set_solver(1); s.randomize(20260927, 8392)
+    assert s.solve() == 0
+    mm = s.meta()
+    assert mm["converged"] == 1
+    x = model.randomized_initial_states(64, first=8392 - 10)  # instance 8392 is row 10
+    for engine in (scpp_amd._lib.STREAM_POOLS, scpp_amd._lib.STREAM_PERSISTENT):
+        alg = scpp_amd.SCvxAlgorithm(model, K=50, batch_max=64, library=hip_lib).initialize()
+        alg.ctx.set_stream_engine(engine)
+        n = alg.solve(x)
+        o = alg.getSolution()
+        alg.ctx.close()
+        assert n == 64 and (o["status"] == 0).all() and np.isfinite(o["U"]).all() and np.abs(o["U"]).max() < 1e6
+        assert int(o["sc_iters"][10]) == mm["iterations"] and int(o["solves"][10]) == mm["solves"], (o["sc_iters"][10], o["solves"][10], mm)
+    print("instance 8392: converged in %d iterations / %d solves on both engines, as the twin" % (mm["iterations"], mm["solves"]))
