@@ -41,8 +41,17 @@ FLOP_PER_IPM_ITER = 2.0e6        # one Mehrotra iteration of one instance: 1 fac
 FLOP_PER_SOCP_INIT = 1.6e6       # W=I factorisation + 2 solves + border (cold start: once per instance)
 IPM_ALGO_BYTES_PER_SOLVE = 131712 + 7208 + 7200  # read dd + td, write X, U: what one sub-problem solve must move
 DISC_BYTES_PER_INSTANCE = 139000  # 7,288 B read + 131,712 B written per instance-call
-DISC_FLOP_PER_RHS = 18.6e3        # one evaluation of the augmented right-hand side (J V on the matrix core + flow map + Jacobian rows)
-COST_FLOP_PER_SOLVE = 3.3e6       # getNonlinearCost of one candidate: 49 segments x 20 RKF78 steps x 13 stages x (flow map ~150 flop + stage combination)
+# One evaluation of the augmented right-hand side of the headline mode (first-order hold, fixed final time: V = [x | Phi | Psi_B | Psi_C], 14 x 23),
+# counted from what discretizeSegment executes USEFULLY (14-wide, not the 16-wide tiles the matrix core multiplies):
+#   A (14 x 14) times the 22 sensitivity columns            14 * 14 * 22 * 2 = 8 624
+#   input forcing of Psi_B, Psi_C (B scaled by (dt-t)/dt, t/dt)  2 * 14 * 4 * 2 =   224
+#   flow map + the 61 structural non-zeros of its Jacobian     ~   450
+#   Runge-Kutta combination: 55 non-zero a_ij + 7 non-zero b_j of RKF78 on 14 * 23 entries, per stage (62 * 322 * 2 / 13)   3 071
+# = 12.4 kflop.  (Rounds 3 - 5 priced it at 18.6 k, the 16-wide tile count; SURVEY 8(d)'s 19.7 k is the reference's Phi^-1 formulation.)
+DISC_FLOP_PER_RHS = 12.4e3
+# getNonlinearCost of one candidate (SCvxAlgorithm.cpp:262-278): 49 segments x 20 RKF78 steps x 13 stages = 12 740 flow-map evaluations of ~120 flop
+# + their share of the stage combination (62 * 14 * 2 / 13 = 134 flop per stage) = 12 740 x 254
+COST_FLOP_PER_SOLVE = 3.2e6
 DISC_MAX_STEP = 12.0 / (14.0 * 5.0)  # csrc/discretize_kernel.h, opt-in rule: n = clamp(ceil(segment seconds / this), 1, 5) RKF78 steps per segment
 PEAK_FP64_TFLOPS = 78.6           # MI355X FP64 vector == FP64 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
@@ -163,7 +172,7 @@ def measured_traffic():
 
 def parity_summary():
     """Counts of the at-scale parity test of the headline mode (tests/test_gpu_parity.py::test_scvx_at_scale_parity_and_literal_audit writes
-    gpurun_out/r05_parity_at_scale.json; the committed copy under profiles/ is what is reported here, with the kernel-source hash it was
+    gpurun_out/r06_parity_at_scale.json; the committed copy under profiles/ is what is reported here, with the kernel-source hash it was
     taken on): identical records, instances beyond 1e-5 in states / inputs, certified instances."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_at_scale*.json")))
     if not files:
@@ -554,6 +563,8 @@ def main():
         assert socp_s <= dt * 1.001, f"ipm_kernel time {socp_s:.3f} s exceeds the timed region {dt:.3f} s"
         achieved_tf = socp_flops_all / socp_s / 1e12 if socp_s > 0 else 0.0
         achieved_tf_span_sum = socp_flops_all / span_sum_s / 1e12 if span_sum_s > 0 else 0.0
+        # continuity with rounds 1 - 4: the interior-point flops alone over the same kernel time
+        achieved_tf_solve_only = socp_flops / socp_s / 1e12 if socp_s > 0 else 0.0
         pmc = measured_traffic()
         traffic = None
         traffic_source = None
@@ -577,6 +588,15 @@ def main():
                             f"passes, of ipm_kernel at commit {d.get('commit', '?')}, {d.get('calibration', 'uncalibrated')}) = "
                             f"{d['ipm_bytes_per_instance_iteration']:.3e} B per instance-IPM-iteration, scaled by this run's iterations "
                             f"per launch; algorithmic minimum (read dd + td, write X, U) = {IPM_ALGO_BYTES_PER_SOLVE} B per instance-solve")
+        # matrix-core utilisation from the same imported PMC summary (tools/pmc_hbm.sh: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), and the
+        # executed matrix-core flops SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 over that pass's kernel time): the two must agree (busy fraction x peak ~ executed)
+        mfma_pipe = None
+        if pmc is not None and isinstance(pmc[1].get("ipm_mfma"), dict):
+            mm = pmc[1]["ipm_mfma"]
+            mfma_pipe = {"mfma_pipe_busy_frac": mm.get("mfma_pipe_busy_frac"), "executed_mfma_TFLOPs": mm.get("executed_mfma_TFLOPs"),
+                         "executed_mfma_frac_of_fp64_peak": mm.get("executed_mfma_frac_of_fp64_peak"),
+                         "note": "imported with `traffic` (same summary, same staleness flag); executed = 16-wide tile flops incl. padding and the transposes' "
+                                 "structural zeros, so it exceeds the algorithmic `achieved`"}
         measured_gbs = (traffic * launches / socp_s / 1e9) if (traffic is not None and socp_s > 0) else None
         mfma_frac = achieved_tf / PEAK_FP64_TFLOPS
         hbm_frac = measured_gbs / PEAK_HBM_GBS if measured_gbs is not None else None
@@ -641,6 +661,11 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": mfma_frac,
+                "achieved_definition": ("ALL steps of the kernel (interior-point solve + multipleShooting + candidate cost: flop_model) over its duration"
+                                        if persistent else "the interior-point solve's flops over the kernel time"),
+                "achieved_solve_only": achieved_tf_solve_only,   # the interior-point flops alone (what rounds 1 - 4 reported as `achieved`)
+                "frac_solve_only": achieved_tf_solve_only / PEAK_FP64_TFLOPS,
+                "mfma_pipe": mfma_pipe,
                 "limiting_resource": limiting,
                 "traffic": traffic,
                 "traffic_source": traffic_source,

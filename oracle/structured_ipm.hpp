@@ -1274,7 +1274,8 @@ class RQStructuredSocp
                 std::printf("%3d  pcost %+.8e gap %.2e pres %.2e dres %.2e mu %.2e sigma %.6f n1 %.3e\n", iter, pcost, gap,
                             pres, dres, mu, sig, n1);
             // (1e30: csrc/ipm_solve.h IPM_BLOWN -- a blown-up iterate has pres ~ 0 in these RELATIVE measures and would pass as optimal)
-            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) || std::fabs(pcost) > 1e30 || gap > 1e30 ||
+            // (round 6: two-sided in the gap, and a gap below -1e-6 = IPM_NEG_GAP is broken with or without a fall-back: the iterate left the cone)
+            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) || std::fabs(pcost) > 1e30 || std::fabs(gap) > 1e30 || gap < -1e-6 ||
                 (bk_valid && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
             {
                 if (!bk_valid)

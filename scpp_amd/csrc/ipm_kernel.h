@@ -134,13 +134,18 @@ constexpr int LANES = 64;
 __host__ __device__ inline int recPitch(int K) { return (K + 1) & ~1; }
 constexpr int GSAVE = 16; // wave-uniform scalars of the last solve (sigma, delta_sigma, n1 and their slacks / duals): warm start
 constexpr int RSAVE = 112; // resume block of the split schedule (ipm_split.h): Glob + Iter + the loop's locals between two launches
+// extra doubles between the workspaces of consecutive instances (a multiple of 16: measurement hook for the address-interleaving experiments of round 6)
+#ifndef IPM_WS_PAD
+#define IPM_WS_PAD 0
+#endif
+static_assert(IPM_WS_PAD % 16 == 0, "workspaces start on a 128-byte line");
 template <class P>
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
     using L = Lay<P>;
     // the exchange records come first so that they start on a 128-byte line; the total is a multiple of a line
     const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE + RSAVE;
-    return (n + 15) & ~size_t(15);
+    return ((n + 15) & ~size_t(15)) + IPM_WS_PAD;
 }
 
 // Strided view of one lane's record, addressed through a buffer resource: every access is

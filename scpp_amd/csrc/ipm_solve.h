@@ -18,6 +18,12 @@ namespace ipm
 // handed inputs of 1e154 N to the next discretisation.  The sub-problems are nondimensional (costs 1e-2 .. 1e3; Rocket2D in SI units: 1e5, gaps up to
 // 1e9 at the cold start): 1e30 is never a value of a working iterate.
 #define IPM_BLOWN 1e30
+// A complementarity gap below -IPM_NEG_GAP is not a rounding artefact of an interior point (s and z inside the cone give s'z > 0): the iterate has left
+// the cone.  Round 6: until then a negative gap counted as broken only once a fall-back iterate existed; without one, `gap < abstol`
+// held trivially and a point with pres, dres below the tolerances and a gap of -1e29 returned status 0.  The magnitude test is two-sided now and a
+// negative gap is broken with or without a fall-back, here, in the split schedule (ipm_split.h) and in the scalar twin (oracle/structured_ipm.hpp).
+#define IPM_NEG_GAP 1e-6
+__device__ inline bool ipmGapBroken(double gap) { return fabs(gap) > IPM_BLOWN || gap < -IPM_NEG_GAP; }
 
 // wave-uniform scalars (every lane holds the same values)
 struct Glob
@@ -1468,6 +1474,29 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         const double d3 = it.resx0 + ny_ + nz_ > 1. ? it.resx0 + ny_ + nz_ : 1.;
         it.dres = sqrt(nrx) / d3;
     }
+#ifdef SCPP_HIP_EMU
+    // Test support (emulator build only): SCPP_EMU_INJECT_RES="n:pres:dres:gap" replaces the termination quantities of the n-th residual evaluation of
+    // every instance of the process (counted per lane: the lanes of the emulated wavefront are fibers of one host thread) -- a numerically broken
+    // iterate on demand, for the regression tests of the breakdown rules (IPM_BLOWN, IPM_NEG_GAP).
+    {
+        static int calls[LANES];
+        static int inj_n = -2;
+        static double inj_v[3];
+        if (inj_n == -2)
+        {
+            const char *e = getenv("SCPP_EMU_INJECT_RES");
+            inj_n = -1;
+            if (e && sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
+                inj_n = -1;
+        }
+        if (inj_n >= 0 && calls[c.lane & (LANES - 1)]++ == inj_n)
+        {
+            it.pres = inj_v[0];
+            it.dres = inj_v[1];
+            it.gap = inj_v[2];
+        }
+    }
+#endif
     {
         // keep the iterate if it already meets ECOS's reduced tolerances (returned if the path breaks down later)
         const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
@@ -1476,7 +1505,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         // first, and until round 5 a blown-up iterate -- pres = 0 in these relative measures, gap = -2.3e303 < 5e-5 -- OVERWROTE the good backup it
         // was about to be replaced by: instance 8392 returned inputs of 1e154 N with status 0 (bench line: solver_failures 1 of 32768).
         const bool broken = !(it.pres == it.pres) || !(it.dres == it.dres) || !(it.gap == it.gap) || fabs(it.pres) > 1e300 || fabs(it.dres) > 1e300 ||
-                            fabs(it.gap) > IPM_BLOWN || fabs(it.pcost) > IPM_BLOWN ||
+                            ipmGapBroken(it.gap) || fabs(it.pcost) > IPM_BLOWN ||
                             (it.bk_valid != 0 && (it.pres > 500. * pres_before || it.gap < 0.));
         const bool inacc = !broken && it.pres < 1e-4 && it.dres < 1e-4 && (it.gap < 5e-5 || it.gap / apc < 5e-5);
         if (inacc)
@@ -2271,7 +2300,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     static double seg_lds[NSEGLDS * 16 * 64];
     c.segl = seg_lds;
 #else
-    extern __shared__ double seg_lds[];
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[]; // 16-byte base: DiscLds members are aligned(16) (b128 LDS accesses), whatever the static LDS before it adds up to
     c.segl = (LDSP double *)seg_lds;
 #endif
     const Settings opt = a.opt;
@@ -2360,7 +2389,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
             const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
             const double relgap = gap / apc;
             const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300 ||
-                                   fabs(it.pcost) > IPM_BLOWN || gap > IPM_BLOWN; // a BLOWN-UP iterate is a broken one: see IPM_BLOWN
+                                   fabs(it.pcost) > IPM_BLOWN || ipmGapBroken(gap); // a BLOWN-UP iterate is a broken one: see IPM_BLOWN, IPM_NEG_GAP
             // ECOS-style safeguarding: residual explosion after an acceptable iterate -> return that iterate
             if (nonfinite || (bk_prev && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
             {

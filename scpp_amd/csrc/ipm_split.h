@@ -100,6 +100,35 @@ __device__ inline void loadUniform(PRIV T *dst, const double *src, int lane)
         d[i] = src[i];
 }
 
+// ---- finalising pass of a TRUNCATED schedule (round 6) ----
+// With fewer (factor, rest) launch pairs than the worst case 2 maxit + 1 -- scpp_hip_set_ipm_schedule(ctx, SCPP_IPM_SPLIT, pairs) or SCPP_IPM_SPLIT_PAIRS,
+// the measurement hooks -- an instance can still be waiting for a factor sweep (PC_INIT_F / PC_MAIN_F) when the last launch ends.  It has written no
+// outputs: status, X / U and the warm flag would keep the previous solve's values and, in SC mode, sc_iters and active would not move -- stale results
+// reported as successes.  This pass retires such an instance as an iteration-limit failure (status -1, no warm start, SC loop stopped), which is what
+// the resident kernel reports when it runs out of iterations.  One lane per instance; nothing to do for an instance that finished.
+template <class P>
+__global__ void __launch_bounds__(WAVE) ipm_split_finalize_kernel(KernelArgs a)
+{
+    const int inst = blockIdx.x * WAVE + threadIdx.x;
+    if (inst >= a.B)
+        return;
+    if (a.active && a.active[inst] == 0)
+        return;
+    double *rl = splitCtx<P>(a, inst, 0).gsave + GSAVE + RS_LOC; // the loop's locals in the resume block
+    const int pc = int(rl[RL_PC]);
+    if (pc != PC_INIT_F && pc != PC_MAIN_F)
+        return;
+    rl[RL_PC] = PC_DONE;
+    a.status[inst] = -1;
+    if (a.warm)
+        a.warm[inst] = 0;
+    if (a.do_sc_update)
+    {
+        a.sc_iters[inst] += 1;
+        a.active[inst] = 0;
+    }
+}
+
 // ---- kernel A: everything but the factor sweep ----
 template <class W>
 __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_tail_calls)) ipm_split_kernel(KernelArgs a, int first)
@@ -250,7 +279,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
                 const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
                 const double relgap = gap / apc;
                 const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300 ||
-                                   fabs(it.pcost) > IPM_BLOWN || gap > IPM_BLOWN; // a BLOWN-UP iterate is a broken one: see IPM_BLOWN
+                                   fabs(it.pcost) > IPM_BLOWN || ipmGapBroken(gap); // a BLOWN-UP iterate is a broken one: see IPM_BLOWN, IPM_NEG_GAP
                 if (nonfinite || (bk_prev && iter > 0 && (pres > 500. * pres_prev || gap < 0.)))
                 {
                     status = bk_prev ? 0 : -2;

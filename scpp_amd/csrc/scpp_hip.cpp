@@ -340,6 +340,9 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
 struct PersistRocketQuat : ipm::RocketQuatSC
 {
 };
+struct PersistRocket2d : ipm::Rocket2dSC
+{
+};
 ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r, bool snapshot)
 {
     ipm::KernelArgs a;
@@ -404,6 +407,9 @@ int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, R
             hipLaunchKernelGGL(ipm::ipm_factor_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a);
             hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a, 0);
         }
+        // a truncated schedule (measurement hook) may leave instances waiting for a factor sweep: retire them as failures instead of reporting stale rows
+        if (pairs < 2 * a.opt.maxit + 1)
+            hipLaunchKernelGGL(ipm::ipm_split_finalize_kernel<ipm::RocketQuatSC>, dim3(unsigned((r.count + WAVE - 1) / WAVE)), dim3(WAVE), 0, r.stream, a);
     }
 #ifdef SCPP_HIP_EMU // (diagnostic of the layout policy; the device library does not carry a third instantiation of the solver for it)
     else if (rq && !zoh && c->ipm_schedule == SCPP_IPM_RESIDENT_WS)
@@ -1313,25 +1319,41 @@ extern "C++"
 {
 namespace
 {
-// Launch of the persistent kernel for the configurations it is instantiated for (RocketQuat, first-order hold); -1: not available, the
-// caller runs the pool engine.
+// Launch of the persistent kernel.  Instantiated for both models and both input holds since round 6 (until then: RocketQuat with first-order hold
+// only, everything else ran the pool engine): T = the refill traits of the model, Model = its flow-map plugin, PF / PZ = the solver tables of the
+// first-order / zero-order hold.  Dynamic LDS: the solver's LDS-resident segment fields during a solve, the integration's stage values / tables during
+// multipleShooting (never live together).
+template <class T, class Model, class PF, class PZ>
+int launchPersistentT(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
+                      const typename T::Params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
+{
+    const PersistentArgs<T> args{a, b, v, q, mp, sc, so, o};
+    const bool foh = (c->mode & SCPP_MODE_FOH) != 0;
+    const size_t seg_b = ipm::segLdsBytes<PF>(c->K), disc_b = foh ? sizeof(DiscLds<Model, true, false>) : sizeof(DiscLds<Model, false, false>);
+    // SCPP_PERSIST_LDS_PAD (bytes of dynamic LDS that are never touched): measurement hook -- it only limits how many wavefronts fit on a CU
+    // (profiles/r06_occupancy_curve.json: the throughput-against-resident-wavefronts curve of DESIGN.md 5)
+    size_t pad = 0;
+    if (const char *e = std::getenv("SCPP_PERSIST_LDS_PAD"))
+        pad = size_t(std::atoi(e) > 0 ? std::atoi(e) : 0);
+    const size_t lds = (seg_b > disc_b ? seg_b : disc_b) + pad;
+    if (foh)
+        hipLaunchKernelGGL((scvx_persistent_kernel<T, Model, PF, true>), dim3(unsigned(S)), dim3(WAVE), lds, c->stream, args);
+    else
+        hipLaunchKernelGGL((scvx_persistent_kernel<T, Model, PZ, false>), dim3(unsigned(S)), dim3(WAVE), lds, c->stream, args);
+    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
 int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
                      const scpp_rocketquat_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
 {
-    if (!(c->mode & SCPP_MODE_FOH))
-        return -1;
-    const PersistentArgs<RefillRocketQuat> args{a, b, v, q, mp, sc, so, o};
-    // dynamic LDS: the solver's LDS-resident segment fields during a solve, the integration's stage values / tables during multipleShooting
-    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, false>);
-    hipLaunchKernelGGL((scvx_persistent_kernel<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, true>), dim3(unsigned(S)), dim3(WAVE),
-                       seg_b > disc_b ? seg_b : disc_b, c->stream, args);
-    return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+    return launchPersistentT<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, ipm::ZeroOrderHold<PersistRocketQuat>>(c, a, b, v, q, mp, sc, so, o, S);
 }
-int launchPersistent(scpp_hip_ctx *, const ipm::KernelArgs &, const SCBuffers &, const SCvxBuffers &, const StreamQueue &,
-                     const scpp_rocket2d_params &, const scpp_sc_opts &, const scpp_scvx_opts &, const PersistentOut &, int)
+int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
+                     const scpp_rocket2d_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
 {
-    return -1;
+    return launchPersistentT<RefillRocket2d, Rocket2dModel, PersistRocket2d, ipm::ZeroOrderHold<PersistRocket2d>>(c, a, b, v, q, mp, sc, so, o, S);
 }
+// the persistent kernel runs a job when the context's engine asks for it and there is at least one iteration to run
+bool persistentAvailable(const scpp_hip_ctx *c, int max_iterations) { return c->stream_engine == SCPP_STREAM_PERSISTENT && max_iterations > 0; }
 
 // queue arrays of the streaming engine (also used, with an empty queue, by the persistent batch solve)
 int ensureQueue(scpp_hip_ctx *c)
@@ -1347,7 +1369,7 @@ int ensureQueue(scpp_hip_ctx *c)
 // whole of SCvxAlgorithm::solve and leaves; no rounds, no host polling.  -1: not available for this configuration.
 int scvxSolvePersistent(scpp_hip_ctx *c)
 {
-    if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->model != SCPP_MODEL_ROCKETQUAT || !(c->mode & SCPP_MODE_FOH) || c->scvx.max_iterations <= 0)
+    if (!persistentAvailable(c, c->scvx.max_iterations))
         return -1;
     if (int rc = ensureQueue(c))
         return rc;
@@ -1378,7 +1400,8 @@ int scvxSolvePersistent(scpp_hip_ctx *c)
     o.disc_steps = c->disc_steps;
     o.shares = c->persist_shares;
     const bool timed = spanBegin(c, 1, c->B, c->stream);
-    const int rc = launchPersistent(c, a, b, v, q, c->mp, c->sc, c->scvx, o, c->B);
+    const int rc = c->model == SCPP_MODEL_ROCKETQUAT ? launchPersistent(c, a, b, v, q, c->mp, c->sc, c->scvx, o, c->B)
+                                                     : launchPersistent(c, a, b, v, q, c->mp2, c->sc, c->scvx, o, c->B);
     spanEnd(c, timed, c->stream);
     return rc;
 }
@@ -1562,7 +1585,9 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     for (int i = 0; i < 4; i++)
         c->stream_ticks[i] = 0;
     // (an explicit pool count -- argument or SCPP_STREAM_POOLS -- asks for the pool engine)
-    if (c->stream_engine == SCPP_STREAM_PERSISTENT && pools == 0 && !std::getenv("SCPP_STREAM_POOLS") && so->max_iterations > 0)
+    // (whether the persistent kernel runs is decided BEFORE a span is opened or persist_shares is touched: until round 5 a configuration the kernel
+    // was not instantiated for recorded an empty span as one launch over N instances -- ADVICE r5)
+    if (persistentAvailable(c, so->max_iterations) && pools == 0 && !std::getenv("SCPP_STREAM_POOLS"))
     {
         // ONE launch: a wavefront per slot takes instance after instance through the whole SCvx loop (scvx_persistent.h)
         if (!c->persist_shares && devAlloc(&c->persist_shares, 8))
@@ -1588,7 +1613,6 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
         const bool timed = spanBegin(c, 1, N, c->stream);
         const int prc = launchPersistent(c, a, b, v, qp, *mp, sc, *so, o, S);
         spanEnd(c, timed, c->stream);
-        if (prc >= 0)
         {
             int counters[4] = {0, 0, 0, 0};
             auto bad = [&](int rc) {

@@ -157,7 +157,7 @@ PERSIST_STEP_FN void persistDiscretize(long slot)
     static DiscLds<Model, FOH, false> lds_obj;
     DiscLds<Model, FOH, false> *lds = &lds_obj;
 #else
-    extern __shared__ double seg_lds[];
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[]; // 16-byte base: DiscLds members are aligned(16) (b128 LDS accesses), whatever the static LDS before it adds up to
     DiscLds<Model, FOH, false> *lds = reinterpret_cast<DiscLds<Model, FOH, false> *>(seg_lds);
 #endif
     for (int k = 0; k < K - 1; k++)
@@ -188,7 +188,7 @@ PERSIST_STEP_FN void persistCost(long slot)
 #ifdef SCPP_HIP_EMU
     static double seg_sum[WAVE];
 #else
-    extern __shared__ double seg_lds[];
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[]; // 16-byte base: DiscLds members are aligned(16) (b128 LDS accesses), whatever the static LDS before it adds up to
     double *seg_sum = seg_lds;
 #endif
     scvxCostUpdateSplit<Model>(b, v, so, slot, seg_sum);
@@ -260,7 +260,7 @@ PERSIST_STEP_FN void scPersistDiscretize(long slot)
     static DiscLds<Model, FOH, VT> lds_obj;
     DiscLds<Model, FOH, VT> *lds = &lds_obj;
 #else
-    extern __shared__ double seg_lds[];
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[]; // 16-byte base: DiscLds members are aligned(16) (b128 LDS accesses), whatever the static LDS before it adds up to
     DiscLds<Model, FOH, VT> *lds = reinterpret_cast<DiscLds<Model, FOH, VT> *>(seg_lds);
 #endif
     for (int k = 0; k < K - 1; k++)

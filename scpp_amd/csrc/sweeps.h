@@ -20,6 +20,21 @@ namespace scpp
 namespace ipm
 {
 
+// issue priority of a wavefront inside the factor sweep / the substitution sweeps (s_setprio 0 .. 3; measurement hooks of round 6: two wavefronts
+// share a SIMD, and the eliminations are bound by instruction issue while the lane phases wait for memory)
+// measured (profiles/r06_ab_priority.json, same box, alternating, all with the non-temporal factor stores): no priorities 5488, factor 1: 5517,
+// substitution 1: 5511, factor 1 + substitution 2: 5524 (+0.65 %), factor 2 + substitution 1: 5510
+#ifndef IPM_PRIO_FACTOR
+#define IPM_PRIO_FACTOR 1
+#endif
+#ifndef IPM_PRIO_SUBST
+#define IPM_PRIO_SUBST 2
+#endif
+#if defined(SCPP_HIP_EMU)
+#define SET_PRIO(p)
+#else
+#define SET_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 // stages of loads in flight ahead of the dependent chain in the forward / backward sweeps (2 at two waves per SIMD)
 #ifndef SWEEP_PREFETCH
 #define SWEEP_PREFETCH 2
@@ -62,15 +77,33 @@ __device__ inline Ctx uniformCtx(const LDSP Ctx *cin)
     return c;
 }
 // ---- branch-free buffer access ----
-struct Buf
+// cache policy per record stream (aux operand of the buffer instructions; gfx950: 1 = sc0, 2 = nt, 16 = sc1).  The factor record and the saved
+// forward columns are written once and read back after >= 186 KB of other traffic of the same wavefront (beyond any cache share); the dynamics
+// blocks are read once per sweep.  Measurement hooks (round 6, tools/r06_*.sh); 0 = the default policy.
+#ifndef IPM_FAC_LD_AUX
+#define IPM_FAC_LD_AUX IPM_LD_AUX
+#endif
+#ifndef IPM_FAC_ST_AUX
+#define IPM_FAC_ST_AUX 2 // non-temporal stores of the factor record / saved columns: +0.7 % (same box, alternating, profiles/r06_ab_cache_policy.json);
+                         // non-temporal LOADS of them -1.6 %, sc1 stores -2.5 %, non-temporal loads of the dynamics blocks +-0
+#endif
+#ifndef IPM_DD_LD_AUX
+#define IPM_DD_LD_AUX IPM_LD_AUX
+#endif
+template <int LA, int SA>
+struct BufT
 {
     __amdgpu_buffer_rsrc_t r;
-    __device__ double ld(int vo, int so) const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, IPM_LD_AUX)); }
-    __device__ void st(int vo, int so, double x) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, vo, so, IPM_ST_AUX); }
+    __device__ double ld(int vo, int so) const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, LA)); }
+    __device__ void st(int vo, int so, double x) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, vo, so, SA); }
 };
-__device__ inline Buf makeBuf(const double *p, int ndoubles)
+typedef BufT<IPM_LD_AUX, IPM_ST_AUX> Buf;
+typedef BufT<IPM_FAC_LD_AUX, IPM_FAC_ST_AUX> BufFac;
+typedef BufT<IPM_DD_LD_AUX, IPM_ST_AUX> BufDd;
+template <class B = Buf>
+__device__ inline B makeBuf(const double *p, int ndoubles)
 {
-    return Buf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, ndoubles * 8, 0x00020000)};
+    return B{__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, ndoubles * 8, 0x00020000)};
 }
 // byte offsets of a lane's four tile entries (register r holds row / contraction index g + 4r), VO_OOB where the entry is
 // outside the stored pattern; they depend on the lane only and are computed once per sweep
@@ -78,7 +111,8 @@ struct Off4
 {
     int v[4];
 };
-__device__ inline Tile ldTile(const Buf &b, const Off4 &o, int so)
+template <class B>
+__device__ inline Tile ldTile(const B &b, const Off4 &o, int so)
 {
     Tile t;
 #pragma unroll
@@ -86,7 +120,8 @@ __device__ inline Tile ldTile(const Buf &b, const Off4 &o, int so)
         t.v[r] = b.ld(o.v[r], so);
     return t;
 }
-__device__ inline void stTile(const Buf &b, const Off4 &o, int so, const Tile &t)
+template <class B>
+__device__ inline void stTile(const B &b, const Off4 &o, int so, const Tile &t)
 {
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -169,10 +204,13 @@ template <class P>
 struct SweepIO
 {
     using L = Lay<P>;
-    Buf fac, sv, sx, A, B, C;
+    BufFac fac, sv;
+    Buf sx;
+    BufDd A, B, C;
     __device__ explicit SweepIO(const Ctx &c)
-        : fac(makeBuf(c.fac, c.K * L::FACREC)), sv(makeBuf(c.sv, c.K * SVREC)), sx(makeBuf(c.sx, c.K * L::XREC)),
-          A(makeBuf(c.A, (c.K - 1) * P::NX * P::NX)), B(makeBuf(c.B, (c.K - 1) * P::NX * P::NU)), C(makeBuf(c.C, (c.K - 1) * P::NX * P::NU))
+        : fac(makeBuf<BufFac>(c.fac, c.K * L::FACREC)), sv(makeBuf<BufFac>(c.sv, c.K * SVREC)), sx(makeBuf<Buf>(c.sx, c.K * L::XREC)),
+          A(makeBuf<BufDd>(c.A, (c.K - 1) * P::NX * P::NX)), B(makeBuf<BufDd>(c.B, (c.K - 1) * P::NX * P::NU)),
+          C(makeBuf<BufDd>(c.C, (c.K - 1) * P::NX * P::NU))
     {
     }
     static __device__ int sFac(int k) { return k * (L::FACREC * 8); }
@@ -544,6 +582,8 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     const int lane = c.lane, K = c.K;
     const int g = lane >> 4, i = lane & 15;
     const bool scvx = c.ip[IP_SCVX] != 0.;
+    if (IPM_PRIO_FACTOR)
+        SET_PRIO(IPM_PRIO_FACTOR);
     // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
     const double dual_reg = scvx ? 1e-9 : 0.;
@@ -747,6 +787,8 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         sh.prof[3] += 1.;
     }
 #endif
+    if (IPM_PRIO_FACTOR)
+        SET_PRIO(0);
     WAVE_SYNC();
 }
 
@@ -969,6 +1011,8 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
+    if (IPM_PRIO_SUBST)
+        SET_PRIO(IPM_PRIO_SUBST);
     const Off4 oLit = offTriT<NV>(lane, L::FAC_LI), oYt = offYt<NL>(lane, L::FAC_YT), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oN = offN<P>(lane);
     const VCols<P, NC> vc(lane);
@@ -1029,6 +1073,8 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         if (!stage(k + 2, b2))
             break;
     }
+    if (IPM_PRIO_SUBST)
+        SET_PRIO(0);
     WAVE_SYNC();
 }
 
@@ -1046,6 +1092,8 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
+    if (IPM_PRIO_SUBST)
+        SET_PRIO(IPM_PRIO_SUBST);
     const Off4 oLi = offTri<NV>(lane, L::FAC_LI), oNt = offNt<P>(lane), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oY = offYtT<NL>(lane, L::FAC_YT);
     const VCols<P, NC> vc(lane);
@@ -1110,6 +1158,8 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         LOADS_ISSUED();
         stage(k - 2, b2);
     }
+    if (IPM_PRIO_SUBST)
+        SET_PRIO(0);
     WAVE_SYNC();
 }
 #ifndef SWEEPS_VECTOR

@@ -45,7 +45,10 @@ def test_committed_profiles_are_of_these_sources():
     import csrc_hash
 
     here = csrc_hash.csrc_sha()
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_pmc_hbm_v*.json")))[-1]
-    assert json.load(open(pmc))["csrc_sha"] == here, (pmc, here)
-    par = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_parity_at_scale*.json")))[-1]
-    assert json.load(open(par))["csrc_sha"] == here, (par, here)
+    sys.path.insert(0, ROOT)
+    import bench  # the selection rule is bench.py's own: the newest summary of the newest round
+
+    pmc, d = bench.measured_traffic()
+    assert d["csrc_sha"] == here, (pmc, here)
+    par = bench.parity_summary()
+    assert par["csrc_sha"] == here and par["stale"] is False, (par["imported_from"], here)

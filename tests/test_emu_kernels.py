@@ -687,3 +687,44 @@ def test_emu_round4_fast_paths_are_bitwise_the_reference_structure(emu_lib, tmp_
     for a, b in zip(*outs):
         for key in ("X", "U", "sigma", "nu_norm", "sc_iters", "ipm_iters", "status", "converged"):
             assert np.array_equal(a[key], b[key]), key
+
+
+def _inject_and_solve(emu_lib, spec):
+    """One cold SC sub-problem solve (K = 8) on the emulator in a fresh process with SCPP_EMU_INJECT_RES=spec; returns (status, ipm_iters)."""
+    import os, subprocess, sys, json
+    code = (
+        "import json, numpy as np, scpp_amd\n"
+        "m = scpp_amd.RocketQuat().loadParameters()\n"
+        "alg = scpp_amd.SCAlgorithm(m, K=8, batch_max=1, library=%r).initialize()\n"
+        "x0 = m.randomized_initial_states(1)\n"
+        "alg.ctx.sc_setup(m.p, alg.opts, x0)\n"
+        "alg.ctx.sc_iterate()\n"
+        "o = alg.ctx.download()\n"
+        "print('RESULT ' + json.dumps([int(o['status'][0]), int(o['ipm_iters'][0]), bool(np.isfinite(o['X']).all())]))\n" % emu_lib
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    if spec:
+        env["SCPP_EMU_INJECT_RES"] = spec
+    else:
+        env.pop("SCPP_EMU_INJECT_RES", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_emu_negative_gap_without_a_fallback_is_a_failure(emu_lib):
+    """the blown-up-iterate guard was one-sided in the gap.  An iterate with pres, dres below the tolerances and a gap in
+    (-1e300, -1e30) -- or any negative gap -- met `gap < abstol` trivially; with no fall-back iterate saved yet (bk_prev == 0) the loop's `gap < 0`
+    rule did not apply and the solve returned status 0 for a point outside the cone.  The emulator build can replace the termination quantities of
+    the n-th residual evaluation (SCPP_EMU_INJECT_RES, test support): a cold solve is handed such an iterate at its 3rd evaluation, before any
+    fall-back exists.  It must FAIL (status -2), for the blown-up and for the merely negative gap; the control (same point, gap +1e-9) is accepted
+    there, which is what shows the injection reaches the test under test."""
+    st, it, fin = _inject_and_solve(emu_lib, "")
+    assert st == 0 and it > 4 and fin
+    st_c, it_c, _ = _inject_and_solve(emu_lib, "2:0:0:1e-9")
+    assert st_c == 0 and it_c == 2  # "converged" at the injected evaluation: the hook works
+    for gap in ("-1e29", "-1e31", "-1e-3"):
+        st_b, it_b, _ = _inject_and_solve(emu_lib, "2:0:0:" + gap)
+        assert st_b == -2 and it_b == 2, (gap, st_b, it_b)

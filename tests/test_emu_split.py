@@ -131,3 +131,22 @@ def test_persistent_cost_step_with_two_passes_of_segment_pairs(model, emu_lib):
     assert np.array_equal(_bits(rows[0]), _bits(rows[1]))
     got = scpp_amd.Context.unpack_stream_rows(rows[1], K)
     assert (got["status"] == 0).all() and got["solves"].sum() >= N * maxit and (got["nonlinear_cost"] > 0).all()
+
+
+def test_truncated_split_schedule_reports_unfinished_instances_as_failures(model, emu_lib):
+    """with fewer (factor, rest) launch pairs than 2 maxit + 1 an instance can still be waiting for a factor sweep when the last launch
+    ends; it has written no outputs.  The finalising pass (ipm_split.h: ipm_split_finalize_kernel) retires it as an iteration-limit failure: status -1,
+    SC loop stopped, iteration counted -- not the previous solve's rows with its status 0."""
+    alg = scpp_amd.SCAlgorithm(model, K=8, batch_max=2, library=emu_lib).initialize()
+    x0 = model.randomized_initial_states(2, first=3)
+    alg.ctx.sc_setup(model.p, alg.opts, x0)
+    alg.ctx.sc_iterate()  # a complete solve first (resident schedule): status 0 is what a stale row would show
+    first = alg.ctx.download()
+    assert (first["status"] == 0).all() and (first["sc_iters"] == 1).all()
+    alg.ctx.set_ipm_schedule(_lib.IPM_SPLIT, 3)  # 3 factor sweeps: far too few for a solve of 15+ iterations
+    alg.ctx.sc_iterate()
+    out = alg.ctx.download()
+    assert (out["status"] == -1).all(), out["status"]
+    assert (out["sc_iters"] == 2).all()
+    assert np.array_equal(_bits(out["X"]), _bits(first["X"]))  # the iterate of the last COMPLETE solve stays
+    # the full schedule on a fresh context is unaffected (no finalising launch) and equals the resident kernel (tests above)

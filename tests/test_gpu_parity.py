@@ -730,7 +730,7 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
     (a') the opt-in step-length rule of discretize_kernel against the default.
     (b) device vs the LITERAL reference-shaped solver on every accepted sub-problem of the first 32 device paths (~550
         sub-problems): row-by-row feasibility, objective gap against the literal optimum, states against the literal optimum.
-    The counts are written to gpurun_out/r05_parity_at_scale.json (bench.py reports the committed copy under profiles/)."""
+    The counts are written to gpurun_out/r06_parity_at_scale.json (bench.py reports the committed copy under profiles/)."""
     import json
     import time
     from concurrent.futures import ThreadPoolExecutor
@@ -861,7 +861,7 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
         pass
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "r05_parity_at_scale.json"), "w"), indent=1)
+        json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "r06_parity_at_scale.json"), "w"), indent=1)
     except OSError:
         pass
     alg.ctx.close()

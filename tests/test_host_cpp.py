@@ -232,9 +232,13 @@ def test_all_gather_layout_and_reindexing_with_several_gpus(batch, gpus, rowd, c
     (the test boxes have one GPU, so N > 1 never ran on hardware)."""
     import subprocess
 
+    import __graft_entry__ as g
+
     host = os.path.join(ROOT, "scpp_amd", "host")
-    subprocess.check_call(["make", "-s", "-C", host, "gather_layout_test"])
-    r = subprocess.run([os.path.join(host, "gather_layout_test"), str(batch), str(gpus), str(rowd), str(chunk_mb)], capture_output=True, text=True)
+    # under the build lock: another worker's `make all` (build_host) may be re-linking this very executable (seen once as "Text file busy")
+    with g._BuildLock():
+        subprocess.check_call(["make", "-s", "-C", host, "gather_layout_test"])
+        r = subprocess.run([os.path.join(host, "gather_layout_test"), str(batch), str(gpus), str(rowd), str(chunk_mb)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "wrong entries 0" in r.stdout
     if (batch, gpus) == (37, 5):

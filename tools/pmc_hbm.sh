@@ -1,13 +1,14 @@
 #!/bin/bash
 # HBM traffic, matrix-core and stall counters of the shipped kernels (rocprofv3 PMC; every counter group in its own pass, no
 # tracing flags), with the FETCH_SIZE / WRITE_SIZE calibration of tools/hbm_calib.hip measured in the same session.
-#   usage: bash tools/pmc_hbm.sh [tag] [batch]      -> gpurun_out/pmc_<tag>/summary.json (copy to profiles/rNN_pmc_hbm_v<n>_<tag>.json)
-TAG=${1:-v1}; BATCH=${2:-4096}
+#   usage: bash tools/pmc_hbm.sh [tag] [batch] [steps]   -> gpurun_out/pmc_<tag>/summary.json (copy to profiles/rNN_pmc_hbm_v<n>_<tag>.json)
+#   (round 6: `steps` batches as one job -- 8192 2 is the bench's own shape: 8192 slots, the queue refilled once)
+TAG=${1:-v1}; BATCH=${2:-4096}; STEPS=${3:-1}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 # the calibration kernels (tools/bin/ is not tracked: built here if the checkout is fresh)
 [ -x $ROOT/tools/bin/hbm_calib ] || { mkdir -p $ROOT/tools/bin && hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/bin/hbm_calib $ROOT/tools/hbm_calib.hip; }
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --batch $BATCH --steps 1 --warmup 0 --no-extras --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --batch $BATCH --steps $STEPS --warmup 0 --no-extras --no-cpu-baseline"
 run_pass () { # name, counters..., -- command
   local name=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=($1); shift; done; shift
   timeout -k 5 600 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $OUT/$name -- "$@" > $OUT/$name.log 2>&1
@@ -22,9 +23,9 @@ run_pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --
 run_pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU -- $BENCH
 cd $ROOT
 for p in fetch write mfma tcc sq; do grep '^{' $OUT/$p.log | tail -1 > $OUT/$p.bench.json; done
-python - "$OUT" "$TAG" "$BATCH" <<'PY'
+python - "$OUT" "$TAG" "$BATCH" "$STEPS" <<'PY'
 import csv, glob, json, sys, collections, subprocess, os
-out, tag, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+out, tag, batch, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 def load(name):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
@@ -42,7 +43,7 @@ def bench(name):
         return json.load(open(f"{out}/{name}.bench.json"))
     except Exception:
         return None
-S = {"tag": tag, "batch": batch, "command": f"bench.py --batch {batch} --steps 1 --warmup 0 --no-extras --no-cpu-baseline under rocprofv3 --pmc (one pass per counter group)"}
+S = {"tag": tag, "batch": batch, "steps": steps, "command": f"bench.py --batch {batch} --steps {steps} --warmup 0 --no-extras --no-cpu-baseline under rocprofv3 --pmc (one pass per counter group)"}
 try:
     S["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -99,7 +100,16 @@ if mk in am:
         it = bm["config"]["mean_ipm_iterations_per_trajectory"] * bm["config"]["instances_timed"]
         S["ipm_mfma"]["MOPS_F64_per_instance_iteration"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"] / it
     if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("SQ_BUSY_CU_CYCLES"):
-        S["ipm_mfma"]["mfma_busy_over_cu_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CU_CYCLES"]
+        # SQ_VALU_MFMA_BUSY_CYCLES sums over the SIMDs (4 per CU, each with its own matrix pipe), SQ_BUSY_CU_CYCLES over the CUs: the fraction of
+        # the time a matrix pipe is busy is busy / (4 x CU-busy).  (Until round 5 this file divided by the CU cycles alone and DESIGN quoted the
+        # result, 0.60, as "matrix core busy 60 %": 4 x too high -- VERDICT r5 weak 7.)
+        S["ipm_mfma"]["mfma_pipe_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * d["SQ_BUSY_CU_CYCLES"])
+    if bm and d.get("SQ_INSTS_VALU_MFMA_MOPS_F64") and bm.get("roofline", {}).get("kernel_time_s"):
+        # executed matrix-core flops: the counter is in units of 512 flop; over the kernel time of the SAME (profiled) run
+        tf = d["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / bm["roofline"]["kernel_time_s"] / 1e12
+        S["ipm_mfma"]["executed_mfma_TFLOPs"] = tf
+        S["ipm_mfma"]["executed_mfma_frac_of_fp64_peak"] = tf / 78.6
+        S["ipm_mfma"]["kernel_time_s_of_that_pass"] = bm["roofline"]["kernel_time_s"]
 for name in ("tcc", "sq"):
     a, _ = load(name)
     S[name] = {k: dict(v) for k, v in a.items() if k in ("scvx_persistent_kernel", "ipm_kernel", "discretize_kernel", "scvx_cost_update_kernel")}
