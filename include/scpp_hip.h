@@ -157,7 +157,7 @@ extern "C"
     /* Build-defined constants of THIS library, so that a binding never hard-codes them (ABI revision 5, round 5: the per-instance status
        SCPP_STATUS_REJECTION_CAP moved from -4 to -5 in revision 4 without a way to ask).  Returns SCPP_E_ARG for an unknown `what` or a NULL
        `value`.  Bindings compare SCPP_Q_ABI_REVISION with the header they were written against and refuse a different library. */
-#define SCPP_ABI_REVISION 5
+#define SCPP_ABI_REVISION 6
 #define SCPP_Q_ABI_REVISION 0          /* SCPP_ABI_REVISION of the build */
 #define SCPP_Q_STATUS_REJECTION_CAP 1  /* the per-instance status of an SCvx run retired in the reject loop */
 #define SCPP_Q_SCVX_SOLVE_CAP 2        /* sub-problem solves per configured SCvx iteration before that happens (csrc/scvx_kernels.h) */
@@ -231,6 +231,20 @@ extern "C"
     int scpp_hip_scvx_solve(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_scvx_download_state(scpp_hip_ctx *ctx, double *trust_region, double *nonlinear_cost, int32_t *solves,
                                      double *last_decision /* [B][4] */);
+    /* SCvxAlgorithm::getAllSolutions (scpp_core/include/SCvxAlgorithm.hpp:48, src/SCvxAlgorithm.cpp:245-260; all_td is filled by solve():
+       :192 before the first iteration, :201 after every iteration, i.e. after every ACCEPTED candidate -- rejected candidates never appear).
+       Opt-in (ABI revision 6, round 6): scpp_hip_scvx_record_iterates(ctx, 1) before scpp_hip_scvx_setup makes that set-up allocate a record of
+       max_iterations + 1 trajectories per instance (K x (nx + nu) doubles each: 223 KB per RocketQuat instance at K = 50 / 30 iterations) and
+       store the initial trajectory; scpp_hip_scvx_solve then appends the trajectory at the end of every iteration on the device (both engines,
+       csrc/scvx_kernels.h: scvxRecordIterate).  The record restarts with every set-up.  Streaming jobs do not record (a slot is re-used).
+       scpp_hip_scvx_download_iterates copies the record of instances [first, first + count) redimensionalised like getAllSolutions does:
+       X [count][capacity][K][nx], U [count][capacity][K][nu], scalars [count][capacity][4] = {trust radius after the iteration's update,
+       sub-problem solves so far (accepted + rejected candidates), nonlinear cost J, decision code: 2 first pass / 1 accepted / 3 converged, 0 for the
+       initial trajectory} (entries beyond an instance's count are left untouched), n_iterates [count] = trajectories recorded (1 + iterations
+       done); any pointer may be NULL.  The last recorded trajectory is bitwise scpp_hip_download's. */
+    int scpp_hip_scvx_record_iterates(scpp_hip_ctx *ctx, int enable);
+    int scpp_hip_scvx_download_iterates(scpp_hip_ctx *ctx, int first, int count, int capacity, double *X, double *U, double *scalars,
+                                        int32_t *n_iterates);
     /* ---- SCvx streaming engine (continuous batching): SCvxAlgorithm::solve (cold start, SCvxAlgorithm.cpp:166-227) of N
        independent instances pushed through `slots` (<= batch_max; 0: batch_max) resident problem slots.  Instances need very
        different numbers of sub-problem solves (accepted + rejected candidates, SCvxAlgorithm.cpp:132-138); a slot whose

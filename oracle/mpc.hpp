@@ -597,7 +597,8 @@ class MpcCondensedIpm
                     v_out[j] = q.D[j] * x[j];
                 return info;
             };
-            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) ||
+            // (round 6: a blown-up or out-of-cone iterate is broken with or without a fall-back -- csrc/mpc_kernel.h, csrc/ipm_solve.h IPM_BLOWN / IPM_NEG_GAP)
+            if (!std::isfinite(pres) || !std::isfinite(dres) || !std::isfinite(gap) || std::fabs(gap) > 1e30 || std::fabs(pcost) > 1e30 || gap < -1e-6 ||
                 (bk_valid && (pres > 500. * pres_prev || gap < 0.)))
             {
                 if (!bk_valid)

@@ -12,7 +12,7 @@ STREAM_POOLS, STREAM_PERSISTENT = 0, 1
 E_ARG, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4
 # What this binding was written against.  load_library() asks the library for ITS values (scpp_hip_query) and refuses one that disagrees: the
 # status moved from -4 to -5 between two builds once, and a constant that is only written down on both sides is how that goes unnoticed.
-ABI_REVISION = 5
+ABI_REVISION = 6
 STATUS_REJECTION_CAP = -5
 SCVX_SOLVE_CAP = 64  # csrc/scvx_kernels.h: sub-problem solves per configured iteration before an instance is retired
 Q_ABI_REVISION, Q_STATUS_REJECTION_CAP, Q_SCVX_SOLVE_CAP, Q_MAX_K, Q_MPC_MAX_K = 0, 1, 2, 3, 4
@@ -133,6 +133,7 @@ SYMBOLS = [
     "scpp_hip_mpc_sim_download",
     "scpp_hip_scvx_solve_stream", "scpp_hip_stream_rows", "scpp_hip_stream_download", "scpp_hip_stream_info",
     "scpp_hip_scvx_setup_rocket2d", "scpp_hip_scvx_solve_stream_rocket2d",
+    "scpp_hip_scvx_record_iterates", "scpp_hip_scvx_download_iterates",
 ]
 
 
@@ -302,6 +303,20 @@ class Context:
         tr, cost, solves, dec = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
         _chk(self.lib.scpp_hip_scvx_download_state(self.h, _p(tr), _p(cost), _p(solves), _p(dec)), "scvx_download_state")
         return dict(trust_region=tr, nonlinear_cost=cost, solves=solves, last_decision=dec)
+
+    def scvx_record_iterates(self, enable=True):
+        """opt in to SCvxAlgorithm::getAllSolutions (SCvxAlgorithm.cpp:245-260): call before scvx_setup"""
+        _chk(self.lib.scpp_hip_scvx_record_iterates(self.h, int(bool(enable))), "scvx_record_iterates")
+
+    def scvx_iterates(self, capacity, first=0, count=None):
+        """(X [count][capacity][K][nx], U [count][capacity][K][nu], n [count], scalars [count][capacity][4] = radius, solves, J, decision code) of the
+        recorded trajectories (dimensional): the initial trajectory and the trajectory after every iteration of the last scvx_solve; rows beyond
+        n[b] are zero."""
+        count = self.B - first if count is None else int(count)
+        X = np.zeros((count, capacity, self.K, self.nx)); U = np.zeros((count, capacity, self.K, self.nu)); n = np.zeros(count, dtype=np.int32)
+        sc = np.zeros((count, capacity, 4))
+        _chk(self.lib.scpp_hip_scvx_download_iterates(self.h, int(first), count, int(capacity), _p(X), _p(U), _p(sc), _p(n)), "scvx_download_iterates")
+        return X, U, n, sc
 
     # ---- SCvx streaming engine (continuous batching) ----
     STREAM_SCALARS = ("sigma", "nu_norm", "nonlinear_cost", "trust_region", "sc_iters", "solves", "converged", "status",

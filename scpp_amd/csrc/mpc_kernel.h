@@ -387,11 +387,37 @@ __global__ void __launch_bounds__(64, MPC_WAVES_PER_SIMD) mpc_solve_kernel(const
             nxx = sh.red[5];
             pcost = sh.red[6];
         }
+        double pres = sqrt(nrz) / fmax(resz0 + sqrt(nxx) + sqrt(nss), 1.);
+        double dres = sqrt(nrx) / fmax(resx0 + sqrt(nzz), 1.);
+#ifdef SCPP_HIP_EMU
+        // Test support (emulator build only): SCPP_EMU_INJECT_MPC_RES="n:pres:dres:gap" replaces the termination quantities of the n-th evaluation of the
+        // process (per lane) -- the broken iterate the magnitude / negative-gap rule below exists for
+        {
+            static int calls[WAVE];
+            static int inj_n = -2;
+            static double inj_v[3];
+            if (inj_n == -2)
+            {
+                const char *e = getenv("SCPP_EMU_INJECT_MPC_RES");
+                inj_n = -1;
+                if (e && sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
+                    inj_n = -1;
+            }
+            if (inj_n >= 0 && calls[lane & (WAVE - 1)]++ == inj_n)
+            {
+                pres = inj_v[0];
+                dres = inj_v[1];
+                gap = inj_v[2];
+            }
+        }
+#endif
         const double mu = gap / Ddeg;
-        const double pres = sqrt(nrz) / fmax(resz0 + sqrt(nxx) + sqrt(nss), 1.);
-        const double dres = sqrt(nrx) / fmax(resx0 + sqrt(nzz), 1.);
         const double relgap = gap / fmax(fabs(pcost), 1e-300);
-        const bool finite = (pres - pres == 0.) && (dres - dres == 0.) && (gap - gap == 0.);
+        // Broken iterate (round 6, the rule the big solver got in round 5 -- csrc/ipm_solve.h: IPM_BLOWN, IPM_NEG_GAP): every residual is RELATIVE to the
+        // iterate's norm, so a blown-up point shows pres = 0, and any negative gap meets `gap < abstol`; until now that was caught only once a
+        // fall-back iterate existed.  The problem is scaled to unit magnitudes at set-up (mpc_setup.h): 1e30 is never a value of a working iterate,
+        // and a gap below -1e-6 means the point has left the cone.
+        const bool finite = (pres - pres == 0.) && (dres - dres == 0.) && (gap - gap == 0.) && fabs(gap) <= 1e30 && fabs(pcost) <= 1e30 && !(gap < -1e-6);
         if (!finite || (bk_valid && (pres > 500. * pres_prev || gap < 0.)))
         {
             if (!bk_valid)

@@ -52,6 +52,11 @@ struct scpp_hip_ctx
     // SCvx state (allocated on first scvx_setup)
     double *vx_Xold = nullptr, *vx_Uold = nullptr, *vx_tr = nullptr, *vx_last = nullptr, *vx_cost = nullptr, *vx_info = nullptr;
     int *vx_has_last = nullptr, *vx_needs_disc = nullptr, *vx_solves = nullptr;
+    // SCvxAlgorithm::getAllSolutions: opt-in record of every iterate of the batch entry point (scpp_hip_scvx_record_iterates)
+    bool vx_record = false;
+    double *vx_iter_ring = nullptr;
+    int *vx_iter_count = nullptr;
+    int vx_iter_cap = 0;
     scpp_scvx_opts scvx{};
     bool scvx_ready = false;
     // streaming engine (allocated on first scvx_solve_stream): instance queue, result rows, slot -> instance map
@@ -685,7 +690,8 @@ int scpp_hip_destroy(scpp_hip_ctx *c)
                     c->mpc_iters, c->mpc_steps, c->mpc_failed, c->mpc_ipm, c->mpc_reached};
     delete c->mpc_host;
     c->mpc_host = nullptr;
-    for (void *p : {(void *)c->q_xinit, (void *)c->q_rows, (void *)c->q_counters, (void *)c->q_slot_inst, (void *)c->persist_shares})
+    for (void *p : {(void *)c->q_xinit, (void *)c->q_rows, (void *)c->q_counters, (void *)c->q_slot_inst, (void *)c->persist_shares, (void *)c->vx_iter_ring,
+                    (void *)c->vx_iter_count})
         if (p)
             (void)hipFree(p);
     if (c->h_poll)
@@ -1023,7 +1029,8 @@ int scSolvePersistent(scpp_hip_ctx *c)
     // ~3000 instances the chip is not full and the serial integration shows (cold solve of 256 / 1024 / 2048 instances: -29 % / -8 % / +-0, 4096 / 8192:
     // +4.6 % / +4.0 %), and in a warm-started solve (SC_sim: 7 interior-point iterations per sub-problem instead of 22) the integration is half of the
     // work (4096 instances: -3 %, 1024: -12 %).
-    if (c->sc_warm || c->B < c->sc_persistent_min)
+    static const bool warm_too = std::getenv("SCPP_SC_PERSISTENT_WARM") != nullptr; // measurement hook (round 6)
+    if ((c->sc_warm && !warm_too) || c->B < c->sc_persistent_min)
         return -1;
     const Range r = fullRange(c);
     ScPersistentArgs args;
@@ -1049,6 +1056,10 @@ int scSolvePersistent(scpp_hip_ctx *c)
 } // namespace
 } // extern "C++"
 
+namespace
+{
+int ensurePools(scpp_hip_ctx *c, int pools);
+}
 int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
 {
     DeviceGuard guard(c);
@@ -1068,7 +1079,8 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
         }
     }
     const int B = c->B;
-    if (B < 1024 || c->last_active != B)
+    static const bool single_stream = std::getenv("SCPP_SC_SINGLE_STREAM") != nullptr; // measurement hook (round 6)
+    if (B < 1024 || c->last_active != B || single_stream)
     {
         // small or partially masked batches: one stream, stop as soon as every instance has terminated
         int n_active = c->last_active;
@@ -1097,6 +1109,46 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
         CHECK_HIP(hipStreamCreate(&c->stream2));
         CHECK_HIP(hipEventCreate(&c->ev_skew));
         CHECK_HIP(hipEventCreate(&c->ev_join));
+    }
+    // measurement hook (round 6): SCPP_SC_CHUNKS = n > 2 runs n chunks on n streams, each looping discretize -> solve on its own, started one
+    // discretisation apart
+    static const int n_chunks = std::getenv("SCPP_SC_CHUNKS") ? std::atoi(std::getenv("SCPP_SC_CHUNKS")) : 2;
+    if (n_chunks > 2 && n_chunks <= 8)
+    {
+        if (int rc = ensurePools(c, n_chunks))
+            return rc;
+        std::vector<Range> ch;
+        const int per = ((B + n_chunks - 1) / n_chunks + 7) & ~7;
+        for (int i = 0, f = 0; i < n_chunks && f < B; i++, f += per)
+            ch.push_back(Range{f, (f + per <= B ? per : B - f), i == 0 ? c->stream : c->pool_streams[size_t(i - 1)]});
+        CHECK_HIP(hipEventRecord(c->pool_events[0], c->stream));
+        for (size_t i = 1; i < ch.size(); i++)
+            CHECK_HIP(hipStreamWaitEvent(ch[i].stream, c->pool_events[0], 0));
+        for (int it = 0; it < c->sc.max_iterations; it++)
+            for (size_t i = 0; i < ch.size(); i++)
+            {
+                int rc = discretizeDispatch(c, c->mode, c->ip + ipm::IP_PAR, ipm::IP_N, c->active, ch[i].count, ch[i]);
+                if (rc)
+                    return rc;
+                if (it == 0 && i + 1 < ch.size())
+                {
+                    CHECK_HIP(hipEventRecord(c->pool_events[i + 1 < c->pool_events.size() ? i + 1 : 0], ch[i].stream));
+                    CHECK_HIP(hipStreamWaitEvent(ch[i + 1].stream, c->pool_events[i + 1 < c->pool_events.size() ? i + 1 : 0], 0));
+                }
+                rc = launchIpm(c, 1, ch[i].count, false, ch[i], 0);
+                if (rc)
+                    return rc;
+            }
+        for (size_t i = 1; i < ch.size(); i++)
+        {
+            CHECK_HIP(hipEventRecord(c->pool_events[i], ch[i].stream));
+            CHECK_HIP(hipStreamWaitEvent(c->stream, c->pool_events[i], 0));
+        }
+        int n = 0;
+        if (int rc = countActive(c, &n))
+            return rc;
+        c->last_active = n;
+        return scpp_hip_sc_finish(c, n_converged);
     }
     const int h0 = (B / 2 + 7) & ~7; // keep the XCD groups of 8 instances intact
     const Range r0{0, h0, c->stream}, r1{h0, B - h0, c->stream2};
@@ -1151,6 +1203,9 @@ SCvxBuffers scvxBuffers(scpp_hip_ctx *c)
     v.has_last = c->vx_has_last;
     v.needs_disc = c->vx_needs_disc;
     v.solves = c->vx_solves;
+    v.iter_ring = c->vx_record ? c->vx_iter_ring : nullptr;
+    v.iter_count = c->vx_iter_count;
+    v.iter_cap = c->vx_iter_cap;
     return v;
 }
 } // namespace
@@ -1184,6 +1239,18 @@ int scvxSetupCommon(scpp_hip_ctx *c, const scpp_scvx_opts *so, const double *x_i
         if (rc)
             return SCPP_E_HIP;
     }
+    if (c->vx_record && (!c->vx_iter_ring || c->vx_iter_cap < so->max_iterations + 1))
+    {
+        if (c->vx_iter_ring)
+            (void)hipFree(c->vx_iter_ring);
+        c->vx_iter_ring = nullptr;
+        c->vx_iter_cap = so->max_iterations + 1;
+        int rc = devAlloc(&c->vx_iter_ring, size_t(c->Bmax) * size_t(c->vx_iter_cap) * scvxIterRecordDoubles(c->K, c->nx, c->nu));
+        if (!c->vx_iter_count)
+            rc |= devAlloc(&c->vx_iter_count, size_t(c->Bmax));
+        if (rc)
+            return SCPP_E_HIP;
+    }
     c->B = B;
     c->scvx = *so;
     // the trajectory / parameter set-up is the SC one (same model code); SCvx specifics are applied on top
@@ -1213,6 +1280,8 @@ int scvxSetupDone(scpp_hip_ctx *c, double final_time, int B, int warm_start)
 {
     hipLaunchKernelGGL(scvx_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), scvxBuffers(c), c->scvx, final_time,
                        warm_start);
+    if (c->vx_record) // all_td.push_back(td) before the first iteration (SCvxAlgorithm.cpp:192); the record restarts with every set-up
+        hipLaunchKernelGGL(scvx_record_initial_kernel, dim3(unsigned(B)), dim3(WAVE), 0, c->stream, scBuffers(c), scvxBuffers(c), c->nx, c->nu);
     c->sc_ready = false; // the SC entry points must not be mixed with an SCvx set-up
     c->scvx_ready = true;
     c->par_from_ip = true;
@@ -1266,6 +1335,11 @@ SCvxBuffers scvxBuffersRange(scpp_hip_ctx *c, Range r)
     v.has_last += f;
     v.needs_disc += f;
     v.solves += f;
+    if (v.iter_ring)
+    {
+        v.iter_ring += f * size_t(v.iter_cap) * scvxIterRecordDoubles(c->K, c->nx, c->nu);
+        v.iter_count += f;
+    }
     return v;
 }
 
@@ -1597,7 +1671,8 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
         r.count = S;
         SCBuffers b = scBuffersRange(c, r);
         b.B = S;
-        const SCvxBuffers v = scvxBuffersRange(c, r);
+        SCvxBuffers v = scvxBuffersRange(c, r);
+        v.iter_ring = nullptr; // a slot is re-used for many instances: iterates are recorded by the batch entry point only
         StreamQueue qp = q;
         qp.slot_inst = c->q_slot_inst;
         qp.warm = c->ipm_warm;
@@ -1660,7 +1735,8 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
         {
             const Range r = pool[size_t(p)];
             const SCBuffers b = scBuffersRange(c, r);
-            const SCvxBuffers v = scvxBuffersRange(c, r);
+            SCvxBuffers v = scvxBuffersRange(c, r);
+            v.iter_ring = nullptr;
             StreamQueue qp = q;
             qp.slot_inst = c->q_slot_inst + r.first;
             qp.warm = c->ipm_warm + r.first;
@@ -1790,6 +1866,65 @@ int scpp_hip_scvx_download_state(scpp_hip_ctx *c, double *trust_region, double *
         CHECK_HIP(hipMemcpy(solves, c->vx_solves, B * sizeof(int), hipMemcpyDeviceToHost));
     if (last_decision)
         CHECK_HIP(hipMemcpy(last_decision, c->vx_info, B * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return SCPP_OK;
+}
+
+int scpp_hip_scvx_record_iterates(scpp_hip_ctx *c, int enable)
+{
+    if (!c || (enable != 0 && enable != 1))
+        return SCPP_E_ARG;
+    c->vx_record = enable != 0;
+    c->scvx_ready = false; // takes effect with the next scvx_setup (which allocates the record and stores the initial trajectory)
+    return SCPP_OK;
+}
+
+int scpp_hip_scvx_download_iterates(scpp_hip_ctx *c, int first, int count, int capacity, double *X, double *U, double *scalars, int32_t *n_iterates)
+{
+    DeviceGuard guard(c);
+    if (!c || first < 0 || count < 1 || capacity < 1)
+        return SCPP_E_ARG;
+    if (!c->scvx_ready || !c->vx_record || !c->vx_iter_ring || first + count > c->B)
+        return SCPP_E_STATE;
+    CHECK_HIP(hipStreamSynchronize(c->stream));
+    const size_t K = size_t(c->K), nx = size_t(c->nx), nu = size_t(c->nu), rec = scvxIterRecordDoubles(c->K, c->nx, c->nu), cap = size_t(c->vx_iter_cap);
+    std::vector<int> cnt(static_cast<size_t>(count));
+    CHECK_HIP(hipMemcpy(cnt.data(), c->vx_iter_count + first, size_t(count) * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<double> ip(size_t(count) * ipm::IP_N), buf(cap * rec);
+    CHECK_HIP(hipMemcpy(ip.data(), c->ip + size_t(first) * ipm::IP_N, ip.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
+    for (int b = 0; b < count; b++)
+    {
+        const int n = cnt[size_t(b)] < capacity ? cnt[size_t(b)] : capacity;
+        if (n_iterates)
+            n_iterates[b] = cnt[size_t(b)];
+        if (n < 1 || (!X && !U && !scalars))
+            continue;
+        CHECK_HIP(hipMemcpy(buf.data(), c->vx_iter_ring + (size_t(first + b) * cap) * rec, size_t(n) * rec * sizeof(double), hipMemcpyDeviceToHost));
+        // redimensionalizeTrajectory of every recorded trajectory (SCvxAlgorithm.cpp:247-255; rocketQuat.cpp:188-201, rocket2d.cpp:108-118): the
+        // factors of the result rows (csrc/scvx_kernels.h: RefillRocketQuat / RefillRocket2d); 1 when the run is not nondimensionalised
+        const double ms = ip[size_t(b) * ipm::IP_N + ipm::IP_MSCALE], rs = ip[size_t(b) * ipm::IP_N + ipm::IP_RSCALE];
+        for (int j = 0; j < n; j++)
+        {
+            if (scalars)
+                for (int e = 0; e < SCVX_ITER_SCALARS; e++)
+                    scalars[(size_t(b) * size_t(capacity) + size_t(j)) * SCVX_ITER_SCALARS + size_t(e)] = buf[size_t(j) * rec + K * (nx + nu) + size_t(e)];
+            for (size_t k = 0; k < K; k++)
+            {
+                if (X)
+                    for (size_t e = 0; e < nx; e++)
+                    {
+                        const double f = rq ? (e == 0 ? ms : (e < 7 ? rs : 1.)) : (e < 4 ? rs : 1.);
+                        X[((size_t(b) * size_t(capacity) + size_t(j)) * K + k) * nx + e] = buf[size_t(j) * rec + k * nx + e] * f;
+                    }
+                if (U)
+                    for (size_t e = 0; e < nu; e++)
+                    {
+                        const double f = rq ? (e < 3 ? ms * rs : ms * rs * rs) : (e == 1 ? ms * rs : 1.);
+                        U[((size_t(b) * size_t(capacity) + size_t(j)) * K + k) * nu + e] = buf[size_t(j) * rec + K * nx + k * nu + e] * f;
+                    }
+            }
+        }
+    }
     return SCPP_OK;
 }
 

@@ -25,7 +25,41 @@ struct SCvxBuffers
     double *cost;              // [B] J of the current candidate
     double *info;              // [B][4]: last rho, actual change, predicted change, accepted code
     int *has_last, *needs_disc, *solves;
+    // SCvxAlgorithm::getAllSolutions (SCvxAlgorithm.cpp:192,201,245-260: all_td): opt-in record of the trajectory before the first iteration and
+    // after every iteration (= after every ACCEPTED candidate), nondimensional as the algorithm holds it; null = off (the default: the headline's
+    // bytes do not move).  Batch entry point only -- a streaming job re-uses a slot for many instances.
+    double *iter_ring; // [B][iter_cap][K * (nx + nu) + SCVX_ITER_SCALARS]: X [K][nx], U [K][nu], then {radius, sub-problem solves so far, J, decision code}
+    int *iter_count;   // [B] trajectories recorded
+    int iter_cap;      // max_iterations + 1
 };
+constexpr int SCVX_ITER_SCALARS = 4;
+__host__ __device__ inline size_t scvxIterRecordDoubles(int K, int nx, int nu) { return size_t(K) * size_t(nx + nu) + SCVX_ITER_SCALARS; }
+// the whole wavefront appends the instance's current trajectory to its record (nothing happens when the record is off or full)
+__device__ inline void scvxRecordIterate(const SCBuffers &b, const SCvxBuffers &v, long i, int nx, int nu, int lane, int lanes)
+{
+    if (!v.iter_ring)
+        return;
+    const int n = v.iter_count[i];
+    if (n >= v.iter_cap)
+        return;
+    const int K = b.K;
+    double *dst = v.iter_ring + (size_t(i) * v.iter_cap + n) * scvxIterRecordDoubles(K, nx, nu);
+    for (int e = lane; e < K * nx; e += lanes)
+        dst[e] = b.X[i * K * nx + e];
+    for (int e = lane; e < K * nu; e += lanes)
+        dst[K * nx + e] = b.U[i * K * nu + e];
+    if (lane == 0)
+    {
+        double *sc = dst + K * (nx + nu);
+        sc[0] = v.tr[i];             // radius after this iteration's update
+        sc[1] = double(v.solves[i]); // accepted + rejected candidates so far
+        sc[2] = v.last_cost[i];      // nonlinear cost J of the trajectory
+        sc[3] = v.info[i * 4 + 3];   // 2 first pass, 1 accepted, 3 converged (0 in the initial record)
+    }
+    WAVE_SYNC(); // every lane has read the count
+    if (lane == 0)
+        v.iter_count[i] = n + 1;
+}
 
 // per-instance SCvx start-up AFTER scSetupOne (which nondimensionalises, builds the initial or warm trajectory
 // and thrust_const): fixed final time, SCvx flags of the sub-problem, radius.
@@ -62,9 +96,21 @@ __global__ void scvx_setup_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so,
         return;
     scvxSetupOne(b, v, so, final_time, warm, i);
 }
+// all_td.push_back(td) before the first iteration (SCvxAlgorithm.cpp:192): one wavefront per instance, after the model's set-up kernel
+__global__ void scvx_record_initial_kernel(SCBuffers b, SCvxBuffers v, int nx, int nu)
+{
+    const long i = blockIdx.x;
+    if (i >= b.B || !v.iter_ring)
+        return;
+    if (threadIdx.x == 0)
+        v.iter_count[i] = 0;
+    WAVE_SYNC();
+    scvxRecordIterate(b, v, i, nx, nu, threadIdx.x, WAVE);
+}
 
 // SCvxAlgorithm.cpp:95-152 for one active instance, after the sub-problem solve and the cost evaluation (one lane).
-// Returns 1 if the candidate was rejected (td = old_td: the caller restores X / U from the backup).
+// Returns bit 0: the candidate was rejected (td = old_td: the caller restores X / U from the backup); bit 1: an iteration has ended with td = the
+// candidate (first pass, accepted or converged: what SCvxAlgorithm::solve pushes to all_td, SCvxAlgorithm.cpp:201).
 __device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, long i, double nonlinear_cost)
 {
     using namespace ipm;
@@ -150,7 +196,7 @@ __device__ inline int scvxDecide(const SCBuffers &b, const SCvxBuffers &v, const
             v.needs_disc[i] = 1;
         }
     }
-    return restore;
+    return restore | (done_iteration ? 2 : 0);
 }
 
 // getNonlinearCost + the accept / reject / radius logic: one wavefront per instance.  Lane k propagates segment k with the
@@ -221,20 +267,22 @@ __device__ __forceinline__ void scvxCostUpdate(const SCBuffers &b, const SCvxBuf
             acc += fabs(y[j] - X[NX + j]);
     }
     acc = wave_sum(acc);
-    int restore = 0;
+    int flags = 0;
     if (k == 0)
     {
         v.cost[i] = acc;
-        restore = scvxDecide(b, v, so, i, acc);
+        flags = scvxDecide(b, v, so, i, acc);
     }
-    restore = __shfl(restore, 0);
-    if (restore)
+    flags = __shfl(flags, 0);
+    if (flags & 1)
     {
         for (int e = k; e < K * NX; e += WAVE)
             b.X[i * K * NX + e] = v.Xold[i * K * NX + e];
         for (int e = k; e < K * NU; e += WAVE)
             b.U[i * K * NU + e] = v.Uold[i * K * NU + e];
     }
+    if (flags & 2)
+        scvxRecordIterate(b, v, i, NX, NU, k, WAVE);
 }
 template <class Model>
 __global__ void __launch_bounds__(WAVE, COST_WAVES_PER_SIMD) scvx_cost_update_kernel(SCBuffers b, SCvxBuffers v, scpp_scvx_opts so)
@@ -355,20 +403,22 @@ __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SC
     double acc = (lane < K - 1) ? seg_sum[lane] : 0.; // lane = segment, as in scvxCostUpdate: the same reduction order
     acc = wave_sum(acc);
     WAVE_SYNC();
-    int restore = 0;
+    int flags = 0;
     if (lane == 0)
     {
         v.cost[i] = acc;
-        restore = scvxDecide(b, v, so, i, acc);
+        flags = scvxDecide(b, v, so, i, acc);
     }
-    restore = __shfl(restore, 0);
-    if (restore)
+    flags = __shfl(flags, 0);
+    if (flags & 1)
     {
         for (int e = lane; e < K * NX; e += WAVE)
             b.X[i * K * NX + e] = v.Xold[i * K * NX + e];
         for (int e = lane; e < K * NU; e += WAVE)
             b.U[i * K * NU + e] = v.Uold[i * K * NU + e];
     }
+    if (flags & 2)
+        scvxRecordIterate(b, v, i, NX, NU, lane, WAVE);
 }
 
 // ---------------------------------------------------------------- streaming engine

@@ -301,12 +301,58 @@ public:
     void solve(bool warm_start = false)
     {
         scvx_result_t r;
+        recordIterates(true); // the single-instance front end keeps all_td like the reference (SCvxAlgorithm.cpp:192,201)
         solveBatch({model->p.x_init}, r, warm_start);
         td = r.td[0];
         converged = r.converged[0] != 0;
         iterations = r.sc_iterations[0];
+        std::vector<std::vector<trajectory_data_t>> all;
+        getAllSolutionsBatch(all);
+        all_td = all.at(0);
     }
     void getSolution(trajectory_data_t &trajectory) const { trajectory = td; }
+    // SCvxAlgorithm::getAllSolutions (SCvxAlgorithm.hpp:48, SCvxAlgorithm.cpp:245-260): the initial trajectory and the trajectory after every iteration
+    // (= after every accepted candidate), redimensionalised
+    void getAllSolutions(std::vector<trajectory_data_t> &all_trajectories) { all_trajectories = all_td; }
+    // the batched form: opt in BEFORE solveBatch (the device then records max_iterations + 1 trajectories per instance, include/scpp_hip.h) ...
+    void recordIterates(bool enable)
+    {
+        if (!ctx)
+            throw std::runtime_error("SCvxAlgorithm::initialize() has not been called");
+        if (enable != recording && scpp_hip_scvx_record_iterates(ctx, enable ? 1 : 0) != SCPP_OK)
+            throw std::runtime_error("scpp_hip_scvx_record_iterates failed");
+        recording = enable;
+    }
+    // ... and read the record of the last solveBatch: all[b] = all_td of instance b
+    void getAllSolutionsBatch(std::vector<std::vector<trajectory_data_t>> &all)
+    {
+        if (!recording || last_B < 1)
+            throw std::runtime_error("getAllSolutionsBatch: recordIterates(true) before solveBatch");
+        const size_t K = size_t(opts.K), nB = size_t(last_B), cap = size_t(opts.max_iterations) + 1;
+        constexpr size_t NX = Model::state_dim, NU = Model::input_dim;
+        std::vector<double> X(nB * cap * K * NX), U(nB * cap * K * NU), sigma(nB, 0.);
+        std::vector<int32_t> n(nB, 0);
+        int rc = scpp_hip_scvx_download_iterates(ctx, 0, last_B, int(cap), X.data(), U.data(), nullptr, n.data());
+        if (rc == SCPP_OK)
+            rc = scpp_hip_download(ctx, nullptr, nullptr, sigma.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc != SCPP_OK)
+            throw std::runtime_error("scpp_hip_scvx_download_iterates failed with code " + std::to_string(rc));
+        all.assign(nB, {});
+        for (size_t b = 0; b < nB; b++)
+            for (size_t j = 0; j < size_t(n[b]) && j < cap; j++)
+            {
+                trajectory_data_t t;
+                t.initialize(K, opts.interpolate_input != 0);
+                for (size_t k = 0; k < K; k++)
+                    for (size_t e = 0; e < NX; e++)
+                        t.X[k][e] = X[((b * cap + j) * K + k) * NX + e];
+                for (size_t k = 0; k < t.U.size(); k++)
+                    for (size_t e = 0; e < NU; e++)
+                        t.U[k][e] = U[((b * cap + j) * K + k) * NU + e];
+                t.t = sigma[b];
+                all[b].push_back(t);
+            }
+    }
     bool hasConverged() const { return converged; }
     int getIterations() const { return iterations; }
 
@@ -317,6 +363,7 @@ public:
         if (!warm_start)
             loadParameters(); // cold start re-reads SCvx.info (:179)
         const int B = int(x_inits.size());
+        last_B = B;
         int rc = scvxSetup(*model, &x_inits[0][0], B, warm_start);
         int nconv = 0;
         if (rc == SCPP_OK)
@@ -374,8 +421,9 @@ private:
     int batch_max, device, K_override;
     scpp_hip_ctx *ctx = nullptr;
     trajectory_data_t td;
-    bool converged = false;
-    int iterations = 0;
+    std::vector<trajectory_data_t> all_td;
+    bool converged = false, recording = false;
+    int iterations = 0, last_B = 0;
 };
 
 // commonFunctions.cpp:6-19

@@ -78,6 +78,7 @@ int main(int argc, char **argv)
                 x_inits.push_back(inst.p.x_init);
             }
             scpp::scvx_result_t r;
+            vsolver.recordIterates(true); // getAllSolutions: every iterate of instance 0 is written below, like SC_oneshot.cpp:31-63 does for all_td
             vsolver.solveBatch(x_inits, r);
             long conv = 0, fails = 0, iters = 0, solves = 0;
             for (size_t b = 0; b < x_inits.size(); b++)
@@ -90,14 +91,22 @@ int main(int argc, char **argv)
             const double n = double(x_inits.size());
             std::printf("SCvx batch %zu: converged %ld, solver failures %ld, mean iterations %.2f, mean sub-problem solves %.2f\n",
                         x_inits.size(), conv, fails, double(iters) / n, double(solves) / n);
-            all_td.push_back(r.td[0]);
-            const fs::path outputPath = fs::path(out) / "output" / Model::getModelName() / "SCvx" / scpp::getTimeString() / "0";
-            scpp::makeDir(outputPath);
-            scpp::writeRows(outputPath / "X.txt", all_td[0].X);
-            scpp::writeRows(outputPath / "U.txt", all_td[0].U);
-            std::ofstream f(outputPath / "t.txt");
-            f << all_td[0].t;
-            std::printf("output: %s\n", outputPath.string().c_str());
+            // output/<Model>/SCvx/<time>/<iteration>/{X,U,t}.txt for every trajectory of all_td (SC_oneshot.cpp:31-63: iteration 0 is the initial
+            // trajectory, iteration j the trajectory after the j-th iteration), instance 0 of the batch
+            std::vector<std::vector<trajectory_data_t>> all;
+            vsolver.getAllSolutionsBatch(all);
+            all_td = all.at(0);
+            const fs::path outputPath = fs::path(out) / "output" / Model::getModelName() / "SCvx" / scpp::getTimeString();
+            for (size_t k = 0; k < all_td.size(); k++)
+            {
+                const fs::path iterationPath = outputPath / std::to_string(k);
+                scpp::makeDir(iterationPath);
+                scpp::writeRows(iterationPath / "X.txt", all_td[k].X);
+                scpp::writeRows(iterationPath / "U.txt", all_td[k].U);
+                std::ofstream f(iterationPath / "t.txt");
+                f << all_td[k].t;
+            }
+            std::printf("output: %s (%zu iterates)\n", outputPath.string().c_str(), all_td.size());
             return 0;
         }
         if (batch > 0 && gpus > 1)

@@ -46,10 +46,9 @@ class SCSim:
         steps = np.zeros(B, dtype=np.int32)
         reached = np.zeros(B, dtype=bool)
         failed = np.zeros(B, dtype=bool)
-        X_sim = [[] for _ in range(B)]
-        U_sim = [[] for _ in range(B)]
-        t_plan = [[] for _ in range(B)]
-        sc_iters = [[] for _ in range(B)]
+        # per-step records of the whole batch + the mask of the loops that took the step (round 6: until then every loop's record was appended in a
+        # Python loop per step, 57 ms per step for 4096 loops -- 11 of the 86 s of BASELINE configs[3] at size)
+        rec_ok, rec_x, rec_u, rec_t, rec_it = [], [], [], [], []
         for step in range(self.max_steps):
             if not active.any():
                 break
@@ -63,20 +62,24 @@ class SCSim:
             u1 = interpolated_input(out["U"], self.time_step, out["sigma"], bool(alg.opts.interpolate_input))
             ctx.set_flow_params(par_dim)
             x_new = ctx.simulate(self.time_step, u0, u1, x)
-            for b in np.nonzero(ok)[0]:
-                x[b] = x_new[b]
-                X_sim[b].append(x_new[b].copy())
-                U_sim[b].append(u0[b].copy())
-                t_plan[b].append(float(out["sigma"][b]))
-                sc_iters[b].append(int(out["sc_iters"][b]))
-                steps[b] += 1
+            x = np.where(ok[:, None], x_new, x)
+            rec_ok.append(ok.copy())
+            rec_x.append(x_new)
+            rec_u.append(u0.copy())
+            rec_t.append(out["sigma"].copy())
+            rec_it.append(out["sc_iters"].copy())
+            steps += ok
             end = ok & ((np.linalg.norm(x - x_final, axis=1) < 0.02) | (out["sigma"] < 0.25))
             reached |= end
             active = (ok & ~end).astype(np.int32)
+        n = len(rec_ok)
+        OK = np.array(rec_ok).reshape(n, B)
+        XS, US = np.array(rec_x).reshape(n, B, 14), np.array(rec_u).reshape(n, B, 4)
+        TS, IT = np.array(rec_t).reshape(n, B), np.array(rec_it, dtype=np.int32).reshape(n, B)
         return dict(
-            X_sim=[np.array(v).reshape(-1, 14) for v in X_sim],
-            U_sim=[np.array(v).reshape(-1, 4) for v in U_sim],
-            t_plan=[np.array(v) for v in t_plan],
-            sc_iters=[np.array(v, dtype=np.int32) for v in sc_iters],
+            X_sim=[XS[OK[:, b], b] for b in range(B)],
+            U_sim=[US[OK[:, b], b] for b in range(B)],
+            t_plan=[TS[OK[:, b], b] for b in range(B)],
+            sc_iters=[IT[OK[:, b], b] for b in range(B)],
             steps=steps, reached_end=reached, solver_failed=failed, x=x,
         )

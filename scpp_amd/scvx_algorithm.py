@@ -29,8 +29,9 @@ def load_scvx_opts(param_folder, K=None, max_iterations=None):
 
 
 class SCvxAlgorithm:
-    def __init__(self, model, K=None, batch_max=1, device=0, library=None, max_iterations=None):
+    def __init__(self, model, K=None, batch_max=1, device=0, library=None, max_iterations=None, record_iterates=False):
         self.model = model
+        self._record = bool(record_iterates)  # getAllSolutions needs the record: opt-in (max_iterations + 1 trajectories per instance on the device)
         self._max_iterations = max_iterations
         self.opts = load_scvx_opts(model.getParameterFolder(), K, max_iterations)
         self.batch_max, self.device, self.library = batch_max, device, library
@@ -39,6 +40,8 @@ class SCvxAlgorithm:
     def initialize(self):
         """SCvxAlgorithm::initialize (SCvxAlgorithm.cpp:46-59): allocates the device context."""
         self.ctx = Context(self.model.model_id, self.opts.K, self.batch_max, self.device, self.library)
+        if self._record:
+            self.ctx.scvx_record_iterates(True)
         return self
 
     def solve(self, x_init=None, warm_start=False):
@@ -66,3 +69,14 @@ class SCvxAlgorithm:
         out = self.ctx.download()
         out.update(self.ctx.scvx_state())
         return out
+
+    def getAllSolutions(self, first=0, count=None):
+        """SCvxAlgorithm::getAllSolutions (SCvxAlgorithm.hpp:48, SCvxAlgorithm.cpp:245-260) for a batch: per instance the list of trajectories
+        all_td -- the initial trajectory, then the trajectory after every iteration of the last solve() (rejected candidates never appear) --
+        redimensionalised, as dicts X [K][nx], U [K][nu], t.  Needs record_iterates=True at construction."""
+        if not self._record:
+            raise RuntimeError("SCvxAlgorithm(..., record_iterates=True) records the iterates getAllSolutions returns")
+        X, U, n, sc = self.ctx.scvx_iterates(self.opts.max_iterations + 1, first, count)
+        sig = self.ctx.download()["sigma"]
+        return [[dict(X=X[b, j], U=U[b, j], t=float(sig[first + b]), trust_region=float(sc[b, j, 0]), solves=int(sc[b, j, 1]), nonlinear_cost=float(sc[b, j, 2]),
+                      decision=int(sc[b, j, 3])) for j in range(int(n[b]))] for b in range(X.shape[0])]

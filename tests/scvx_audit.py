@@ -21,9 +21,11 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def device_path(alg, x0, max_iterations):
+def device_path_capped(alg, x0, max_iterations):
     """path[j] = dict(X, U, radius, solves, iters, converged) after j iterations, j = 0 .. (until every instance has ended);
-    path[0] is the initial trajectory (getInitializedTrajectory, redimensionalised) with the configured radius."""
+    path[0] is the initial trajectory (getInitializedTrajectory, redimensionalised) with the configured radius.
+    The way rounds 3 - 5 recovered the iterates: j + 1 runs capped at max_iterations = 0 .. j (the engine is deterministic, so a run capped at j ends at
+    iterate j of the full run).  Kept as the independent check of device_path below (tests: bitwise the same path)."""
     path = []
     keep = alg._max_iterations
     try:
@@ -38,6 +40,35 @@ def device_path(alg, x0, max_iterations):
                 break
     finally:
         alg._max_iterations = keep
+    return path
+
+
+def device_path(alg, x0, max_iterations):
+    """The same path from ONE run: the device records every iterate (scpp_hip_scvx_record_iterates / _download_iterates, round 6 -- the counterpart of
+    SCvxAlgorithm::getAllSolutions, SCvxAlgorithm.cpp:245-260: the initial trajectory and the trajectory after every iteration, with the radius, the
+    solve count and J at that point)."""
+    keep = alg._max_iterations
+    try:
+        alg._max_iterations = max_iterations
+        alg.ctx.scvx_record_iterates(True)
+        alg.solve(x0)
+        o = alg.getSolution()
+        assert (o["status"] == 0).all()
+        X, U, n, sc = alg.ctx.scvx_iterates(max_iterations + 1)
+    finally:
+        alg._max_iterations = keep
+        alg.ctx.scvx_record_iterates(False)
+    B = X.shape[0]
+    rows = np.arange(B)
+    assert (n >= 1).all() and (n - 1 == np.where(max_iterations > 0, o["sc_iters"], 0)).all() and np.array_equal(X[rows, n - 1], o["X"]) and np.array_equal(U[rows, n - 1], o["U"])
+    path = []
+    for j in range(0, max_iterations + 1):
+        jj = np.minimum(j, n - 1)  # an instance that ended earlier keeps its last iterate (what a run capped at j returns for it)
+        conv = ((o["converged"] == 1) & (j >= n - 1)).astype(np.int32)
+        path.append(dict(X=X[rows, jj].copy(), U=U[rows, jj].copy(), radius=sc[rows, jj, 0].copy(), solves=sc[rows, jj, 1].astype(np.int32),
+                         iters=(jj if j > 0 else o["sc_iters"] * 0 + 1).astype(np.int32), converged=conv))
+        if (conv == 1).all():
+            break
     return path
 
 

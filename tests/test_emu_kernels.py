@@ -728,3 +728,45 @@ def test_emu_negative_gap_without_a_fallback_is_a_failure(emu_lib):
     for gap in ("-1e29", "-1e31", "-1e-3"):
         st_b, it_b, _ = _inject_and_solve(emu_lib, "2:0:0:" + gap)
         assert st_b == -2 and it_b == 2, (gap, st_b, it_b)
+
+
+def test_emu_scvx_recorded_iterates_equal_capped_reruns(model, emu_lib):
+    """scpp_hip_scvx_record_iterates / _download_iterates (SCvxAlgorithm::getAllSolutions, SCvxAlgorithm.cpp:192,201,245-260): ONE run that records the
+    trajectory before the first and after every iteration on the device must give bitwise the path rounds 3 - 5 recovered with j + 1 runs capped at
+    max_iterations = 0 .. j -- trajectories, radius and solve counts (rejected candidates on the way are counted, never recorded) -- on both engines; the
+    mirror's getAllSolutions returns the same trajectories per instance, the last one bitwise getSolution's."""
+    import scvx_audit
+    from scpp_amd import _lib
+
+    K, B, maxit = 8, 3, 6
+    x0 = model.randomized_initial_states(B, first=11)
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    ref = scvx_audit.device_path_capped(alg, x0, maxit)
+    assert sum(int(p["solves"].sum()) for p in ref[-1:]) > B * len(ref[1:])  # rejected candidates on the way
+    for engine in (_lib.STREAM_PERSISTENT, _lib.STREAM_POOLS):
+        alg.ctx.set_stream_engine(engine)
+        got = scvx_audit.device_path(alg, x0, maxit)
+        assert len(got) == len(ref)
+        for j, (a, b) in enumerate(zip(got, ref)):
+            for key in ("X", "U", "radius", "solves", "converged"):
+                assert np.array_equal(a[key], b[key]), (engine, j, key)
+            if j > 0:
+                assert np.array_equal(a["iters"], b["iters"]), (engine, j)
+    alg.ctx.close()
+    rec = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit, record_iterates=True).initialize()
+    rec.solve(x0)
+    sol, all_td = rec.getSolution(), rec.getAllSolutions()
+    assert len(all_td) == B
+    for b in range(B):
+        assert len(all_td[b]) == sol["sc_iters"][b] + 1
+        assert np.array_equal(all_td[b][-1]["X"], sol["X"][b]) and np.array_equal(all_td[b][-1]["U"], sol["U"][b])
+        for j, td in enumerate(all_td[b]):
+            assert np.array_equal(td["X"], ref[min(j, len(ref) - 1)]["X"][b])
+        assert [td["decision"] for td in all_td[b]][:2] == [0, 2]  # initial trajectory, first pass
+    # without the opt-in there is no record to return, and a streaming job does not record
+    plain = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=maxit).initialize()
+    plain.solve(x0)
+    with pytest.raises(scpp_amd.ScppHipError):
+        plain.ctx.scvx_iterates(maxit + 1)
+    with pytest.raises(RuntimeError):
+        plain.getAllSolutions()

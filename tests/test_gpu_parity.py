@@ -1001,3 +1001,36 @@ def test_broken_iterate_does_not_replace_the_fallback_on_gpu(oracle, model, hip_
         assert n == 64 and (o["status"] == 0).all() and np.isfinite(o["U"]).all() and np.abs(o["U"]).max() < 1e6
         assert int(o["sc_iters"][10]) == mm["iterations"] and int(o["solves"][10]) == mm["solves"], (o["sc_iters"][10], o["solves"][10], mm)
     print("instance 8392: converged in %d iterations / %d solves on both engines, as the twin" % (mm["iterations"], mm["solves"]))
+
+
+@pytest.mark.gpu
+def test_recorded_iterates_equal_capped_reruns_on_gpu(model, hip_lib):
+    """SCvxAlgorithm::getAllSolutions on the device (round 6: scpp_hip_scvx_record_iterates / _download_iterates): ONE run at K = 50 that records the
+    trajectory before the first and after every iteration must give BITWISE the path the audits of rounds 3 - 5 recovered with j + 1 runs capped at
+    max_iterations = 0 .. j -- trajectories, radius, solve counts -- on both engines.  (tests/scvx_audit.device_path, which every path audit of this
+    suite uses, reads the record since round 6.)"""
+    import scvx_audit
+
+    K, B, maxit = 50, 16, 8
+    x0 = model.randomized_initial_states(B, first=700)
+    alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=hip_lib, max_iterations=maxit).initialize()
+    ref = scvx_audit.device_path_capped(alg, x0, maxit)
+    assert int(ref[-1]["solves"].sum()) > B * (len(ref) - 1)  # rejected candidates on the way
+    for engine in (scpp_amd._lib.STREAM_PERSISTENT, scpp_amd._lib.STREAM_POOLS):
+        alg.ctx.set_stream_engine(engine)
+        got = scvx_audit.device_path(alg, x0, maxit)
+        assert len(got) == len(ref)
+        for j, (a, b) in enumerate(zip(got, ref)):
+            for key in ("X", "U", "radius", "solves", "converged"):
+                assert np.array_equal(a[key], b[key]), (engine, j, key)
+    alg.ctx.close()
+    rec = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=hip_lib, record_iterates=True).initialize()  # the shipped 30 iterations
+    n = rec.solve(x0)
+    sol, all_td = rec.getSolution(), rec.getAllSolutions()
+    assert n == B
+    for b in range(B):
+        assert len(all_td[b]) == sol["sc_iters"][b] + 1 and all_td[b][-1]["decision"] == 3
+        assert np.array_equal(all_td[b][-1]["X"], sol["X"][b]) and np.array_equal(all_td[b][-1]["U"], sol["U"][b])
+        assert all_td[b][-1]["solves"] == sol["solves"][b] and all_td[b][-1]["trust_region"] == sol["trust_region"][b]
+    print("getAllSolutions on the device: %d instances, %d .. %d trajectories each, bitwise the capped re-runs" % (B, min(len(t) for t in all_td), max(len(t) for t in all_td)))
+    rec.ctx.close()

@@ -165,12 +165,26 @@ def test_sc_oneshot_scvx_mode(oracle, host_emu, tmp_path):
     assert s.solve() == 0
     m = s.meta()
     assert f"converged {m['converged']}, solver failures 0, mean iterations {m['iterations']:.2f}, mean sub-problem solves {m['solves']:.2f}" in out
-    run = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SCvx" / "*" / "0"))[0]
-    X, U, t = s.iterate(-1)
-    Xf, Uf = _read(os.path.join(run, "X.txt")), _read(os.path.join(run, "U.txt"))
-    assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max())
-    assert np.allclose(Uf, U, rtol=2e-4, atol=2e-4 * np.abs(U).max())
-    assert abs(float(open(os.path.join(run, "t.txt")).read()) - t) <= 1e-5 * t
+    # round 6: every trajectory of getAllSolutions is written, like the reference's driver does (SC_oneshot.cpp:31-63): <time>/0 = the initial
+    # trajectory, <time>/j = the trajectory after iteration j
+    base = glob.glob(str(tmp_path / "output" / "RocketQuat" / "SCvx" / "*"))[0]
+    dirs = sorted(int(d) for d in os.listdir(base))
+    assert dirs == list(range(m["iterations"] + 1)) and f"({m['iterations'] + 1} iterates)" in out
+    # the oracle keeps all_td nondimensional (as the reference's member does); getAllSolutions redimensionalises (SCvxAlgorithm.cpp:247-255):
+    # mass and length scale from the final trajectory, which the oracle returns in both forms
+    (Xd, _, _), (Xn, _, _) = s.iterate(-1), s.iterate(dirs[-1])
+    ms, rs = Xd[0, 0] / Xn[0, 0], Xd[0, 3] / Xn[0, 3]
+    fx = np.array([ms] + [rs] * 6 + [1.0] * 7)
+    fu = np.array([ms * rs] * 3 + [ms * rs * rs])
+    for j in dirs:
+        run = os.path.join(base, str(j))
+        X, U, t = s.iterate(j)
+        X, U = X * fx, U * fu
+        Xf, Uf = _read(os.path.join(run, "X.txt")), _read(os.path.join(run, "U.txt"))
+        assert np.allclose(Xf, X, rtol=2e-5, atol=2e-5 * np.abs(X).max()), j
+        assert np.allclose(Uf, U, rtol=2e-4, atol=2e-4 * np.abs(U).max()), j
+        assert abs(float(open(os.path.join(run, "t.txt")).read()) - t) <= 1e-5 * t
+    assert np.allclose(Xd, Xn * fx, rtol=1e-12)
 
 
 def test_mpc_sim_matches_oracle_closed_loop(oracle, host_emu, tmp_path):

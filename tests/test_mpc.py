@@ -264,3 +264,37 @@ def test_emu_mpc_mirror_symmetry(rocket2d, emu_lib):
     assert np.abs(X[:6] * M - X[6:]).max() <= 1e-6 * np.abs(X).max()
     assert np.abs(out["cost"][:6] - out["cost"][6:]).max() <= 1e-7 * out["cost"].max()
     a.ctx.close()
+
+
+def _mpc_inject(emu_lib, spec):
+    """one MPC solve of one controller on the emulator in a fresh process with SCPP_EMU_INJECT_MPC_RES=spec -> (status, iterations)"""
+    import json, os, subprocess, sys
+    code = (
+        "import json, numpy as np, scpp_amd\n"
+        "m = scpp_amd.Rocket2D().loadParameters(); m.p.constrain_initial_final = False\n"
+        "alg = scpp_amd.MPCAlgorithm(m, batch_max=1, library=%r).initialize()\n"
+        "alg.setInitialState(m.randomized_initial_states(1)); alg.setFinalState(m.p.x_final)\n"
+        "alg.solve(); o = alg.getSolution()\n"
+        "print('RESULT ' + json.dumps([int(o['status'][0]), int(o['iters'][0])]))\n" % emu_lib
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("SCPP_EMU_INJECT_MPC_RES", None)
+    if spec:
+        env["SCPP_EMU_INJECT_MPC_RES"] = spec
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_emu_mpc_broken_iterate_without_a_fallback_is_a_failure(emu_lib):
+    """VERDICT r5 missing 3 / DESIGN r5 section 9 item 4: mpc_solve_kernel's breakdown test came before its fall-back save (the right order) but, like the big
+    solver until round 5, let a blown-up or out-of-cone iterate through its convergence test when no fall-back existed: pres, dres are relative to
+    the iterate's norm and a negative gap meets `gap < abstol`.  The emulator build replaces the termination quantities of the 3rd evaluation of a
+    cold solve (no fall-back yet): it must fail with -2 for a blown-up, a hugely negative and a merely negative gap; the control (gap +1e-12) is
+    accepted there, which shows the hook reaches the rule."""
+    st, it = _mpc_inject(emu_lib, "")
+    assert st == 0 and it > 4
+    assert _mpc_inject(emu_lib, "2:0:0:1e-12") == [0, 2]
+    for gap in ("1e31", "-1e31", "-1e29", "-1e-3"):
+        assert _mpc_inject(emu_lib, "2:0:0:" + gap) == [-2, 2], gap
