@@ -5,9 +5,25 @@
 // JIT-compiles a CppAD-generated C file instead: systemDynamics.hpp:132-144).
 // Reference quirks kept on purpose: un-normalised quaternion rotation matrix
 // (Eigen toRotationMatrix), gyroscopic term w x w == 0.
+//
+// ONE source of truth per model (round 6): this flow map is the only place a model's dynamics are written.  The analytic Jacobian rows / table the
+// discretisation kernel uses (model_jacobian_rows.h) are GENERATED from it: tools/flowmap_symbolic.cpp instantiates systemFlowMap with a scalar type
+// that records expressions (T = PT = Sym), tools/gen_model_jacobian.py parses what it prints with sympy, differentiates and emits the header -- the
+// reference's CppAD tape -> CppADCodeGen -> C step (systemDynamics.hpp:109-168) at build time.  Hence the two template parameters: T = scalar of states,
+// inputs and outputs (double, Dual1, Sym), PT = scalar of the parameters (double everywhere on the device, Sym in the generator).
 #pragma once
 #include "common.h"
+#ifndef SCPP_FLOWMAP_ONLY // (the generator's host tool compiles the flow maps without the header it is about to generate)
 #include "model_jacobian_rows.h"
+#else
+namespace scpp
+{
+struct RocketQuatJacobianRows;
+struct RocketQuatJacobianTable;
+struct Rocket2dJacobianRows;
+struct Rocket2dJacobianTable;
+} // namespace scpp
+#endif
 
 namespace scpp
 {
@@ -22,10 +38,10 @@ struct RocketQuatModel
     using JacobianTable = RocketQuatJacobianTable; // the same, one output per lane (discretize_kernel)
 
     // par = [alpha_m, g_I(3), J_B(3), r_T_B(3)]   rocketQuat.cpp:168-173
-    template <class T>
-    __host__ __device__ static void systemFlowMap(const T *x, const T *u, const double *par, T *f)
+    template <class T, class PT = double>
+    __host__ __device__ static void systemFlowMap(const T *x, const T *u, const PT *par, T *f)
     {
-        const double alpha_m = par[0];
+        const PT alpha_m = par[0];
         const T m = x[0];
         const T qw = x[7], qx = x[8], qy = x[9], qz = x[10];
         const T wx = x[11], wy = x[12], wz = x[13];
@@ -49,7 +65,7 @@ struct RocketQuatModel
         f[8] = 0.5 * (wx * qw + wz * qy - wy * qz);
         f[9] = 0.5 * (wy * qw - wz * qx + wx * qz);
         f[10] = 0.5 * (wz * qw + wy * qx - wx * qy);
-        const double rx = par[7], ry = par[8], rz = par[9];
+        const PT rx = par[7], ry = par[8], rz = par[9];
         const T cxr = ry * Tz - rz * Ty, cyr = rz * Tx - rx * Tz, czr = rx * Ty - ry * Tx;
         f[11] = (1. / par[4]) * cxr - (wy * wz - wz * wy);
         f[12] = (1. / par[5]) * cyr - (wz * wx - wx * wz);
@@ -64,10 +80,10 @@ struct Rocket2dModel
     static constexpr int MODEL_ID = 1;
     using JacobianRows = Rocket2dJacobianRows;
     using JacobianTable = Rocket2dJacobianTable;
-    template <class T>
-    __host__ __device__ static void systemFlowMap(const T *x, const T *u, const double *par, T *f)
+    template <class T, class PT = double>
+    __host__ __device__ static void systemFlowMap(const T *x, const T *u, const PT *par, T *f)
     {
-        const double m = par[0], J_B = par[1];
+        const PT m = par[0], J_B = par[1];
         const T eta = x[4], w = x[5];
         const T angle = u[0], magnitude = u[1];
         const T TBx = dcos(angle) * 0. - dsin(angle) * magnitude;

@@ -122,7 +122,9 @@ def test_generated_rows_match_sympy_golden_and_forward_ad(rows_bin, name, flag, 
 
 
 def test_generated_header_is_up_to_date(tmp_path):
-    """The committed header is what tools/gen_model_jacobian.py produces from the current symbolic flow maps."""
+    """The committed header is what tools/gen_model_jacobian.py produces from the C++ flow maps (round 6: the generator EXECUTES
+    csrc/model_rocketquat.h's systemFlowMap with an expression-recording scalar, tools/flowmap_symbolic.cpp -- a model's dynamics are written in one
+    place; a change of a flow map without regenerating fails here)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen", os.path.join(ROOT, "tools", "gen_model_jacobian.py"))
     gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)

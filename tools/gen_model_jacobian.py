@@ -2,7 +2,8 @@
 
 The reference obtains its Jacobians by taping systemFlowMap with CppAD and letting CppADCodeGen emit optimised (sparse) C
 source that is compiled and dlopen'ed at start-up (scpp_core/include/systemDynamics.hpp:109-168).  The build-time analogue
-here: the same flow maps written symbolically (sympy), differentiated, simplified by common-subexpression elimination and
+here: the C++ flow maps themselves, EXECUTED with a scalar type that records expressions (tools/flowmap_symbolic.cpp; round 6 --
+the model is written once), parsed with sympy, differentiated, simplified by common-subexpression elimination and
 printed as one `case` per state row -- discretize_kernel keeps one Jacobian row per lane, so a lane evaluates only the
 handful of non-zeros of ITS row instead of taking part in an 18-direction forward-mode sweep of the whole map.
 The generated header is committed (hipcc needs no sympy); tests/test_oracle_model.py checks it against the sympy goldens
@@ -34,37 +35,47 @@ class Printer(C99CodePrinter):
         return "(%d.0/%d.0)" % (e.p, e.q)
 
 
+_FLOWMAPS = None
+
+
+def flowmaps_from_cpp():
+    """The flow maps as sympy expressions, obtained by EXECUTING the C++ plugins with a recording scalar type (tools/flowmap_symbolic.cpp): the model is
+    written once, in csrc/model_rocketquat.h.  (Until round 6 this file carried a hand transcription of both maps, kept in step with the C++ by tests.)"""
+    global _FLOWMAPS
+    if _FLOWMAPS is not None:
+        return _FLOWMAPS
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "bin", "flowmap_symbolic")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-DSCPP_HIP_EMU", "-DSCPP_FLOWMAP_ONLY", "-I" + os.path.join(ROOT, "tests", "emu"),
+                           "-I" + os.path.join(ROOT, "scpp_amd", "csrc"), os.path.join(ROOT, "tools", "flowmap_symbolic.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True)
+    models, cur = {}, None
+    for line in out.splitlines():
+        if line.startswith("model "):
+            _, name, nx, nu, npar = line.split()
+            cur = dict(name=name, x=sp.symbols("x0:%d" % int(nx), real=True), u=sp.symbols("u0:%d" % int(nu), real=True),
+                       p=sp.symbols("p0:%d" % int(npar), real=True), f=[])
+            models[name] = cur
+        elif line.strip():
+            lhs, rhs = line.split(" = ", 1)
+            assert lhs == "f%d" % len(cur["f"])
+            loc = {str(s_): s_ for s_ in list(cur["x"]) + list(cur["u"]) + list(cur["p"])}
+            # numeric literals of the C++ source (2., 0.5, 1.) are exact rationals
+            cur["f"].append(sp.nsimplify(sp.sympify(rhs, locals=loc), rational=True))
+    _FLOWMAPS = models
+    return models
+
+
 def rocketquat():
     """csrc/model_rocketquat.h: RocketQuatModel::systemFlowMap (rocketQuat.cpp:7-37, incl. the un-normalised rotation matrix)"""
-    x = sp.symbols("x0:14", real=True)
-    u = sp.symbols("u0:4", real=True)
-    p = sp.symbols("p0:10", real=True)
+    m_ = flowmaps_from_cpp()["RocketQuat"]
+    x, u, p, f = m_["x"], m_["u"], m_["p"], m_["f"]
+    # OPTIMISATION HINTS, not model definition: wave-uniform, slow sub-expressions (a division or a square root each) evaluated ONCE before the row
+    # switch instead of inside its divergent cases: (C name, sympy expression); applied in this order, a later entry may use an earlier symbol
     m = x[0]
-    qw, qx, qy, qz = x[7:11]
-    wx, wy, wz = x[11:14]
-    T = sp.Matrix(u[0:3])
-    R = sp.Matrix([
-        [1 - 2 * (qy**2 + qz**2), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
-        [2 * (qx * qy + qw * qz), 1 - 2 * (qx**2 + qz**2), 2 * (qy * qz - qw * qx)],
-        [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx**2 + qy**2)],
-    ])
-    f = [None] * 14
-    f[0] = -p[0] * sp.sqrt(T.dot(T))
-    f[1], f[2], f[3] = x[4], x[5], x[6]
-    acc = R * T / m + sp.Matrix(p[1:4])
-    f[4], f[5], f[6] = acc
-    f[7] = sp.Rational(1, 2) * (-wx * qx - wy * qy - wz * qz)
-    f[8] = sp.Rational(1, 2) * (wx * qw + wz * qy - wy * qz)
-    f[9] = sp.Rational(1, 2) * (wy * qw - wz * qx + wx * qz)
-    f[10] = sp.Rational(1, 2) * (wz * qw + wy * qx - wx * qy)
-    rx, ry, rz = p[7:10]
-    f[11] = (ry * T[2] - rz * T[1]) / p[4]
-    f[12] = (rz * T[0] - rx * T[2]) / p[5]
-    f[13] = (rx * T[1] - ry * T[0] + u[3]) / p[6]
-    # wave-uniform, slow sub-expressions (a division or a square root each) evaluated ONCE before the row switch instead
-    # of inside its divergent cases: (C name, sympy expression)
-    # applied in this order; a later entry may be written in terms of an earlier symbol
-    TT = T.dot(T)
+    TT = u[0]**2 + u[1]**2 + u[2]**2
     tn = sp.Symbol("t_norm", real=True)
     hoist = [("inv_m", 1 / m), ("t_norm", sp.sqrt(TT)), ("inv_t_norm", 1 / tn),
              ("inv_j0", 1 / p[4]), ("inv_j1", 1 / p[5]), ("inv_j2", 1 / p[6])]  # the last three depend on par only -> aux[]
@@ -73,13 +84,8 @@ def rocketquat():
 
 def rocket2d():
     """csrc/model_rocketquat.h: Rocket2dModel::systemFlowMap (rocket2d.cpp:7-38)"""
-    x = sp.symbols("x0:6", real=True)
-    u = sp.symbols("u0:2", real=True)
-    p = sp.symbols("p0:6", real=True)
-    TBx, TBy = -sp.sin(u[0]) * u[1], sp.cos(u[0]) * u[1]
-    ce, se = sp.cos(x[4]), sp.sin(x[4])
-    f = [x[2], x[3], (ce * TBx - se * TBy) / p[0] + p[2], (se * TBx + ce * TBy) / p[0] + p[3], x[5],
-         (p[4] * TBy - p[5] * TBx) / p[1]]
+    m_ = flowmaps_from_cpp()["Rocket2d"]
+    x, u, p, f = m_["x"], m_["u"], m_["p"], m_["f"]
     hoist = [("inv_m", 1 / p[0]), ("inv_j", 1 / p[1]), ("sin_g", sp.sin(u[0])), ("cos_g", sp.cos(u[0])),
              ("sin_e", sp.sin(x[4])), ("cos_e", sp.cos(x[4]))]
     return "Rocket2d", x, u, p, f, hoist
@@ -320,16 +326,19 @@ def emit_table(model):
     return "\n".join(L)
 
 
-def main():
+def main(out=None):
+    out = out or OUT
     hdr = ["// GENERATED by tools/gen_model_jacobian.py (sympy %s) -- do not edit; regenerate after changing a flow map." % sp.__version__,
            "// Analytic rows of [df/dx | df/du] of the model plugins (the build-time analogue of the reference's CppADCodeGen step,",
            "// scpp_core/include/systemDynamics.hpp:109-168).  One `case` per state row: discretize_kernel keeps one Jacobian row per lane.",
            "#pragma once", "#include \"common.h\"", "", "namespace scpp", "{", ""]
     body = [emit(rocketquat()), emit_table(rocketquat()), emit(rocket2d()), emit_table(rocket2d())]
-    with open(OUT, "w") as fh:
+    with open(out, "w") as fh:
         fh.write("\n".join(hdr) + "\n".join(body) + "} // namespace scpp\n")
-    print("wrote", OUT)
+    print("wrote", out)
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+
+    main(sys.argv[1] if len(sys.argv) > 1 else OUT)
