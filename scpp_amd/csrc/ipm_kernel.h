@@ -32,6 +32,9 @@ namespace scpp
 namespace ipm
 {
 
+#ifndef IPM_FAC_ALIGN
+#define IPM_FAC_ALIGN 1 // 0: the factor / saved-column blocks where the field-major records end and records of 472 doubles (until round 6; A/B hook)
+#endif
 // ---- record layout of a model's problem (doubles per stage / segment) ----
 template <class P>
 struct Lay : Derived<P>
@@ -85,7 +88,11 @@ struct Lay : Derived<P>
     //      Ti lower triangle of the NL x NL block.  Z = Ti N is not stored: N = [I | -C] makes it 4 extra matrix-core
     //      instructions from Ti and the entries of C.
     static constexpr int FAC_LI = 0, FAC_YT = NV * (NV + 1) / 2, FAC_TI = FAC_YT + NV * NL;
-    static constexpr int FACREC = (FAC_TI + NL * (NL + 1) / 2 + 7) & ~7;
+    // Multiple of a 128-byte line, and the block starts on one (facOffset below): a stage's record then spans exactly FACREC / 16 lines for each of its
+    // four passes per iteration (one write, three reads).  Until round 6 the block started wherever the field-major records ended (16 bytes past a
+    // line at K = 50) and a record of 472 doubles = 29.5 lines: every record straddled one line more than it fills, and so did every 128-byte vector
+    // of the saved forward columns behind it -- 51 KB per iteration in lines for 25.6 KB of data (tools/traffic_table.py, the emulator's tracer).
+    static constexpr int FACREC = IPM_FAC_ALIGN ? ((FAC_TI + NL * (NL + 1) / 2 + 15) & ~15) : ((FAC_TI + NL * (NL + 1) / 2 + 7) & ~7);
     // field-major copy of the segment dynamics (A, B, C, s, z) for the lane = segment phases
     static constexpr int DY_A = 0, DY_B = NX * NX, DY_C = DY_B + NX * NU, DY_S = DY_C + NX * NU, DY_Z = DY_S + NX, DYNREC = DY_Z + NX;
 };
@@ -139,12 +146,20 @@ constexpr int RSAVE = 112; // resume block of the split schedule (ipm_split.h): 
 #define IPM_WS_PAD 0
 #endif
 static_assert(IPM_WS_PAD % 16 == 0, "workspaces start on a 128-byte line");
+// doubles from the start of an instance's workspace to its factor records: exchange records, then the three field-major blocks, rounded up to a line
+template <class P>
+__host__ __device__ inline size_t facOffset(int K)
+{
+    using L = Lay<P>;
+    const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC);
+    return IPM_FAC_ALIGN ? ((n + 15) & ~size_t(15)) : n;
+}
 template <class P>
 __host__ __device__ inline size_t workspaceDoubles(int K)
 {
     using L = Lay<P>;
     // the exchange records come first so that they start on a 128-byte line; the total is a multiple of a line
-    const size_t n = size_t(K) * L::XREC + size_t(recPitch(K)) * (L::STREC + G_NFIELDS * L::NL + L::DYNREC) + size_t(K) * (L::FACREC + SVREC) + GSAVE + RSAVE;
+    const size_t n = facOffset<P>(K) + size_t(K) * (L::FACREC + SVREC) + GSAVE + RSAVE;
     return ((n + 15) & ~size_t(15)) + IPM_WS_PAD;
 }
 
@@ -206,6 +221,11 @@ __device__ inline SV makeSX(double *block, int xrec, int K, unsigned stage)
 // End of a load group: nothing is scheduled across this point, so every load written above it is issued before the arithmetic
 // below starts (left alone, the pressure heuristics of the scheduler sink loads into the arithmetic and turn one memory round
 // trip per group into one per handful of values -- counted in the ISA with tools/isa_round_trips.py).
+#ifndef SCPP_HIP_EMU // (the emulator's traffic tracer, tests/emu/hip_emu.h: which phase a buffer access belongs to, which record block it hits)
+#define EMU_PHASE(name)
+#define EMU_TRAFFIC_REGION(name, base, bytes, field_bytes, rec_bytes)
+#define EMU_TRAFFIC_MANUAL(what, n, store)
+#endif
 #ifdef SCPP_HIP_EMU
 #define LOADS_ISSUED()
 #else

@@ -765,6 +765,7 @@ __device__ inline Views makeViews(const Ctx &c)
 template <class P>
 PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
 {
+    EMU_PHASE("phSetup");
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;
     const bool warm = uniformInt(warmIn) != 0;
@@ -822,6 +823,7 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
         for (int i = 0; i < L::NL; i++)
             v.xs[L::X_S + i] = c.S[size_t(k) * NX + i];
         // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
+        EMU_TRAFFIC_MANUAL("dd A, B, C, S, Z row-major (plain pointers)", NX * NX + 2 * NX * NU + 3 * NX, false);
         const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
         for (int e = 0; e < NX * NX; e++)
             dy[L::DY_A + e] = Ak[e];
@@ -838,6 +840,7 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
     }
     if (v.vst)
     {
+        EMU_TRAFFIC_MANUAL("td X, U, uhat (plain pointers)", P::NXV + P::NUV + 3, false);
         const double *Xb = X + size_t(k) * NX, *Ub = U + size_t(k) * NU;
 #pragma unroll
         for (int j = 0; j < P::NXV; j++)
@@ -886,6 +889,7 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
 template <class P>
 PHASE_FN void phInitPrimalRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phInitPrimalRhs");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -928,6 +932,7 @@ PHASE_FN void phInitPrimalRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_
 template <class P>
 PHASE_FN void phInitPrimalFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phInitPrimalFinish");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
@@ -945,6 +950,7 @@ PHASE_FN void phInitPrimalFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *
 template <class P>
 PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phInitDualRhs");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -978,6 +984,7 @@ PHASE_FN void phInitDualRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 template <class P>
 PHASE_FN void phInitDualFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phInitDualFinish");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -1016,6 +1023,7 @@ PHASE_FN void phInitDualFinish(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip
 template <class P>
 PHASE_FN void phWarmInit(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phWarmInit");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     Glob g = loadPriv(gp);
@@ -1031,6 +1039,7 @@ PHASE_FN void phWarmInit(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 template <class P>
 PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phDataNorms");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -1308,6 +1317,7 @@ __device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz
 template <class P>
 PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phResiduals");
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;
     const Ctx c = uniformCtx(cin);
@@ -1548,6 +1558,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 template <class P>
 PHASE_FN void phScalings(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phScalings");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -1629,6 +1640,7 @@ __device__ inline void rhsSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
 template <class P, int PASS>
 PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE(PASS ? "phRhs<1>" : "phRhs<0>");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
@@ -1805,6 +1817,7 @@ struct DirChunkOut
 template <class P, int I0, int N, int PASS>
 PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu, double z3, double dz3, double dsig, double ainv, double sumdnb)
 {
+    EMU_PHASE(PASS ? "phDirSeg<1>" : "phDirSeg<0>");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const int k = c.lane, K = c.K;
@@ -1822,6 +1835,7 @@ PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu,
 template <class P, int PASS>
 PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE(PASS ? "phDirStage<1>" : "phDirStage<0>");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
@@ -1947,6 +1961,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 template <class P, int PASS>
 PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE(PASS ? "phDirSeg<1>" : "phDirSeg<0>");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     constexpr int pass = PASS; // 0: predictor (affine), 1: corrector -- two instantiations, no run-time branches around loads
@@ -2127,6 +2142,7 @@ __device__ inline void updSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
 template <class P, bool TO_LDS>
 PHASE_FN void phSegLdsCopy(const PRIV Ctx *cin)
 {
+    EMU_PHASE("phSegLdsCopy");
     using L = Lay<P>;
     if constexpr (!SegInLds<P>::value)
         return; // the fields never leave the workspace
@@ -2162,6 +2178,7 @@ PHASE_FN void phSegLdsCopy(const PRIV Ctx *cin)
 template <class P>
 PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
+    EMU_PHASE("phUpdate");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const Views v = makeViews<P>(c);
@@ -2286,7 +2303,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     c.pitch = recPitch(K);
     c.sg = c.st + size_t(c.pitch) * L::STREC;
     c.dy = c.sg + size_t(c.pitch) * (G_NFIELDS * L::NL);
-    c.fac = c.dy + size_t(c.pitch) * L::DYNREC;
+    c.fac = ws + facOffset<P>(K); // on a 128-byte line (ipm_kernel.h: FACREC)
     c.sv = c.fac + size_t(K) * L::FACREC;
     c.gsave = c.sv + size_t(K) * SVREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;
@@ -2295,6 +2312,16 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     c.S = a.S + size_t(inst) * (K - 1) * NX;
     c.Z = a.Z + size_t(inst) * (K - 1) * NX;
     c.ip = a.ip + size_t(inst) * IP_N;
+    EMU_PHASE("solve: outside the phases");
+    EMU_TRAFFIC_REGION("exchange [K][XREC]", c.sx, size_t(K) * L::XREC * 8, 8, size_t(L::XREC) * 8);
+    EMU_TRAFFIC_REGION("stage [STREC][K]", c.st, size_t(c.pitch) * L::STREC * 8, size_t(c.pitch) * 8, 0);
+    EMU_TRAFFIC_REGION("segment [G_NFIELDS*NL][K]", c.sg, size_t(c.pitch) * (G_NFIELDS * L::NL) * 8, size_t(c.pitch) * 8, 0);
+    EMU_TRAFFIC_REGION("dd copy [DYNREC][K]", c.dy, size_t(c.pitch) * L::DYNREC * 8, size_t(c.pitch) * 8, 0);
+    EMU_TRAFFIC_REGION("factor [K][FACREC]", c.fac, size_t(K) * L::FACREC * 8, 8, size_t(L::FACREC) * 8);
+    EMU_TRAFFIC_REGION("saved columns [K][SVREC]", c.sv, size_t(K) * SVREC * 8, 8, size_t(SVREC) * 8);
+    EMU_TRAFFIC_REGION("dd A [K-1][NX][NX]", c.A, size_t(K - 1) * NX * NX * 8, 8, size_t(NX) * NX * 8);
+    EMU_TRAFFIC_REGION("dd B [K-1][NX][NU]", c.B, size_t(K - 1) * NX * NU * 8, 8, size_t(NX) * NU * 8);
+    EMU_TRAFFIC_REGION("dd C [K-1][NX][NU]", c.C, size_t(K - 1) * NX * NU * 8, 8, size_t(NX) * NU * 8);
     // dynamic LDS (launchIpm: segLdsBytes<P>(K) [+ pad]): the LDS-resident segment fields
 #ifdef SCPP_HIP_EMU
     static double seg_lds[NSEGLDS * 16 * 64];
@@ -2329,6 +2356,8 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
 
     if (a.Xold && k < K)
     {
+        EMU_TRAFFIC_MANUAL("td X, U -> old_td snapshot (plain pointers)", NX + NU, false);
+        EMU_TRAFFIC_MANUAL("td X, U -> old_td snapshot (plain pointers)", NX + NU, true);
         const size_t o = size_t(inst) * K + k;
         for (int j = 0; j < NX; j++)
             a.Xold[o * NX + j] = a.X[o * NX + j];
@@ -2528,6 +2557,8 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     {
         if (vst)
         {
+            EMU_PHASE("solve: outputs");
+            EMU_TRAFFIC_MANUAL("td X, U written (plain pointers)", NX + NU, true);
             double *Xo = t.X + (size_t(inst) * K + k) * NX, *Uo = t.U + (size_t(inst) * K + k) * NU;
             // states / inputs the table pins for the whole horizon are written as their constant (0)
 #pragma unroll

@@ -71,7 +71,7 @@ __device__ inline Ctx splitCtx(const KernelArgs &a, int inst, int lane)
     c.pitch = recPitch(K);
     c.sg = c.st + size_t(c.pitch) * L::STREC;
     c.dy = c.sg + size_t(c.pitch) * (G_NFIELDS * L::NL);
-    c.fac = c.dy + size_t(c.pitch) * L::DYNREC;
+    c.fac = ws + facOffset<P>(K); // on a 128-byte line (ipm_kernel.h: FACREC)
     c.sv = c.fac + size_t(K) * L::FACREC;
     c.gsave = c.sv + size_t(K) * SVREC;
     c.A = a.A + size_t(inst) * (K - 1) * NX * NX;

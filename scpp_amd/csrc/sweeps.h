@@ -575,6 +575,7 @@ struct FactorOffs
 template <class P, int NCV>
 SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpec &spin)
 {
+    EMU_PHASE("factorSweepFused");
     using L = Lay<P>;
     constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
@@ -819,6 +820,7 @@ __device__ inline FwdIn loadFwdIn(const SweepIO<P> &io, const FwdOffs<P> &o, int
 template <class P>
 SWEEP_FN void fwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
+    EMU_PHASE("fwdSweep");
     using L = Lay<P>;
     constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
@@ -912,6 +914,7 @@ __device__ inline BwdIn loadBwdIn(const SweepIO<P> &io, const BwdOffs<P> &o, int
 template <class P>
 SWEEP_FN void bwdSweep(const LDSP Ctx *cin, const RhsSpec &spin)
 {
+    EMU_PHASE("bwdSweep");
     using L = Lay<P>;
     constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
@@ -1006,6 +1009,7 @@ struct FwdVIn
 template <class P, int NC>
 SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
 {
+    EMU_PHASE("fwdSweep");
     using L = Lay<P>;
     constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);
@@ -1087,6 +1091,7 @@ struct BwdVIn
 template <class P, int NC>
 SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
 {
+    EMU_PHASE("bwdSweep");
     using L = Lay<P>;
     constexpr int NL = L::NL;
     const Ctx c = uniformCtx(cin);

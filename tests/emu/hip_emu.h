@@ -20,6 +20,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
 #include <mutex>
 #include <vector>
 
@@ -288,19 +292,147 @@ inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, 
 {
     return hipemu_rsrc{reinterpret_cast<char *>(p), unsigned(num_records)};
 }
+// ---- traffic tracer (round 6; tools/traffic_table.py): with SCPP_EMU_TRAFFIC=<file> every in-range buffer access of the kernels is counted per
+// (phase, record block, field, load / store) -- the per-field traffic table of DESIGN.md 4.2c is this count, not an estimate.  The kernels announce
+// their record blocks (EMU_TRAFFIC_REGION) and the phase they are in (EMU_PHASE); accesses outside every announced block are counted as "other".
+namespace hipemu
+{
+struct TrafficRegion
+{
+    std::string name;
+    const char *base;
+    size_t bytes;
+    size_t field_bytes; // field-major block: bytes of one field row (pitch x 8) ; stage-major block: 8
+    size_t rec_bytes;   // stage-major block: bytes of one stage's record (field = (offset % rec) / 8) ; field-major block: 0
+};
+struct Traffic
+{
+    bool on = false;
+    std::string file;
+    std::vector<TrafficRegion> regions;
+    const char *phase = "outside";
+    std::map<std::string, long long> cnt; // "phase|region|field|L" or "...|S" -> 8-byte lane accesses
+    // distinct 128-byte lines touched by the loads / stores of ONE invocation of a phase (what reaches the L2 / the fabric once the lanes of an
+    // instruction, and the instructions of a phase that re-touch a line, have coalesced): "U|phase|region|L" -> lines, summed over invocations
+    std::map<std::pair<int, int>, std::set<uintptr_t>> lines; // (region index, store) -> lines of the current invocation
+    void flush()
+    {
+        for (auto &kv : lines)
+        {
+            const std::string region = kv.first.first >= 0 ? regions[size_t(kv.first.first)].name : "other";
+            cnt["U|" + std::string(phase) + "|" + region + (kv.first.second ? "|S" : "|L")] += (long long)kv.second.size();
+        }
+        lines.clear();
+    }
+    Traffic()
+    {
+        if (const char *e = std::getenv("SCPP_EMU_TRAFFIC"))
+        {
+            on = true;
+            file = e;
+        }
+    }
+    ~Traffic()
+    {
+        if (!on)
+            return;
+        flush();
+        if (FILE *f = std::fopen(file.c_str(), "w"))
+        {
+            std::fprintf(f, "{\n");
+            bool first = true;
+            for (const auto &kv : cnt)
+            {
+                std::fprintf(f, "%s \"%s\": %lld", first ? "" : ",\n", kv.first.c_str(), kv.second);
+                first = false;
+            }
+            std::fprintf(f, "\n}\n");
+            std::fclose(f);
+        }
+    }
+};
+inline Traffic &traffic()
+{
+    static Traffic t;
+    return t;
+}
+inline void traffic_region(const char *name, const void *base, size_t bytes, size_t field_bytes, size_t rec_bytes)
+{
+    Traffic &t = traffic();
+    if (!t.on)
+        return;
+    for (auto &r : t.regions)
+        if (r.name == name)
+        {
+            r = TrafficRegion{name, reinterpret_cast<const char *>(base), bytes, field_bytes, rec_bytes};
+            return;
+        }
+    t.regions.push_back(TrafficRegion{name, reinterpret_cast<const char *>(base), bytes, field_bytes, rec_bytes});
+}
+inline void traffic_access(const char *addr, bool store)
+{
+    Traffic &t = traffic();
+    if (!t.on)
+        return;
+    std::string key = std::string(t.phase) + "|";
+    bool found = false;
+    int ri = -1;
+    for (size_t q = 0; q < t.regions.size(); q++)
+    {
+        const auto &r = t.regions[q];
+        if (addr >= r.base && addr < r.base + r.bytes)
+        {
+            const size_t o = size_t(addr - r.base);
+            const size_t field = r.rec_bytes ? (o % r.rec_bytes) / 8 : o / r.field_bytes;
+            key += r.name + "|" + std::to_string(field);
+            found = true;
+            ri = int(q);
+            break;
+        }
+    }
+    t.lines[{ri, store ? 1 : 0}].insert(reinterpret_cast<uintptr_t>(addr) >> 7);
+    if (!found)
+        key += "other|0";
+    key += store ? "|S" : "|L";
+    t.cnt[key] += 1;
+}
+inline void traffic_manual(const char *what, long long n, bool store) // accesses through plain pointers (not buffer resources), counted by hand
+{
+    Traffic &t = traffic();
+    if (t.on)
+        t.cnt[std::string(t.phase) + "|" + what + "|0|" + (store ? "S" : "L")] += n;
+}
+} // namespace hipemu
+#define EMU_TRAFFIC_MANUAL(what, n, store) hipemu::traffic_manual(what, n, store)
+// (lane 0 enters a phase first -- the lanes are fibers run in order between synchronisation points, and every phase ends on one: the lines of the
+//  invocation that just ended are complete when lane 0 announces the next)
+#define EMU_PHASE(name)                                                                                                \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (hipemu::traffic().on && threadIdx.x == 0)                                                                  \
+            hipemu::traffic().flush();                                                                                 \
+        hipemu::traffic().phase = (name);                                                                              \
+    } while (0)
+#define EMU_TRAFFIC_REGION(name, base, bytes, field_bytes, rec_bytes) hipemu::traffic_region(name, base, bytes, field_bytes, rec_bytes)
 inline hipemu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int)
 {
     hipemu_u32x2 v = {0u, 0u};
     const unsigned o = unsigned(voffset) + unsigned(soffset);
     if (o + 8u <= r.nbytes)
+    {
         std::memcpy(&v, r.base + o, 8);
+        hipemu::traffic_access(r.base + o, false);
+    }
     return v;
 }
 inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int)
 {
     const unsigned o = unsigned(voffset) + unsigned(soffset);
     if (o + 8u <= r.nbytes)
+    {
         std::memcpy(r.base + o, &v, 8);
+        hipemu::traffic_access(r.base + o, true);
+    }
 }
 
 // ---- host runtime shim ----
@@ -318,7 +450,7 @@ typedef hipemu_event *hipEvent_t;
 #define hipMemcpyDefault 4
 inline hipError_t hipMalloc(void **p, size_t n)
 {
-    *p = std::malloc(n ? n : 1);
+    *p = std::aligned_alloc(256, ((n ? n : 1) + 255) & ~size_t(255)); // 256-byte aligned like the device allocator (the traffic tracer counts 128-byte lines)
     if (*p)
         std::memset(*p, 0xFF, n); // poison: any read-before-write of device memory shows up as NaN
     return *p ? 0 : 2;
