@@ -475,6 +475,41 @@ def main():
         except Exception as e:
             extras["single_batch"] = {"error": str(e)}
         ctx.close()
+        # ---- the other instantiations of the persistent kernel (round 6: both models, both input holds): a 2-batch streaming job each ----
+        try:
+            import shutil, tempfile
+
+            legs = {}
+            for mdl, foh, Kx in (("RocketQuat", False, K), ("Rocket2D", True, 30), ("Rocket2D", False, 30)):
+                d = tempfile.mkdtemp()
+                cfg = os.path.join(d, "config")
+                shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
+                pth = os.path.join(cfg, mdl, "SCvx.info")
+                t = open(pth).read()
+                if not foh:
+                    t = t.replace("interpolate_input                   true", "interpolate_input                   false")
+                if mdl == "Rocket2D":  # the shipped file runs in SI units and does not converge; nondimensionalised it does
+                    t = t.replace("nondimensionalize                   false", "nondimensionalize                   true")
+                open(pth, "w").write(t)
+                mx = (scpp_amd.RocketQuat if mdl == "RocketQuat" else scpp_amd.Rocket2D)(cfg).loadParameters()
+                ax = scpp_amd.SCvxAlgorithm(mx, K=Kx, batch_max=B, device=dev_index, library=args.library).initialize()
+                xx = mx.randomized_initial_states(2 * B, seed=args.seed, first=40_000_000)
+                ax.solveStream(xx[:256], slots=256)
+                tx0 = time.perf_counter()
+                ncx = ax.solveStream(xx, slots=B)
+                ox = ax.ctx.stream_download()
+                tx = time.perf_counter() - tx0
+                legs["%s_%s_K%d" % (mdl, "FOH" if foh else "ZOH", Kx)] = {
+                    "engine": "persistent kernel" if ax.ctx.stream_rounds()["pools"] == 0 else "pool engine",
+                    "converged_trajectories_per_s": ncx / tx, "converged_fraction": ncx / (2 * B), "solver_failures": int((ox["status"] != 0).sum()),
+                    "mean_subproblem_solves": float(ox["solves"].mean()), "mean_ipm_iterations_per_trajectory": float(ox["ipm_iters"].mean()),
+                    "config": "SCvx.info with interpolate_input %s%s" % ("true" if foh else "false", ", nondimensionalize true" if mdl == "Rocket2D" else ""),
+                }
+                ax.ctx.close()
+                shutil.rmtree(d, ignore_errors=True)
+            extras["other_instantiations"] = legs
+        except Exception as e:
+            extras["other_instantiations"] = {"error": str(e)}
         # ---- SC mode (SCAlgorithm: what SC_oneshot runs): terminated trajectories/s ----
         try:
             salg = scpp_amd.SCAlgorithm(model, K=K, batch_max=B, device=dev_index, library=args.library).initialize()

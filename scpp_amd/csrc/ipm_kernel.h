@@ -221,8 +221,17 @@ __device__ inline SV makeSX(double *block, int xrec, int K, unsigned stage)
 // End of a load group: nothing is scheduled across this point, so every load written above it is issued before the arithmetic
 // below starts (left alone, the pressure heuristics of the scheduler sink loads into the arithmetic and turn one memory round
 // trip per group into one per handful of values -- counted in the ISA with tools/isa_round_trips.py).
+// issue priority of a wavefront inside a lane phase (s_setprio; the sweeps set their own, sweeps.h): measurement hook of round 6
+#ifndef IPM_PRIO_LANE
+#define IPM_PRIO_LANE 0
+#endif
 #ifndef SCPP_HIP_EMU // (the emulator's traffic tracer, tests/emu/hip_emu.h: which phase a buffer access belongs to, which record block it hits)
-#define EMU_PHASE(name)
+#define EMU_PHASE(name)                                                                                                \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (IPM_PRIO_LANE)                                                                                             \
+            __builtin_amdgcn_s_setprio(IPM_PRIO_LANE);                                                                 \
+    } while (0)
 #define EMU_TRAFFIC_REGION(name, base, bytes, field_bytes, rec_bytes)
 #define EMU_TRAFFIC_MANUAL(what, n, store)
 #endif

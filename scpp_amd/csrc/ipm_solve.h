@@ -18,6 +18,7 @@ namespace ipm
 // handed inputs of 1e154 N to the next discretisation.  The sub-problems are nondimensional (costs 1e-2 .. 1e3; Rocket2D in SI units: 1e5, gaps up to
 // 1e9 at the cold start): 1e30 is never a value of a working iterate.
 #define IPM_BLOWN 1e30
+#define IPM_FUSE_UPDATE 1 // the step x += alpha dx is applied by the NEXT residual pass on its way in (phResiduals<P, true>; round 6)
 // A complementarity gap below -IPM_NEG_GAP is not a rounding artefact of an interior point (s and z inside the cone give s'z > 0): the iterate has left
 // the cone.  Round 6: until then a negative gap counted as broken only once a fall-back iterate existed; without one, `gap < abstol`
 // held trivially and a point with pres, dres below the tolerances and a gap of -1e29 returned status 0.  The magnitude test is two-sided now and a
@@ -53,6 +54,8 @@ struct KernelArgs
     int max_sc_iterations;
     int *warm;                   // [B] (may be null) 1: the workspace holds the primal-dual point of a successful previous solve
     int do_sc_update;            // 1: apply readSolution + convergence logic ; 0: plain sub-problem solve
+    const int *dd_fresh;         // (may be null) [B] 0: A .. Z of the instance are what this workspace's PREVIOUS solve saw (SCvx: a re-solve after a rejected
+                                 // candidate, SCvxAlgorithm.cpp:132-138) -- the field-major copy of dd and the data norm built on it are kept (round 6)
     double *Xold, *Uold;         // (may be null) SCvx: snapshot of the linearisation point taken before the solution
                                  // overwrites X / U (old_td = td, SCvxAlgorithm.cpp:77), [B][K][14] / [B][K][4]
     Settings opt;
@@ -505,6 +508,14 @@ __device__ inline void ldPad(const SV &r, const SV &rz, int f, double (&v)[N])
     for (int i = 0; i < N; i++)
         v[i] = (i >= 1 && i <= NP) ? double(rz[f + i]) : double(r[f + i]);
 }
+// entries I0 .. I0 + CN - 1 of a padded stage vector (ldPad's rule per entry) into an array of their own
+template <int NP, int I0, int CN>
+__device__ inline void ldPadPart(const SV &r, const SV &rz, int f, double (&v)[CN])
+{
+#pragma unroll
+    for (int i = 0; i < CN; i++)
+        v[i] = (I0 + i >= 1 && I0 + i <= NP) ? double(rz[f + I0 + i]) : double(r[f + I0 + i]);
+}
 template <int N, int NP>
 __device__ inline void stPad(const SV &r, const SV &rz, int f, const double (&v)[N])
 {
@@ -763,12 +774,13 @@ __device__ inline Views makeViews(const Ctx &c)
 
 // ---- setup: clear records, field-major copy of the dynamics, trust-region centre, fixed values ----
 template <class P>
-PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn)
+PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin, const double *uhatIn, PRIV Glob *gp, PRIV Iter *ip_, int warmIn, int ddSameIn)
 {
     EMU_PHASE("phSetup");
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;
     const bool warm = uniformInt(warmIn) != 0;
+    const bool dd_same = uniformInt(ddSameIn) != 0; // the workspace's field-major copy of A .. Z is still that of these data (167 KB not rewritten per re-solve)
     const Ctx c = uniformCtx(cin);
     const double *X = uniformPtr(Xin), *U = uniformPtr(Uin), *uhat = uniformPtr(uhatIn);
     const Views v = makeViews<P>(c);
@@ -822,20 +834,23 @@ PHASE_FN void phSetup(const PRIV Ctx *cin, const double *Xin, const double *Uin,
                 sg[i] = 0.;
         for (int i = 0; i < L::NL; i++)
             v.xs[L::X_S + i] = c.S[size_t(k) * NX + i];
-        // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
-        EMU_TRAFFIC_MANUAL("dd A, B, C, S, Z row-major (plain pointers)", NX * NX + 2 * NX * NU + 3 * NX, false);
-        const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
-        for (int e = 0; e < NX * NX; e++)
-            dy[L::DY_A + e] = Ak[e];
-        for (int e = 0; e < NX * NU; e++)
+        if (!dd_same)
         {
-            dy[L::DY_B + e] = Bk[e];
-            dy[L::DY_C + e] = Ck[e];
-        }
-        for (int e = 0; e < NX; e++)
-        {
-            dy[L::DY_S + e] = c.S[k * NX + e];
-            dy[L::DY_Z + e] = c.Z[k * NX + e];
+            // field-major copy of this segment's dynamics (read once row-major, re-read coalesced every iteration)
+            EMU_TRAFFIC_MANUAL("dd A, B, C, S, Z row-major (plain pointers)", NX * NX + 2 * NX * NU + 3 * NX, false);
+            const double *Ak = c.A + size_t(k) * NX * NX, *Bk = c.B + size_t(k) * NX * NU, *Ck = c.C + size_t(k) * NX * NU;
+            for (int e = 0; e < NX * NX; e++)
+                dy[L::DY_A + e] = Ak[e];
+            for (int e = 0; e < NX * NU; e++)
+            {
+                dy[L::DY_B + e] = Bk[e];
+                dy[L::DY_C + e] = Ck[e];
+            }
+            for (int e = 0; e < NX; e++)
+            {
+                dy[L::DY_S + e] = c.S[k * NX + e];
+                dy[L::DY_Z + e] = c.Z[k * NX + e];
+            }
         }
     }
     if (v.vst)
@@ -1037,11 +1052,12 @@ PHASE_FN void phWarmInit(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 }
 // ---- data norms for the termination test (ECOS-style scaling) ----
 template <class P>
-PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
+PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_, int ddSameIn)
 {
     EMU_PHASE("phDataNorms");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
+    const bool dd_same = uniformInt(ddSameIn) != 0; // the norm of the dynamics' constant part is that of the previous solve of this workspace (gsave[13])
     const Views v = makeViews<P>(c);
     const int K = v.K;
     const SV &st = v.st, &stN = v.stN, &dy = v.dy;
@@ -1064,7 +1080,7 @@ PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             for (int i = 0; i < L::NS; i++)
                 nh += r[i] * r[i];
         }
-        if (v.vsg)
+        if (v.vsg && !dd_same)
         {
             const unsigned fmn = L::fixedMask(v.k + 1, K);
             for (int j = 0; j < NV; j++)
@@ -1079,7 +1095,10 @@ PHASE_FN void phDataNorms(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         nb = wave_sum(nb);
         nh = wave_sum(nh) + 0.001 * 0.001 + 0.25 + 0.25 + it.sigbar * it.sigbar;
         it.resx0 = resx0;
-        it.resy0 = sqrt(nb) > 1. ? sqrt(nb) : 1.;
+        // (same data, same pinned variables -> the same number, bit for bit: kept in the warm-start block instead of 128 KB of the copy read again)
+        it.resy0 = dd_same ? double(c.gsave[13]) : (sqrt(nb) > 1. ? sqrt(nb) : 1.);
+        if (!dd_same && c.lane == 0)
+            c.gsave[13] = it.resy0;
         it.resz0 = sqrt(nh) > 1. ? sqrt(nh) : 1.;
     }
     storePriv(ip_, it);
@@ -1277,12 +1296,39 @@ __device__ inline SegDirRow segDirRow(const SegRhsRow &r, double vl, double bcl,
 }
 
 // ---- residuals, duality gap, termination quantities ----
+#ifdef SCPP_HIP_EMU
+// (one counter for both instantiations of phResiduals: a function of its own, not statics inside the template)
+inline void emuInjectResiduals(int lane, double &pres, double &dres, double &gap)
+{
+    static int calls[LANES];
+    static int inj_n = -2;
+    static double inj_v[3];
+    if (inj_n == -2)
+    {
+        const char *e = getenv("SCPP_EMU_INJECT_RES");
+        inj_n = -1;
+        if (e && sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
+            inj_n = -1;
+    }
+    if (inj_n >= 0 && calls[lane & (LANES - 1)]++ == inj_n)
+    {
+        pres = inj_v[0];
+        dres = inj_v[1];
+        gap = inj_v[2];
+    }
+}
+#endif
 struct ResAcc
 {
     double gap, rx, ry, rz, xx, yy, zz, ss, rxs, sumnb;
 };
-template <class P, int I0, int N>
-__device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz, double z3, ResAcc &p)
+// what the pending step of the previous iteration needs (UPD: phResiduals applies it on the way in, see there)
+struct PendingStep
+{
+    double om, sigmu, z3_old, dz3, dsig, alpha;
+};
+template <class P, int I0, int N, bool UPD>
+__device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz, const SV &xs, const SV &xsz, double z3, ResAcc &p, const PendingStep &u)
 {
     using L = Lay<P>;
     double nu[N], nub[N], s1[N], z1[N], s2[N], z2[N], lam[N], S[N];
@@ -1294,7 +1340,40 @@ __device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz
     ldl<P, SL_NUB, I0, N>(sl, nub);
     ldl<P, SL_LAM, I0, N>(sl, lam);
     ldf<N>(dyz, L::DY_S + I0, S); // dS/dsigma column: zero for a fixed final time (SCvx), read through the padded view
-    LOADS_ISSUED();
+    if constexpr (UPD)
+    {
+        // x += alpha dx ; s += alpha ds ; z += alpha dz of the rows' PREVIOUS iteration, applied here instead of in a phase of its own (round 6): the
+        // seven state fields are read ONCE for the step and for the residuals of the point it leads to.  The arithmetic is updSegChunk's, statement for
+        // statement (the corrector direction recomputed from the state, the predictor's products and the block solve's multiplier direction).
+        double vl[N], bcl[N], p1[N], p2[N];
+        ldf<N>(xs, L::X_VL + I0, vl);
+        ldf<N>(xsz, L::X_BCL + I0, bcl);
+        ldf<N>(sg, G_DS1 * L::NL + I0, p1);
+        ldf<N>(sg, G_DS2 * L::NL + I0, p2);
+        LOADS_ISSUED();
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            const SegRhsRow r = segRhsRow<1>(nu[i], nub[i], s1[i], z1[i], s2[i], z2[i], lam[i], p1[i], p2[i], u.om, u.sigmu, u.z3_old, u.dz3);
+            const SegDirRow d = segDirRow(r, vl[i], bcl[i], u.om, u.dsig);
+            nu[i] = nu[i] + u.alpha * d.dnu;
+            nub[i] = nub[i] + u.alpha * d.dnub;
+            lam[i] = lam[i] + u.alpha * d.dlam;
+            s1[i] = s1[i] + u.alpha * d.ds1;
+            z1[i] = z1[i] + u.alpha * d.dz1;
+            s2[i] = s2[i] + u.alpha * d.ds2;
+            z2[i] = z2[i] + u.alpha * d.dz2;
+        }
+        stl<P, SL_NU, I0, N>(sl, nu);
+        stl<P, SL_NUB, I0, N>(sl, nub);
+        stl<P, SL_LAM, I0, N>(sl, lam);
+        stf<N>(sg, G_S1 * L::NL + I0, s1);
+        stf<N>(sg, G_Z1 * L::NL + I0, z1);
+        stf<N>(sg, G_S2 * L::NL + I0, s2);
+        stf<N>(sg, G_Z2 * L::NL + I0, z2);
+    }
+    else
+        LOADS_ISSUED();
     // (the row residuals are not stored: the right-hand-side / direction phases recompute them from the state, segRhsRow)
 #pragma unroll
     for (int i = 0; i < N; i++)
@@ -1314,10 +1393,13 @@ __device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz
         p.rxs += S[i] * lam[i];
     }
 }
-template <class P>
+// UPD (round 6): the step of the previous iteration (phUpdate's work) is applied on the way into the residual pass -- the seven segment fields and W, delta,
+// s, z of a stage are read once for the step AND for the residuals of the new point instead of being stored by one phase and loaded by the next
+// (-47 KB of 1.92 MB per iteration, tools/traffic_table.py).  Same operations in the same order on every entry: bitwise the two phases.
+template <class P, bool UPD>
 PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 {
-    EMU_PHASE("phResiduals");
+    EMU_PHASE(UPD ? "phResiduals<update>" : "phResiduals");
     using L = Lay<P>;
     constexpr int NX = P::NX, NU = P::NU;
     const Ctx c = uniformCtx(cin);
@@ -1326,6 +1408,43 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &sgP = v.sgP, &dy = v.dy, &dyP = v.dyP;
     const double *ip = c.ip;
     const unsigned fm = v.fm;
+    PendingStep u{0., 0., 0., 0., 0., 0.};
+    if constexpr (UPD)
+    {
+        // the wave-uniform rows of the step (phUpdate's tail), first: everything below reads the new point
+        Glob g = loadPriv(gp);
+        const double sigma_c = ip_->sigma_c;
+        u.alpha = ip_->alpha;
+        u.om = 1. - sigma_c;
+        u.sigmu = sigma_c * double(ip_->mu);
+        u.z3_old = g.z3;
+        u.dz3 = g.dz3;
+        u.dsig = g.dsig;
+        const double alpha = u.alpha;
+        g.sig += alpha * g.dsig;
+        g.dsg += alpha * g.ddsg;
+        g.n1 += alpha * g.dn1;
+        g.ss += alpha * g.dss;
+        g.zs += alpha * g.dzs;
+        g.s3 += alpha * g.ds3;
+        g.z3 += alpha * g.dz3;
+        for (int i = 0; i < 3; i++)
+        {
+            g.sc3[i] += alpha * g.dsc3[i];
+            g.zc3[i] += alpha * g.dzc3[i];
+        }
+        PUT_BEGIN();
+        PUT(gp, g, sig);
+        PUT(gp, g, dsg);
+        PUT(gp, g, n1);
+        PUT(gp, g, ss);
+        PUT(gp, g, zs);
+        PUT(gp, g, s3);
+        PUT(gp, g, z3);
+        PUT(gp, g, sc3);
+        PUT(gp, g, zc3);
+        PUT_END();
+    }
     const double g_z3 = gp->z3, g_sig = gp->sig, it_wtrx = ip_->wtrx;
     const bool scvx = scvxMode(ip);
     const SV stz = padView(v.st, scvx);
@@ -1337,20 +1456,63 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     double p_dl = 0.;
     if (v.vsg)
     {
-        forSegChunks<P, chunkFor<P>(IPM_RES_CHUNK, IPM_RES_CHUNK_W)>([&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, sl, dyz, g_z3, p); });
+        const SV xsz = padView(v.xs, scvx);
+        forSegChunks<P, chunkFor<P>(IPM_RES_CHUNK, IPM_RES_CHUNK_W)>(
+            [&](auto i0, auto n) { resSegChunk<P, decltype(i0)::value, decltype(n)::value, UPD>(sg, sl, dyz, v.xs, xsz, g_z3, p, u); });
     }
+    double x0[NV], gw[NV], gdl = 0., dl = 0.;
     if (v.vst)
     {
-        double x0[NV], gw[NV], gdl, dl;
         {
             // rz = s - saff<P>(x) ; gap ; L'z
-            double wbar[NV], uh[3], sa[L::NS], sv[L::NS];
+            double wbar[NV], uh[3], sa[L::NS], sv[L::NS], zv[L::NS];
             ldf<NV>(st, L::F_W, x0);
             ldf<NV>(st, L::F_WBAR, wbar);
             ldf<3>(st, L::F_UHAT, uh);
             dl = st[L::F_DL];
-            ldPad<L::NS, P::NXV>(st, stz, L::F_S, sv);
-            LOADS_ISSUED();
+            if constexpr (UPD)
+            {
+                // the stage's share of the step (phUpdate's arithmetic: w += alpha dw on the free variables, delta, s += alpha ds), kept in registers.
+                // The directions arrive in pieces (W ; two halves of ds ; two halves of dz): all of them next to s, z, rz and W at once is 40 doubles
+                // more than a lane has (first form of this pass: 444 bytes of scratch per lane against 128, and 1.1 % SLOWER than the two phases).
+                constexpr int H0 = (L::NS + 1) / 2, H1 = L::NS - H0;
+                {
+                    double dw[NV];
+                    ldf<NV>(st, L::F_DW, dw);
+                    const double ddl = st[L::F_DDL];
+                    LOADS_ISSUED();
+#pragma unroll
+                    for (int j = 0; j < NV; j++)
+                        x0[j] = x0[j] + ((fm & (1u << j)) ? 0. : u.alpha * dw[j]);
+                    dl = dl + u.alpha * ddl;
+                }
+                ldPad<L::NS, P::NXV>(st, stz, L::F_S, sv);
+                {
+                    double d[H0];
+                    ldPadPart<P::NXV, 0, H0>(st, stz, L::F_DS, d);
+                    LOADS_ISSUED();
+#pragma unroll
+                    for (int i = 0; i < H0; i++)
+                        sv[i] = sv[i] + u.alpha * d[i];
+                }
+                {
+                    double d[H1];
+                    ldPadPart<P::NXV, H0, H1>(st, stz, L::F_DS, d);
+                    LOADS_ISSUED();
+#pragma unroll
+                    for (int i = 0; i < H1; i++)
+                        sv[H0 + i] = sv[H0 + i] + u.alpha * d[i];
+                }
+                ldPad<L::NS, P::NXV>(st, stz, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
+                stf<NV>(st, L::F_W, x0);
+                st[L::F_DL] = dl;
+                stPad<L::NS, P::NXV>(st, stz, L::F_S, sv);
+            }
+            else
+            {
+                ldPad<L::NS, P::NXV>(st, stz, L::F_S, sv);
+                LOADS_ISSUED();
+            }
             saff<P>(ip, v.act, x0, dl, wbar, uh, sa);
 #pragma unroll
             for (int i = 0; i < L::NS; i++)
@@ -1359,10 +1521,34 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 p.rz += sa[i] * sa[i];
                 p.ss += sv[i] * sv[i];
             }
-            double zv[L::NS];
-            ldPad<L::NS, P::NXV>(st, stz, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
-            LOADS_ISSUED();
-            stPad<L::NS, P::NXV>(st, stz, L::F_RZ, sa);
+            if constexpr (UPD)
+            {
+                constexpr int H0 = (L::NS + 1) / 2, H1 = L::NS - H0;
+                stPad<L::NS, P::NXV>(st, stz, L::F_RZ, sa);
+                {
+                    double d[H0];
+                    ldPadPart<P::NXV, 0, H0>(st, stz, L::F_DZ, d);
+                    LOADS_ISSUED();
+#pragma unroll
+                    for (int i = 0; i < H0; i++)
+                        zv[i] = zv[i] + u.alpha * d[i];
+                }
+                {
+                    double d[H1];
+                    ldPadPart<P::NXV, H0, H1>(st, stz, L::F_DZ, d);
+                    LOADS_ISSUED();
+#pragma unroll
+                    for (int i = 0; i < H1; i++)
+                        zv[H0 + i] = zv[H0 + i] + u.alpha * d[i];
+                }
+                stPad<L::NS, P::NXV>(st, stz, L::F_Z, zv);
+            }
+            else
+            {
+                ldPad<L::NS, P::NXV>(st, stz, L::F_Z, zv); // requested ahead of the stores below (a load behind a store waits for it)
+                LOADS_ISSUED();
+                stPad<L::NS, P::NXV>(st, stz, L::F_RZ, sa);
+            }
 #pragma unroll
             for (int i = 0; i < L::NS; i++)
             {
@@ -1371,6 +1557,19 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             }
             LTmul<P>(ip, fm, zv, uh, gw, &gdl);
         }
+    }
+    if constexpr (UPD)
+    {
+        // the neighbours' new W (stN below) and lambda (LDS) were written by other lanes of this wavefront a moment ago: a function boundary stood
+        // between the two phases (s_waitcnt vmcnt(0) is part of the call ABI); here the wait is explicit (outside the lane-dependent branches: the
+        // emulator's lanes are fibers that meet at synchronisation points)
+#ifndef SCPP_HIP_EMU
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        WAVE_SYNC();
+    }
+    if (v.vst)
+    {
         const double rxd = (ip[IP_SCVX] != 0.) ? 0. : it_wtrx - gdl; // SCvx: delta_k is not a variable
         // r = -L'z + M_k' lam_k + N_{k-1}' lam_{k-1}   and   res = x_{k+1} - A x_k - B u_k - C u_{k+1} - S sigma - nu - Z
         // in ONE pass over the field-major copy of (A,B,C): the loads of a row are issued together
@@ -1488,24 +1687,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     // Test support (emulator build only): SCPP_EMU_INJECT_RES="n:pres:dres:gap" replaces the termination quantities of the n-th residual evaluation of
     // every instance of the process (counted per lane: the lanes of the emulated wavefront are fibers of one host thread) -- a numerically broken
     // iterate on demand, for the regression tests of the breakdown rules (IPM_BLOWN, IPM_NEG_GAP).
-    {
-        static int calls[LANES];
-        static int inj_n = -2;
-        static double inj_v[3];
-        if (inj_n == -2)
-        {
-            const char *e = getenv("SCPP_EMU_INJECT_RES");
-            inj_n = -1;
-            if (e && sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
-                inj_n = -1;
-        }
-        if (inj_n >= 0 && calls[c.lane & (LANES - 1)]++ == inj_n)
-        {
-            it.pres = inj_v[0];
-            it.dres = inj_v[1];
-            it.gap = inj_v[2];
-        }
-    }
+    emuInjectResiduals(c.lane, it.pres, it.dres, it.gap);
 #endif
     {
         // keep the iterate if it already meets ECOS's reduced tolerances (returned if the path breaks down later)
@@ -2366,12 +2548,14 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     }
     PROF_T(tp0);
     int warm = (a.warm && a.warm[inst] != 0) ? 1 : 0;
+    // a re-solve on unchanged data (only where the previous solve of this workspace ran to its end on them: it is warm-startable)
+    const int dd_same = (a.dd_fresh && a.dd_fresh[inst] == 0 && warm) ? 1 : 0;
     int status = -1, iter = 0, iter_total = 0;
     bool use_backup = false;
     // a warm start that breaks down is repeated from ECOS's cold initialisation (attempt 1)
     for (int attempt = 0; attempt < 2; attempt++)
     {
-    phSetup<P>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
+    phSetup<P>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm, dd_same);
     if (warm)
     {
         // sub-problems of consecutive SC iterations are close: restart from the previous primal-dual point
@@ -2395,7 +2579,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
         }
         phInitDualFinish<P>(cs, gp, itp);
     }
-    phDataNorms<P>(cs, gp, itp);
+    phDataNorms<P>(cs, gp, itp, dd_same);
     phSegLdsCopy<P, true>(cs);
     PROF_T(tp1);
     PROF_ADD(0, tp0, tp1);
@@ -2410,7 +2594,11 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     for (iter = 0;; iter++)
     {
         PROF_T(tr0);
-        phResiduals<P>(cs, gp, itp);
+        // (the step of the previous iteration is applied on the way into this pass: phResiduals<P, true>)
+        if (iter == 0)
+            phResiduals<P, false>(cs, gp, itp);
+        else
+            phResiduals<P, true>(cs, gp, itp);
         PROF_T(tr1);
         PROF_ADD(1, tr0, tr1);
         {
@@ -2504,10 +2692,9 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
             status = inacc_ok ? 0 : -2;
             break;
         }
-        PROF_T(tu0);
-        phUpdate<P>(cs, gp, itp);
-        PROF_T(tu1);
-        PROF_ADD(7, tu0, tu1);
+#if !IPM_FUSE_UPDATE
+#error "the step is applied by the next phResiduals<P, true>"
+#endif
     }
 
     phSegLdsCopy<P, false>(cs);

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         if (pc == PC_START)
         {
             // (ipm_kernel: top of the attempt loop)
-            phSetup<W>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm);
+            phSetup<W>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm, 0);
             if (warm)
             {
                 phWarmInit<W>(cs, gp, itp);
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         }
         else if (pc == PC_NORMS)
         {
-            phDataNorms<W>(cs, gp, itp);
+            phDataNorms<W>(cs, gp, itp, 0);
             status = -1;
             iter = 0;
             use_backup = false;
@@ -273,7 +273,10 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         }
         else if (pc == PC_HEAD)
         {
-            phResiduals<W>(cs, gp, itp);
+            if (iter == 0)
+                phResiduals<W, false>(cs, gp, itp);
+            else
+                phResiduals<W, true>(cs, gp, itp); // applies the step of the previous iteration on its way in (ipm_solve.h)
             {
                 const double pres = it.pres, dres = it.dres, gap = it.gap;
                 const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
@@ -338,8 +341,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
                 pc = PC_END;
                 continue;
             }
-            phUpdate<W>(cs, gp, itp);
-            iter++;
+            iter++; // (the step is applied by the next residual pass: phResiduals<W, true>)
             pc = PC_HEAD;
         }
         else // PC_END: the attempt has ended

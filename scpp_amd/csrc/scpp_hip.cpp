@@ -380,6 +380,7 @@ ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r,
     a.max_sc_iterations = c->sc.max_iterations;
     a.warm = c->ipm_warm + f;
     a.do_sc_update = do_sc_update;
+    a.dd_fresh = (snapshot && c->ipm_schedule == SCPP_IPM_RESIDENT) ? c->vx_needs_disc + f : nullptr; // SCvx rounds: needs_disc == 0 <=> a re-solve on the old dd
     a.Xold = snapshot ? c->vx_Xold + f * K * nx : nullptr;
     a.Uold = snapshot ? c->vx_Uold + f * K * nu : nullptr;
     a.opt.feastol = c->socp.feastol;

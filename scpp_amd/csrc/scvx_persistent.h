@@ -173,6 +173,8 @@ PERSIST_STEP_FN void persistSolve(long slot)
     PERSIST_ARGS(T, A);
     const ipm::KernelArgs a = argCopy(A.a);
     ipm::ipmSolveInstance<P>(a, int(slot), &A.a);
+    if (IPM_PRIO_LANE)
+        SET_PRIO(0); // the integration and the cost step run at the default priority
     stepFence();
 }
 template <class T, class Model>

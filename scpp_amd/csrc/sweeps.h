@@ -583,7 +583,7 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
     const int lane = c.lane, K = c.K;
     const int g = lane >> 4, i = lane & 15;
     const bool scvx = c.ip[IP_SCVX] != 0.;
-    if (IPM_PRIO_FACTOR)
+    if (IPM_PRIO_FACTOR != IPM_PRIO_LANE)
         SET_PRIO(IPM_PRIO_FACTOR);
     // static dual regularisation of the multiplier block, SCvx only (oracle/structured_ipm.hpp: dualReg): there the
     // virtual control really vanishes (E^-1 -> 0) and Theta_0 = E^-1 + Y Y' with rank(M_0) = 3 would turn singular
@@ -788,8 +788,8 @@ SWEEP_FN void factorSweepFused(const LDSP Ctx *cin, TileShared &sh, const RhsSpe
         sh.prof[3] += 1.;
     }
 #endif
-    if (IPM_PRIO_FACTOR)
-        SET_PRIO(0);
+    if (IPM_PRIO_FACTOR != IPM_PRIO_LANE)
+        SET_PRIO(IPM_PRIO_LANE);
     WAVE_SYNC();
 }
 
@@ -1015,7 +1015,7 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    if (IPM_PRIO_SUBST)
+    if (IPM_PRIO_SUBST != IPM_PRIO_LANE)
         SET_PRIO(IPM_PRIO_SUBST);
     const Off4 oLit = offTriT<NV>(lane, L::FAC_LI), oYt = offYt<NL>(lane, L::FAC_YT), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oN = offN<P>(lane);
@@ -1077,8 +1077,8 @@ SWEEP_FN void fwdSweepV(const LDSP Ctx *cin)
         if (!stage(k + 2, b2))
             break;
     }
-    if (IPM_PRIO_SUBST)
-        SET_PRIO(0);
+    if (IPM_PRIO_SUBST != IPM_PRIO_LANE)
+        SET_PRIO(IPM_PRIO_LANE);
     WAVE_SYNC();
 }
 
@@ -1097,7 +1097,7 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
     const Ctx c = uniformCtx(cin);
     const int lane = c.lane, K = c.K;
     const SweepIO<P> io(c);
-    if (IPM_PRIO_SUBST)
+    if (IPM_PRIO_SUBST != IPM_PRIO_LANE)
         SET_PRIO(IPM_PRIO_SUBST);
     const Off4 oLi = offTri<NV>(lane, L::FAC_LI), oNt = offNt<P>(lane), oTit = offTriT<NL>(lane, L::FAC_TI), oTi = offTri<NL>(lane, L::FAC_TI),
                oY = offYtT<NL>(lane, L::FAC_YT);
@@ -1163,8 +1163,8 @@ SWEEP_FN void bwdSweepV(const LDSP Ctx *cin)
         LOADS_ISSUED();
         stage(k - 2, b2);
     }
-    if (IPM_PRIO_SUBST)
-        SET_PRIO(0);
+    if (IPM_PRIO_SUBST != IPM_PRIO_LANE)
+        SET_PRIO(IPM_PRIO_LANE);
     WAVE_SYNC();
 }
 #ifndef SWEEPS_VECTOR
