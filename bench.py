@@ -238,6 +238,9 @@ def main():
                          "all_gather_into_tensor, in chunks) inside the timed region even with ONE rank: a world-1 process group "
                          "of --backend is created, so a 1-GPU box executes the RCCL branch")
     ap.add_argument("--gather-chunk-mb", type=float, default=64.0, help="largest per-rank payload of one all-gather (MB)")
+    ap.add_argument("--placement-candidates", type=int, default=None,
+                    help="contexts allocated side by side, a short probe job on each, the best one kept (SCvxAlgorithm.initialize; DESIGN.md 5: the placement "
+                         "regimes; measured in round 6: no gain on a box whose first allocation is already in the fast regime, profiles/r06_placement_regimes.json).  Default 1 = off.  Outside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (SC mode, single batch, single pool, MPC)")
     ap.add_argument("--mpc-batch", type=int, default=32768)
@@ -279,8 +282,9 @@ def main():
 
     B, K = args.batch, args.K
     model = scpp_amd.RocketQuat().loadParameters()
+    n_place = args.placement_candidates if args.placement_candidates is not None else 1
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, device=dev_index, library=args.library,
-                                 max_iterations=args.max_iterations).initialize()
+                                 max_iterations=args.max_iterations).initialize(placement_candidates=n_place)
     ctx = alg.ctx
     rowd = K * 18 + len(ctx.STREAM_SCALARS)
 
@@ -684,6 +688,10 @@ def main():
                 "rounds": rounds,
                 "stream_profile_ticks": stream_profile,
                 "parity": parity_summary(),
+                "placement": ({"what": "SCvxAlgorithm.initialize(placement_candidates): candidate contexts allocated side by side, a short warm streaming job on "
+                                       "each, the fastest kept, before the warm-up and outside the timed region (DESIGN.md 5: one library is 2.5 - 3.6 % faster or "
+                                       "slower by where the driver placed a context's allocations)", **alg.placement} if getattr(alg, "placement", None) else
+                              {"candidates": 1}),
                 **extras,
             },
             "roofline": {

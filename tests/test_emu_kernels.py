@@ -770,3 +770,22 @@ def test_emu_scvx_recorded_iterates_equal_capped_reruns(model, emu_lib):
         plain.ctx.scvx_iterates(maxit + 1)
     with pytest.raises(RuntimeError):
         plain.getAllSolutions()
+
+
+def test_emu_placement_selection_keeps_one_context_and_the_results(model, emu_lib):
+    """SCvxAlgorithm.initialize(placement_candidates=n): n contexts side by side, a probe job on each, one kept (the placement regimes).
+    The selection must not leak into results: the kept context solves a job bitwise like a context that never ran a probe."""
+    K, B = 8, 2
+    x0 = model.randomized_initial_states(3, first=5)
+    plain = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=4).initialize()
+    n0 = plain.solveStream(x0, slots=B)
+    ref = plain.getStreamSolution()
+    plain.ctx.close()
+    sel = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=B, library=emu_lib, max_iterations=4).initialize(placement_candidates=2, probe_instances=2)
+    assert sel.placement["candidates"] == 2 and 0 <= sel.placement["chosen"] < 2 and len(sel.placement["trajectories_per_s_of_the_probes"]) == 2
+    n1 = sel.solveStream(x0, slots=B)
+    got = sel.getStreamSolution()
+    assert n0 == n1
+    for key in ("X", "U", "sigma", "sc_iters", "solves", "ipm_iters", "status", "converged"):
+        assert np.array_equal(ref[key], got[key]), key
+    sel.ctx.close()

@@ -12,6 +12,16 @@ m = scpp_amd.RocketQuat().loadParameters()
 x = m.randomized_initial_states(2 * B, seed=20260927, first=0)
 algs = [scpp_amd.SCvxAlgorithm(m, K=50, batch_max=B, device=0).initialize() for _ in range(N)]
 algs[0].solveStream(x[:1024], slots=1024)
+probe = {}
+for i, a in enumerate(algs):  # does a SHORT warm probe predict the ranking of the long jobs?  (what a placement selection would run)
+    ts = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        nc = a.solveStream(x[:4096], slots=B)
+        a.ctx.stream_download()
+        ts.append(nc / (time.perf_counter() - t0))
+    probe[i] = ts
+    print("probe context %d  %s converged/s (4096 instances, three times)" % (i, ["%.0f" % t for t in ts]), flush=True)
 rows = []
 for r in range(R):
     for i, a in enumerate(algs):
@@ -23,6 +33,6 @@ for r in range(R):
         rows.append({"round": r, "context": i, "converged_per_s": nc / dt})
         print("round %d context %d  %.1f converged/s" % (r, i, nc / dt), flush=True)
 per = {i: [q["converged_per_s"] for q in rows if q["context"] == i] for i in range(N)}
-print(json.dumps({"what": "N contexts alive at once, same job on each in turn", "slots": B, "per_context": per,
+print(json.dumps({"what": "N contexts alive at once, same job on each in turn", "slots": B, "per_context": per, "probe_4096": probe,
                   "spread_between_contexts": max(np.mean(v) for v in per.values()) / min(np.mean(v) for v in per.values()) - 1.,
                   "largest_spread_within_a_context": max(max(v) / min(v) - 1. for v in per.values())}))
