@@ -86,14 +86,16 @@ extern "C"
         double x_final[14];
         double final_time;
         int exact_minimum_thrust;
-        /* must be 0.  PERMANENTLY outside this engine's tile design (decided in round 4, after three rounds of carrying it): with roll
+        /* must be 0.  Outside this engine's tile design (round 4; round 6 wrote down the bordered-stage design that would carry it, DESIGN.md section 8,
+           and did not build it): with roll
            control (rocketQuat.cpp:135-138) state 13 (omega_z) and input 3 (tau_z) are free, a node then has 14 + 4 = 18 free variables,
            and every stage operation of the solver -- the Hessian block, its inverse Cholesky factor, the coupling products, the
            right-hand sides of the three substitution sweeps, the packed factor record -- is ONE 16 x 16 FP64 tile in the register layout of
            v_mfma_f64_16x16x4_f64 (csrc/tile_engine.h).  Neither extra variable can be presolved (tau_z drives omega_z, omega_z enters the
            quaternion rows of every segment), and eliminating tau_z by its own Schur complement couples the multipliers of segments k-1 and
            k directly, which breaks the block-tridiagonal order the sweeps rely on.  Two tiles per block would be a second solver (32-wide
-           eliminations, four products where there is one, a different record layout and lane algebra), not a variant of this one.
+           eliminations, four products where there is one, a different record layout and lane algebra); a rank-2 border per stage keeps the
+           16-wide tile and adds two skinny columns to every stage operation -- a second sweep set all the same.
            The shipped RocketQuat configuration has roll control off (model.info:203), as has every BASELINE configuration.
            scpp_hip_sc_setup / scpp_hip_scvx_setup / scpp_hip_scvx_solve_stream return SCPP_E_UNSUPPORTED for 1. */
         int enable_roll_control;

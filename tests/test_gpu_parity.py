@@ -738,6 +738,8 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
     import scvx_audit
 
     K, N, first = 50, 512, 300_000
+    # one-off larger audits on other instances (the driver's run is the default): SCPP_PARITY_N / SCPP_PARITY_FIRST; their summary goes to a file of its own
+    N, first = int(os.environ.get("SCPP_PARITY_N", N)), int(os.environ.get("SCPP_PARITY_FIRST", first))
     seed = 20260927
     x0 = model.randomized_initial_states(N, first=first)
     alg = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=N, library=hip_lib).initialize()
@@ -861,7 +863,9 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
         pass
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "r06_parity_at_scale.json"), "w"), indent=1)
+        summary["first_instance"] = first
+        name = "r06_parity_at_scale.json" if (N, first) == (512, 300_000) else "r06_parity_at_scale_N%d_first%d.json" % (N, first)
+        json.dump(summary, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
     except OSError:
         pass
     alg.ctx.close()
