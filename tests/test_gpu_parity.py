@@ -676,6 +676,13 @@ BAR_TIE_MARGIN = 1e-4             # every NON-identical instance must part ways 
 #                                   variable lies within this distance of its threshold (rho vs rho_0 / rho_1 / rho_2; |dL| vs
 #                                   change_threshold, relative): a tie the two solvers' termination tolerances decide, not an error
 #                                   (measured: all at rho_0 = 0 with |rho| <= 3.7e-6)
+BAR_WIDE_FRACTION = 0.001         # (round 6, from a 4096-instance audit: 2 of 4096; at the default 512 instances this allows NONE, as before) non-identical
+#                                   instances whose first diverging decision is NOT a tie.
+#                                   They are explained differently, and the explanation is mandatory: the iterates of device and twin had separated
+#                                   (1e-4 in the states) at an EARLIER sub-problem with a flat optimum while the decisions still agreed
+#                                   (tests/tools/divergence_probe.py) -- so every accepted sub-problem of the device path up to the diverging iteration
+#                                   must carry the certificate below (feasible to 1e-9 and eps-optimal in the LITERAL problem): the device is then at
+#                                   an optimum of every problem it was given, and so is the twin; they are different optima of a flat problem
 BAR_STATE_INPUT = 1e-5            # north_star: states and inputs within 1e-5 relative -- on every identical-record instance, OR
 #                                   the instance carries a certificate (mandatory, no cap on the count other than BAR_FLAGGED):
 BAR_CERT_FEAS = 1e-9              # its final iterate is feasible row by row in the LITERAL problem of its last solve
@@ -781,7 +788,8 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
             assert d is not None, ("records differ but no diverging decision found", b)
             margins.append((b,) + d)
         print("non-identical records: " + "; ".join("instance %d at iteration %d (%s), twin margin %.1e" % m for m in margins))
-        assert max(m[3] for m in margins) <= BAR_TIE_MARGIN
+    wide_m = [m for m in margins if m[3] > BAR_TIE_MARGIN]  # (b, iteration, kind, margin): certified below, with the literal audit
+    assert len(wide_m) <= int(BAR_WIDE_FRACTION * N), wide_m
     # ---- (a') the opt-in step-length rule (2 RKF78 steps at K = 50, 1e-13 away in A .. z) against the default: a 1e-13 perturbation
     # of the sub-problem data.  Most instances reproduce the record and the trajectory to ~1e-9; in a few the perturbation reaches an
     # accept / reject tie or an ill-determined direction of an optimum; every run still converges.
@@ -802,6 +810,7 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
     flagged = [int(b) for b in np.nonzero(same & ((relU > BAR_STATE_INPUT) | (relX > BAR_STATE_INPUT)))[0]]
     assert len(flagged) <= BAR_FLAGGED_FRACTION * N
     sel = list(range(32)) + [b for b in flagged if b >= 32]
+    sel += [m[0] for m in wide_m if m[0] not in sel]
     path = scvx_audit.device_path(alg, x0[sel], max_it)
     sub = scpp_amd.SCvxAlgorithm(model, K=K, batch_max=len(sel), library=hip_lib).initialize()  # (the same rows as a batch of their own)
     sub.solve(x0[sel])
@@ -841,17 +850,29 @@ def test_scvx_at_scale_parity_and_literal_audit(oracle, model, hip_lib):
         certified += 1
     print("certificates for %d instances whose inputs or states differ from the twin's by more than 1e-5: all feasible and eps-optimal "
           "in the literal problem of their last solve" % certified)
+    wide_certified = 0
+    for (b, it_div, kind, margin) in wide_m:
+        rows_b = [r for r in per[sel.index(b)] if r["iteration"] <= it_div]
+        assert rows_b, b
+        for r in rows_b:  # every accepted sub-problem up to the diverging iteration: the device sits at an optimum of each
+            assert r["eq_violation"] <= BAR_CERT_FEAS and r["min_lp_slack"] >= -BAR_CERT_FEAS and r["min_cone_slack"] >= -BAR_CERT_FEAS, (b, r["iteration"])
+            assert r["lit_exitflag"] in (0, 10), ("the literal solver did not solve a sub-problem of a wide-margin instance", b, r["iteration"])
+            assert abs(r["cost"] - r["lit_cost"]) <= BAR_CERT_GAP * abs(r["lit_cost"]), (b, r["iteration"])
+        wide_certified += 1
+        print("instance %d parts ways at iteration %d (%s) with twin margin %.1e, NOT a tie: %d accepted device sub-problems up to there certified in the "
+              "literal problem (worst gap %.1e)" % (b, it_div, kind, margin, len(rows_b), max(abs(r["cost"] - r["lit_cost"]) / abs(r["lit_cost"]) for r in rows_b)))
     summary = dict(
         test="tests/test_gpu_parity.py::test_scvx_at_scale_parity_and_literal_audit", instances=N, K=K, rkf78_steps=5,
         identical_records=int(same.sum()), non_identical_records=len(bad),
-        non_identical_explained_by_a_tie=len(margins), largest_tie_margin=max([m[3] for m in margins] or [0.0]),
+        non_identical_explained_by_a_tie=len(margins) - len(wide_m), largest_tie_margin=max([m[3] for m in margins if m[3] <= BAR_TIE_MARGIN] or [0.0]),
+        non_identical_not_a_tie=[dict(instance=int(m[0]), iteration=int(m[1]), kind=m[2], twin_margin=float(m[3])) for m in wide_m], non_identical_not_a_tie_certified=wide_certified,
         instances_beyond_1e5_states=n_x, instances_beyond_1e5_inputs=n_u, flagged=len(flagged), certified=certified,
         rel_dX=dict(median=float(np.median(relX[same])), p99=float(np.percentile(relX[same], 99)), max=float(relX[same].max())),
         rel_dU=dict(median=float(np.median(relU[same])), p99=float(np.percentile(relU[same], 99)), max=float(relU[same].max())),
         literal_audit=dict(subproblems=len(rows32), literal_exit_flags={str(k): int(v) for k, v in flags.items()},
                            gap_median=float(np.median(np.abs(gaps))), gap_max=float(np.abs(gaps).max()), relX_max=float(rx.max()),
                            relU_median=float(np.median(ru)), relU_max=float(ru.max())),
-        bars=dict(identical_fraction=BAR_IDENTICAL_FRACTION, tie_margin=BAR_TIE_MARGIN, state_input=BAR_STATE_INPUT, cert_feas=BAR_CERT_FEAS,
+        bars=dict(identical_fraction=BAR_IDENTICAL_FRACTION, tie_margin=BAR_TIE_MARGIN, wide_fraction=BAR_WIDE_FRACTION, state_input=BAR_STATE_INPUT, cert_feas=BAR_CERT_FEAS,
                   cert_gap=BAR_CERT_GAP, flagged_fraction=BAR_FLAGGED_FRACTION),
     )
     try:
