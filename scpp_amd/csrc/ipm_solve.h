@@ -18,7 +18,10 @@ namespace ipm
 // handed inputs of 1e154 N to the next discretisation.  The sub-problems are nondimensional (costs 1e-2 .. 1e3; Rocket2D in SI units: 1e5, gaps up to
 // 1e9 at the cold start): 1e30 is never a value of a working iterate.
 #define IPM_BLOWN 1e30
-#define IPM_FUSE_UPDATE 1 // the step x += alpha dx is applied by the NEXT residual pass on its way in (phResiduals<P, true>; round 6)
+#ifndef IPM_FUSE_UPDATE
+#define IPM_FUSE_UPDATE 1 // the step x += alpha dx is applied by the NEXT residual pass on its way in (phResiduals<P, true>; round 6).  0: the two phases of
+                          // rounds 1 - 5 (phUpdate, then phResiduals<P, false>) -- bitwise the same results (tests/tools/lib_equal.py on the GPU), 0.8 % slower
+#endif
 // A complementarity gap below -IPM_NEG_GAP is not a rounding artefact of an interior point (s and z inside the cone give s'z > 0): the iterate has left
 // the cone.  Round 6: until then a negative gap counted as broken only once a fall-back iterate existed; without one, `gap < abstol`
 // held trivially and a point with pres, dres below the tolerances and a gap of -1e29 returned status 0.  The magnitude test is two-sided now and a
@@ -2595,10 +2598,14 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     {
         PROF_T(tr0);
         // (the step of the previous iteration is applied on the way into this pass: phResiduals<P, true>)
+#if IPM_FUSE_UPDATE
         if (iter == 0)
             phResiduals<P, false>(cs, gp, itp);
         else
             phResiduals<P, true>(cs, gp, itp);
+#else
+        phResiduals<P, false>(cs, gp, itp);
+#endif
         PROF_T(tr1);
         PROF_ADD(1, tr0, tr1);
         {
@@ -2693,7 +2700,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
             break;
         }
 #if !IPM_FUSE_UPDATE
-#error "the step is applied by the next phResiduals<P, true>"
+        phUpdate<P>(cs, gp, itp);
 #endif
     }
 

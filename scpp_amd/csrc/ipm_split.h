@@ -273,10 +273,14 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         }
         else if (pc == PC_HEAD)
         {
+#if IPM_FUSE_UPDATE
             if (iter == 0)
                 phResiduals<W, false>(cs, gp, itp);
             else
                 phResiduals<W, true>(cs, gp, itp); // applies the step of the previous iteration on its way in (ipm_solve.h)
+#else
+            phResiduals<W, false>(cs, gp, itp);
+#endif
             {
                 const double pres = it.pres, dres = it.dres, gap = it.gap;
                 const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
@@ -341,7 +345,10 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
                 pc = PC_END;
                 continue;
             }
-            iter++; // (the step is applied by the next residual pass: phResiduals<W, true>)
+#if !IPM_FUSE_UPDATE
+            phUpdate<W>(cs, gp, itp);
+#endif
+            iter++; // (IPM_FUSE_UPDATE: the step is applied by the next residual pass, phResiduals<W, true>)
             pc = PC_HEAD;
         }
         else // PC_END: the attempt has ended
