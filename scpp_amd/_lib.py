@@ -420,16 +420,25 @@ class Context:
     def socp_solve(self):
         _chk(self.lib.scpp_hip_socp_solve(self.h), "socp_solve")
 
-    def download(self):
+    _DOWNLOAD_FIELDS = ("X", "U", "sigma", "sc_iters", "nu_norm", "converged", "status", "ipm_iters", "sum_delta")
+
+    def download(self, fields=None, out=None):
+        """Results of the batch (scpp_hip_download).  `fields`: the subset to copy (default: everything) -- the entry point skips a NULL
+        destination, and a receding-horizon driver that needs U, sigma and status only does not have to move 23 MB of states per step
+        (SC_sim at size: 4096 x 50 x 14 doubles).  `out`: a dict returned by an earlier call with the same batch size, reused instead of
+        allocating (fresh pages cost more than the copy)."""
         B, K = self.B, self.K
-        out = dict(
-            X=np.zeros((B, K, self.nx)), U=np.zeros((B, K, self.nu)), sigma=np.zeros(B), sc_iters=np.zeros(B, dtype=np.int32),
-            nu_norm=np.zeros(B), converged=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32),
-            ipm_iters=np.zeros(B, dtype=np.int32), sum_delta=np.zeros(B),
-        )
-        _chk(self.lib.scpp_hip_download(self.h, _p(out["X"]), _p(out["U"]), _p(out["sigma"]), _p(out["sc_iters"]), _p(out["nu_norm"]),
-                                        _p(out["converged"]), _p(out["status"]), _p(out["ipm_iters"]), _p(out["sum_delta"])), "download")
-        return out
+        fields = self._DOWNLOAD_FIELDS if fields is None else tuple(fields)
+        shapes = dict(X=((B, K, self.nx), np.float64), U=((B, K, self.nu), np.float64), sigma=((B,), np.float64), sc_iters=((B,), np.int32),
+                      nu_norm=((B,), np.float64), converged=((B,), np.int32), status=((B,), np.int32), ipm_iters=((B,), np.int32),
+                      sum_delta=((B,), np.float64))
+        res = {}
+        for f in fields:
+            shp, dt = shapes[f]
+            a = out.get(f) if out is not None else None
+            res[f] = a if (a is not None and a.shape == shp and a.dtype == dt and a.flags.c_contiguous) else np.zeros(shp, dtype=dt)
+        _chk(self.lib.scpp_hip_download(self.h, *[_p(res.get(f)) for f in self._DOWNLOAD_FIELDS]), "download")
+        return res
 
     def socp_info(self):
         info = np.zeros((self.B, 32))

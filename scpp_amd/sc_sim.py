@@ -12,6 +12,8 @@ Per simulation step, exactly as the reference does for its single loop:
   stop when ||x - x_final|| < 0.02 or t < 0.25                SC_sim.cpp:57-62
 Loops that stopped (or whose sub-problem failed: the reference would terminate) are masked out of later solves.
 All numerical work runs in libscpp_hip.so (scpp_hip_sc_setup / sc_set_active / sc_solve / simulate)."""
+import time
+
 import numpy as np
 
 
@@ -49,29 +51,48 @@ class SCSim:
         # per-step records of the whole batch + the mask of the loops that took the step (round 6: until then every loop's record was appended in a
         # Python loop per step, 57 ms per step for 4096 loops -- 11 of the 86 s of BASELINE configs[3] at size)
         rec_ok, rec_x, rec_u, rec_t, rec_it = [], [], [], [], []
+        # what a step needs from the solve: the inputs, the planned time, the status and the iteration count -- not the 23 MB of planned states of
+        # 4096 loops; the destination arrays are reused from step to step (`host_profile` in the result says where the host's share of a step goes)
+        need = ("U", "sigma", "status", "sc_iters")
+        out = None
+        prof = dict(setup=0.0, solve=0.0, download=0.0, plant=0.0, bookkeeping=0.0)
+        clock = time.perf_counter
+        foh = bool(alg.opts.interpolate_input)
         for step in range(self.max_steps):
             if not active.any():
                 break
+            t0 = clock()
             ctx.sc_setup(model.p, alg.opts, x, warm_start=step > 0)
             ctx.sc_set_active(active)
+            t1 = clock()
             ctx.sc_solve()
-            out = ctx.download()
+            t2 = clock()
+            out = ctx.download(fields=need, out=out)
+            t3 = clock()
             ok = (active != 0) & (out["status"] == 0)
             failed |= (active != 0) & (out["status"] != 0)
-            u0 = out["U"][:, 0, :]
-            u1 = interpolated_input(out["U"], self.time_step, out["sigma"], bool(alg.opts.interpolate_input))
+            u0 = out["U"][:, 0, :].copy()
+            u1 = interpolated_input(out["U"], self.time_step, out["sigma"], foh)
+            t4 = clock()
             ctx.set_flow_params(par_dim)
             x_new = ctx.simulate(self.time_step, u0, u1, x)
+            t5 = clock()
             x = np.where(ok[:, None], x_new, x)
-            rec_ok.append(ok.copy())
+            rec_ok.append(ok)
             rec_x.append(x_new)
-            rec_u.append(u0.copy())
+            rec_u.append(u0)
             rec_t.append(out["sigma"].copy())
             rec_it.append(out["sc_iters"].copy())
             steps += ok
             end = ok & ((np.linalg.norm(x - x_final, axis=1) < 0.02) | (out["sigma"] < 0.25))
             reached |= end
             active = (ok & ~end).astype(np.int32)
+            t6 = clock()
+            prof["setup"] += t1 - t0
+            prof["solve"] += t2 - t1
+            prof["download"] += t3 - t2
+            prof["plant"] += t5 - t4
+            prof["bookkeeping"] += (t4 - t3) + (t6 - t5)
         n = len(rec_ok)
         OK = np.array(rec_ok).reshape(n, B)
         XS, US = np.array(rec_x).reshape(n, B, 14), np.array(rec_u).reshape(n, B, 4)
@@ -81,5 +102,5 @@ class SCSim:
             U_sim=[US[OK[:, b], b] for b in range(B)],
             t_plan=[TS[OK[:, b], b] for b in range(B)],
             sc_iters=[IT[OK[:, b], b] for b in range(B)],
-            steps=steps, reached_end=reached, solver_failed=failed, x=x,
+            steps=steps, reached_end=reached, solver_failed=failed, x=x, host_profile=prof,
         )

@@ -631,6 +631,7 @@ def test_sc_sim_monte_carlo_4096_loops_200_steps(oracle, model, hip_lib):
     print("SC_sim at size: %d loops x %d steps in %.1f s (%.0f warm-started solves + plant steps per second); final planned time %.1f .. %.1f s, "
           "final altitude %.0f .. %.0f m; two loops vs the oracle over %d steps: worst relative state deviation %.2e (oracle %.0f s)"
           % (B, steps, t_dev, B * steps / t_dev, tp_end.min(), tp_end.max(), alt_end.min(), alt_end.max(), n_oracle, worst, time.time() - t0))
+    print("SC_sim at size, the host's view of a step (s over the run): " + ", ".join("%s %.1f" % kv for kv in r["host_profile"].items()))
     assert worst <= 1e-5
     a.ctx.close()
 
