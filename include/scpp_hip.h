@@ -47,6 +47,7 @@ extern "C"
 
 #define SCPP_MODEL_ROCKETQUAT 0
 #define SCPP_MODEL_ROCKET2D 1
+#define SCPP_MODEL_LANDER3DOF 2 /* not a model of the reference: this repository's third model (csrc/model_lander3dof.h), added through the plugin registry */
 
 #define SCPP_MODE_FOH 1 /* interpolate_input   (discretizationData.hpp:56-59) */
 #define SCPP_MODE_VT 2  /* free_final_time     (discretizationData.hpp:62-65) */
@@ -113,6 +114,18 @@ extern "C"
         double final_time;
     } scpp_rocket2d_params;
 
+    /* Lander3dof (ABI revision 7, round 6): point mass with a thrust vector, states [m, r(3), v(3)], inputs T(3) -- a model the reference does
+       NOT have; what a user of the reference's SystemModel interface (systemModel.hpp:64-82) adds here for a model of their own: this struct,
+       the three *_lander3dof entry points below, a flow map, a constraint table and a plugin struct.  Angles in radians. */
+    typedef struct
+    {
+        int exact_minimum_thrust;
+        double g_I[3];
+        double alpha_m, T_min, T_max, pointing_max, gamma_gs;
+        double x_final[7];
+        double final_time;
+    } scpp_lander3dof_params;
+
     /* SC.info (SCAlgorithm.cpp:22-46) */
     typedef struct
     {
@@ -159,7 +172,7 @@ extern "C"
     /* Build-defined constants of THIS library, so that a binding never hard-codes them (ABI revision 5, round 5: the per-instance status
        SCPP_STATUS_REJECTION_CAP moved from -4 to -5 in revision 4 without a way to ask).  Returns SCPP_E_ARG for an unknown `what` or a NULL
        `value`.  Bindings compare SCPP_Q_ABI_REVISION with the header they were written against and refuse a different library. */
-#define SCPP_ABI_REVISION 6
+#define SCPP_ABI_REVISION 7
 #define SCPP_Q_ABI_REVISION 0          /* SCPP_ABI_REVISION of the build */
 #define SCPP_Q_STATUS_REJECTION_CAP 1  /* the per-instance status of an SCvx run retired in the reject loop */
 #define SCPP_Q_SCVX_SOLVE_CAP 2        /* sub-problem solves per configured SCvx iteration before that happens (csrc/scvx_kernels.h) */
@@ -209,6 +222,9 @@ extern "C"
        sub-problem is the same structured solver instantiated for Rocket2d's constraint table (csrc/constraint_table.h) */
     int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_sc_opts *opts,
                                    const double *x_init /* [B][6] dimensional */, int B, int warm_start);
+    /* the same for a Lander3dof context (SCPP_MODEL_LANDER3DOF; not a model of the reference, see scpp_lander3dof_params) */
+    int scpp_hip_sc_setup_lander3dof(scpp_hip_ctx *ctx, const scpp_lander3dof_params *model, const scpp_sc_opts *opts,
+                                     const double *x_init /* [B][7] dimensional */, int B, int warm_start);
     /* restrict the next sc_iterate / sc_solve to a subset (mask[i] != 0); call after sc_setup.  This is the batched
        form of SC_sim's per-closed-loop stop rule (scpp/src/SC_sim.cpp:57-62): finished loops are not solved again */
     int scpp_hip_sc_set_active(scpp_hip_ctx *ctx, const int32_t *mask /* [B] */, int B);
@@ -230,6 +246,8 @@ extern "C"
        Rocket2d's constraint table.  scvx_solve / download / scvx_download_state serve both models. */
     int scpp_hip_scvx_setup_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_scvx_opts *opts,
                                      const double *x_init /* [B][6] dimensional */, int B, int warm_start);
+    int scpp_hip_scvx_setup_lander3dof(scpp_hip_ctx *ctx, const scpp_lander3dof_params *model, const scpp_scvx_opts *opts,
+                                       const double *x_init /* [B][7] dimensional */, int B, int warm_start);
     int scpp_hip_scvx_solve(scpp_hip_ctx *ctx, int *n_converged);
     int scpp_hip_scvx_download_state(scpp_hip_ctx *ctx, double *trust_region, double *nonlinear_cost, int32_t *solves,
                                      double *last_decision /* [B][4] */);
@@ -267,6 +285,10 @@ extern "C"
     int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *ctx, const scpp_rocket2d_params *model, const scpp_scvx_opts *opts,
                                             const double *x_init /* [N][6] dimensional */, int N, int slots, int pools,
                                             int *n_converged);
+    /* Lander3dof: rows of K*10 + 10 float64 (X [K][7], U [K][3], then the same ten scalars) */
+    int scpp_hip_scvx_solve_stream_lander3dof(scpp_hip_ctx *ctx, const scpp_lander3dof_params *model, const scpp_scvx_opts *opts,
+                                              const double *x_init /* [N][7] dimensional */, int N, int slots, int pools,
+                                              int *n_converged);
     /* Engine of scpp_hip_scvx_solve_stream.  The result rows are bitwise the same with either (every instance's arithmetic is identical):
          SCPP_STREAM_POOLS       rounds of four launches per slot pool (refill, multipleShooting, sub-problem solve, cost + accept / reject);
          SCPP_STREAM_PERSISTENT  (default) ONE launch: a wavefront per slot takes instance after instance through the whole of

@@ -62,6 +62,7 @@ struct SCHandleBase
     virtual int solve(int warm) = 0;
     virtual SCAlgorithm<RocketQuat> *rq() { return nullptr; }
     virtual SCAlgorithm<Rocket2d> *r2() { return nullptr; }
+    virtual SCAlgorithm<Lander3dof> *l3() { return nullptr; }
 };
 
 template <class M>
@@ -81,17 +82,18 @@ struct SCHandle : SCHandleBase
         alg->solve(warm != 0);
         return alg->solver_failed ? -1 : 0;
     }
-    SCAlgorithm<RocketQuat> *rq() override;
-    SCAlgorithm<Rocket2d> *r2() override;
+    SCAlgorithm<RocketQuat> *rq() override { return pick<RocketQuat>(); }
+    SCAlgorithm<Rocket2d> *r2() override { return pick<Rocket2d>(); }
+    SCAlgorithm<Lander3dof> *l3() override { return pick<Lander3dof>(); }
+    template <class T>
+    SCAlgorithm<T> *pick()
+    {
+        if constexpr (std::is_same<T, M>::value)
+            return alg.get();
+        else
+            return nullptr;
+    }
 };
-template <>
-SCAlgorithm<RocketQuat> *SCHandle<RocketQuat>::rq() { return alg.get(); }
-template <>
-SCAlgorithm<Rocket2d> *SCHandle<RocketQuat>::r2() { return nullptr; }
-template <>
-SCAlgorithm<RocketQuat> *SCHandle<Rocket2d>::rq() { return nullptr; }
-template <>
-SCAlgorithm<Rocket2d> *SCHandle<Rocket2d>::r2() { return alg.get(); }
 
 template <class F>
 auto withAlg(void *h, F f)
@@ -99,6 +101,8 @@ auto withAlg(void *h, F f)
     SCHandleBase *b = static_cast<SCHandleBase *>(h);
     if (b->rq())
         return f(*b->rq());
+    if (b->l3())
+        return f(*b->l3());
     return f(*b->r2());
 }
 
@@ -115,6 +119,12 @@ int oracle_model_dims(int model, int *dims)
         dims[1] = RocketQuat::NU;
         dims[2] = RocketQuat::NP;
     }
+    else if (model == 2)
+    {
+        dims[0] = Lander3dof::NX;
+        dims[1] = Lander3dof::NU;
+        dims[2] = Lander3dof::NP;
+    }
     else
     {
         dims[0] = Rocket2d::NX;
@@ -126,7 +136,7 @@ int oracle_model_dims(int model, int *dims)
 
 int oracle_flow(int model, const double *x, const double *u, const double *par, double *f, double *A, double *B)
 {
-    return model == 0 ? flowImpl<RocketQuat>(x, u, par, f, A, B) : flowImpl<Rocket2d>(x, u, par, f, A, B);
+    return model == 0 ? flowImpl<RocketQuat>(x, u, par, f, A, B) : model == 2 ? flowImpl<Lander3dof>(x, u, par, f, A, B) : flowImpl<Rocket2d>(x, u, par, f, A, B);
 }
 
 int oracle_rkf78_tableau(double *c, double *a, double *b)
@@ -159,8 +169,9 @@ int oracle_rkf78_harmonic(double omega, double dt, int N, double *y)
 int oracle_discretize(int model, int K, int foh, int vt, const double *par, const double *X, const double *U, double t,
                       double *A, double *B, double *C, double *s, double *z)
 {
-    return model == 0 ? discretizeImpl<RocketQuat>(K, foh, vt, par, X, U, t, A, B, C, s, z)
-                      : discretizeImpl<Rocket2d>(K, foh, vt, par, X, U, t, A, B, C, s, z);
+    return model == 0   ? discretizeImpl<RocketQuat>(K, foh, vt, par, X, U, t, A, B, C, s, z)
+           : model == 2 ? discretizeImpl<Lander3dof>(K, foh, vt, par, X, U, t, A, B, C, s, z)
+                        : discretizeImpl<Rocket2d>(K, foh, vt, par, X, U, t, A, B, C, s, z);
 }
 
 int oracle_simulate(int model, const double *par, double dt, const double *u0, const double *u1, double *x)
@@ -169,6 +180,13 @@ int oracle_simulate(int model, const double *par, double dt, const double *u0, c
     {
         RocketQuat m;
         for (int i = 0; i < RocketQuat::NP; i++)
+            m.par[i] = par[i];
+        simulate(m, dt, u0, u1, x);
+    }
+    else if (model == 2)
+    {
+        Lander3dof m;
+        for (int i = 0; i < Lander3dof::NP; i++)
             m.par[i] = par[i];
         simulate(m, dt, u0, u1, x);
     }
@@ -255,6 +273,8 @@ void *oracle_sc_create(int model, const char *config_root, int K_override)
     {
         if (model == 0)
             return new SCHandle<RocketQuat>(config_root, K_override);
+        if (model == 2)
+            return new SCHandle<Lander3dof>(config_root, K_override);
         return new SCHandle<Rocket2d>(config_root, K_override);
     }
     catch (const std::exception &e)
@@ -535,6 +555,7 @@ struct SCvxHandleBase
     virtual ~SCvxHandleBase() {}
     virtual SCvxAlgorithm<RocketQuat> *rq() { return nullptr; }
     virtual SCvxAlgorithm<Rocket2d> *r2() { return nullptr; }
+    virtual SCvxAlgorithm<Lander3dof> *l3() { return nullptr; }
 };
 template <class M>
 struct SCvxHandleT : SCvxHandleBase
@@ -548,23 +569,26 @@ struct SCvxHandleT : SCvxHandleBase
         alg.reset(new SCvxAlgorithm<M>(&model, folder, K));
         alg->initialize();
     }
-    SCvxAlgorithm<RocketQuat> *rq() override;
-    SCvxAlgorithm<Rocket2d> *r2() override;
+    SCvxAlgorithm<RocketQuat> *rq() override { return pick<RocketQuat>(); }
+    SCvxAlgorithm<Rocket2d> *r2() override { return pick<Rocket2d>(); }
+    SCvxAlgorithm<Lander3dof> *l3() override { return pick<Lander3dof>(); }
+    template <class T>
+    SCvxAlgorithm<T> *pick()
+    {
+        if constexpr (std::is_same<T, M>::value)
+            return alg.get();
+        else
+            return nullptr;
+    }
 };
-template <>
-SCvxAlgorithm<RocketQuat> *SCvxHandleT<RocketQuat>::rq() { return alg.get(); }
-template <>
-SCvxAlgorithm<Rocket2d> *SCvxHandleT<RocketQuat>::r2() { return nullptr; }
-template <>
-SCvxAlgorithm<RocketQuat> *SCvxHandleT<Rocket2d>::rq() { return nullptr; }
-template <>
-SCvxAlgorithm<Rocket2d> *SCvxHandleT<Rocket2d>::r2() { return alg.get(); }
 template <class F>
 auto withScvx(void *h, F f)
 {
     SCvxHandleBase *b = static_cast<SCvxHandleBase *>(h);
     if (b->rq())
         return f(*b->rq());
+    if (b->l3())
+        return f(*b->l3());
     return f(*b->r2());
 }
 } // namespace
@@ -577,6 +601,8 @@ void *oracle_scvx_create_model(int model, const char *config_root, int K_overrid
     {
         if (model == 0)
             return static_cast<SCvxHandleBase *>(new SCvxHandleT<RocketQuat>(config_root, K_override));
+        if (model == 2)
+            return static_cast<SCvxHandleBase *>(new SCvxHandleT<Lander3dof>(config_root, K_override));
         return static_cast<SCvxHandleBase *>(new SCvxHandleT<Rocket2d>(config_root, K_override));
     }
     catch (const std::exception &e)

@@ -727,4 +727,215 @@ struct Rocket2d : ModelBase<Rocket2d, 6, 2, 6>
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Lander3dof: NOT a model of the reference -- the third model of this repository (csrc/model_lander3dof.h: a point-mass powered-descent
+// vehicle, RocketQuat without the attitude states), added in round 6 to exercise the model-plugin path end to end.  This is the checker's
+// restatement of it in the reference's own plugin shape (systemModel.hpp:64-82): flow map, parameters with nondimensionalize /
+// redimensionalize, getInitializedTrajectory, getNewModelParameters, addApplicationConstraints on the literal problem.
+struct Lander3dof : ModelBase<Lander3dof, 7, 3, 4>
+{
+    static constexpr int NX = 7, NU = 3, NP = 4;
+    static const char *modelName() { return "Lander3dof"; }
+
+    template <class T>
+    static void flow(const T *x, const T *u, const T *par, T *f)
+    {
+        const T m = x[0];
+        f[0] = -par[0] * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        f[1] = x[4];
+        f[2] = x[5];
+        f[3] = x[6];
+        f[4] = u[0] / m + par[1];
+        f[5] = u[1] / m + par[2];
+        f[6] = u[2] / m + par[3];
+    }
+
+    struct Parameters
+    {
+        bool exact_minimum_thrust = true;
+        double g_I[3];
+        double alpha_m, T_min, T_max, pointing_max, gamma_gs;
+        double x_init[7], x_final[7];
+        double final_time;
+        double m_scale = 1., r_scale = 1.;
+
+        void loadFromFile(const std::string &path)
+        {
+            ParameterServer param(path);
+            double I_sp, m_init, m_dry, r_init[3], v_init[3], r_final[3], v_final[3];
+            param.loadVector("g_I", g_I, 3);
+            param.loadScalar("m_init", m_init);
+            param.loadVector("r_init", r_init, 3);
+            param.loadVector("v_init", v_init, 3);
+            param.loadScalar("final_time", final_time);
+            param.loadScalar("m_dry", m_dry);
+            param.loadVector("r_final", r_final, 3);
+            param.loadVector("v_final", v_final, 3);
+            param.loadScalar("exact_minimum_thrust", exact_minimum_thrust);
+            param.loadScalar("I_sp", I_sp);
+            param.loadScalar("T_min", T_min);
+            param.loadScalar("T_max", T_max);
+            param.loadScalar("pointing_max", pointing_max);
+            param.loadScalar("gamma_gs", gamma_gs);
+            const double d2r = M_PI / 180.;
+            pointing_max *= d2r;
+            gamma_gs *= d2r;
+            alpha_m = 1. / (I_sp * std::fabs(g_I[2]));
+            x_init[0] = m_init;
+            x_final[0] = m_dry;
+            for (int i = 0; i < 3; i++)
+            {
+                x_init[1 + i] = r_init[i];
+                x_init[4 + i] = v_init[i];
+                x_final[1 + i] = r_final[i];
+                x_final[4 + i] = v_final[i];
+            }
+        }
+        void nondimensionalize()
+        {
+            m_scale = x_init[0];
+            r_scale = std::sqrt(x_init[1] * x_init[1] + x_init[2] * x_init[2] + x_init[3] * x_init[3]);
+            alpha_m *= r_scale;
+            for (int i = 0; i < 3; i++)
+                g_I[i] /= r_scale;
+            x_init[0] /= m_scale;
+            x_final[0] /= m_scale;
+            for (int i = 1; i < 7; i++)
+            {
+                x_init[i] /= r_scale;
+                x_final[i] /= r_scale;
+            }
+            T_min /= m_scale * r_scale;
+            T_max /= m_scale * r_scale;
+        }
+        void redimensionalize()
+        {
+            alpha_m /= r_scale;
+            for (int i = 0; i < 3; i++)
+                g_I[i] *= r_scale;
+            x_init[0] *= m_scale;
+            x_final[0] *= m_scale;
+            for (int i = 1; i < 7; i++)
+            {
+                x_init[i] *= r_scale;
+                x_final[i] *= r_scale;
+            }
+            T_min *= m_scale * r_scale;
+            T_max *= m_scale * r_scale;
+        }
+    } p;
+
+    struct DynamicParameters
+    {
+        double gs_const = 0., pointing_const = 0.;
+        std::vector<double> thrust_const; // [K][3]
+    } p_dyn;
+
+    void loadParameters(const std::string &folder) { p.loadFromFile(folder + "/model.info"); }
+    void nondimensionalize() { p.nondimensionalize(); }
+    void redimensionalize() { p.redimensionalize(); }
+
+    void getInitializedTrajectory(TrajectoryData &td) const
+    {
+        const int K = td.K;
+        for (int k = 0; k < K; k++)
+        {
+            const double alpha1 = double(K - k) / K, alpha2 = double(k) / K; // (the reference models' k / K interpolation)
+            for (int i = 0; i < NX; i++)
+                td.x(k)[i] = alpha1 * p.x_init[i] + alpha2 * p.x_final[i];
+        }
+        for (int k = 0; k < td.nU; k++)
+        {
+            td.u(k)[0] = 0.;
+            td.u(k)[1] = 0.;
+            td.u(k)[2] = (p.T_max + p.T_min) / 2.;
+        }
+        td.t = p.final_time;
+    }
+
+    void getNewModelParameters(const TrajectoryData &td)
+    {
+        par[0] = p.alpha_m;
+        for (int i = 0; i < 3; i++)
+            par[1 + i] = p.g_I[i];
+        p_dyn.gs_const = std::tan(p.gamma_gs);
+        p_dyn.pointing_const = std::tan(p.pointing_max);
+        if (p.exact_minimum_thrust)
+        {
+            p_dyn.thrust_const.assign(size_t(td.nU) * 3, 0.);
+            for (int k = 0; k < td.nU; k++)
+            {
+                const double *u = td.u(k);
+                const double z = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+                const double s = z > 0. ? 1. / std::sqrt(z) : 1.;
+                for (int i = 0; i < 3; i++)
+                    p_dyn.thrust_const[size_t(k) * 3 + i] = u[i] * s;
+            }
+        }
+    }
+
+    void nondimensionalizeTrajectory(TrajectoryData &td) const
+    {
+        for (int k = 0; k < td.K; k++)
+        {
+            td.x(k)[0] /= p.m_scale;
+            for (int i = 1; i < 7; i++)
+                td.x(k)[i] /= p.r_scale;
+        }
+        for (int k = 0; k < td.nU; k++)
+            for (int i = 0; i < 3; i++)
+                td.u(k)[i] /= p.m_scale * p.r_scale;
+    }
+    void redimensionalizeTrajectory(TrajectoryData &td) const
+    {
+        for (int k = 0; k < td.K; k++)
+        {
+            td.x(k)[0] *= p.m_scale;
+            for (int i = 1; i < 7; i++)
+                td.x(k)[i] *= p.r_scale;
+        }
+        for (int k = 0; k < td.nU; k++)
+            for (int i = 0; i < 3; i++)
+                td.u(k)[i] *= p.m_scale * p.r_scale;
+    }
+
+    template <class FX, class FU, class KeyFn>
+    void addApplicationConstraints(Socp &socp, int K, int nU, FX vX, FU vU, KeyFn key) const
+    {
+        // initial state; final position and velocity (the final mass is free)
+        for (int i = 0; i < NX; i++)
+            socp.addEq(Aff(-p.x_init[i]).add(vX(i, 0), 1.), key.stageEq(0));
+        for (int i = 1; i < 7; i++)
+            socp.addEq(Aff(-p.x_final[i]).add(vX(i, K - 1), 1.), key.stageEq(K - 1));
+        // the last input points straight up
+        for (int i : {0, 1})
+            socp.addEq(Aff().add(vU(i, nU - 1), 1.), key.stageEq(nU - 1));
+        // mass >= m_dry
+        for (int k = 0; k < K; k++)
+            socp.addGe0(Aff(-p.x_final[0]).add(vX(0, k), 1.), key.stageCone(k));
+        // glide slope || r_xy || <= tan(gamma_gs) r_z
+        for (int k = 0; k < K; k++)
+            socp.addSoc({Aff().add(vX(3, k), p_dyn.gs_const), Aff().add(vX(1, k), 1.), Aff().add(vX(2, k), 1.)}, key.stageCone(k));
+        // minimum thrust: linearised at the trajectory the solve started from, or T_z >= T_min
+        for (int k = 0; k < nU; k++)
+        {
+            if (p.exact_minimum_thrust)
+            {
+                Aff e(-p.T_min);
+                for (int i = 0; i < 3; i++)
+                    e.add(vU(i, k), p_dyn.thrust_const[size_t(k) * 3 + i]);
+                socp.addGe0(e, key.stageCone(k));
+            }
+            else
+                socp.addGe0(Aff(-p.T_min).add(vU(2, k), 1.), key.stageCone(k));
+        }
+        // maximum thrust || T || <= T_max
+        for (int k = 0; k < nU; k++)
+            socp.addSoc({Aff(p.T_max), Aff().add(vU(0, k), 1.), Aff().add(vU(1, k), 1.), Aff().add(vU(2, k), 1.)}, key.stageCone(k));
+        // thrust pointing || T_xy || <= tan(pointing_max) T_z
+        for (int k = 0; k < nU; k++)
+            socp.addSoc({Aff().add(vU(2, k), p_dyn.pointing_const), Aff().add(vU(0, k), 1.), Aff().add(vU(1, k), 1.)}, key.stageCone(k));
+    }
+};
+
 } // namespace oracle

@@ -5,6 +5,7 @@ for the multi-GPU gather).  All compute runs in hand-written HIP kernels inside 
 raises if that library is missing -- there is no CPU fallback.
 """
 from ._lib import (  # noqa: F401
+    MODEL_LANDER3DOF,
     MODEL_ROCKET2D,
     MODEL_ROCKETQUAT,
     MODE_FOH,
@@ -19,7 +20,7 @@ from ._lib import (  # noqa: F401
     load_library,
 )
 from .parameter_server import ParameterServer  # noqa: F401
-from .models import Rocket2D, RocketQuat, counter_uniform  # noqa: F401
+from .models import Lander3dof, Rocket2D, RocketQuat, counter_uniform  # noqa: F401
 from .sc_algorithm import SCAlgorithm, load_sc_opts  # noqa: F401
 from .sc_sim import SCSim, interpolated_input  # noqa: F401
 from .scvx_algorithm import SCvxAlgorithm, load_scvx_opts  # noqa: F401

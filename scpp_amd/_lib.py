@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-MODEL_ROCKETQUAT, MODEL_ROCKET2D = 0, 1
+MODEL_ROCKETQUAT, MODEL_ROCKET2D, MODEL_LANDER3DOF = 0, 1, 2
 MODE_FOH, MODE_VT = 1, 2
 IPM_RESIDENT, IPM_SPLIT, IPM_RESIDENT_WS = 0, 1, 2
 STREAM_POOLS, STREAM_PERSISTENT = 0, 1
@@ -12,7 +12,7 @@ STREAM_POOLS, STREAM_PERSISTENT = 0, 1
 E_ARG, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4
 # What this binding was written against.  load_library() asks the library for ITS values (scpp_hip_query) and refuses one that disagrees: the
 # status moved from -4 to -5 between two builds once, and a constant that is only written down on both sides is how that goes unnoticed.
-ABI_REVISION = 6
+ABI_REVISION = 7
 STATUS_REJECTION_CAP = -5
 SCVX_SOLVE_CAP = 64  # csrc/scvx_kernels.h: sub-problem solves per configured iteration before an instance is retired
 Q_ABI_REVISION, Q_STATUS_REJECTION_CAP, Q_SCVX_SOLVE_CAP, Q_MAX_K, Q_MPC_MAX_K = 0, 1, 2, 3, 4
@@ -54,6 +54,16 @@ class Rocket2dParams(C.Structure):
         ("T_min", C.c_double), ("T_max", C.c_double),
         ("gimbal_max", C.c_double), ("theta_max", C.c_double), ("gamma_gs", C.c_double), ("w_B_max", C.c_double),
         ("x_final", C.c_double * 6), ("final_time", C.c_double),
+    ]
+
+
+class Lander3dofParams(C.Structure):
+    """scpp_lander3dof_params (this repository's third model: csrc/model_lander3dof.h; not a model of the reference)."""
+
+    _fields_ = [
+        ("exact_minimum_thrust", C.c_int), ("g_I", C.c_double * 3),
+        ("alpha_m", C.c_double), ("T_min", C.c_double), ("T_max", C.c_double), ("pointing_max", C.c_double), ("gamma_gs", C.c_double),
+        ("x_final", C.c_double * 7), ("final_time", C.c_double),
     ]
 
 
@@ -133,6 +143,7 @@ SYMBOLS = [
     "scpp_hip_mpc_sim_download",
     "scpp_hip_scvx_solve_stream", "scpp_hip_stream_rows", "scpp_hip_stream_download", "scpp_hip_stream_info",
     "scpp_hip_scvx_setup_rocket2d", "scpp_hip_scvx_solve_stream_rocket2d",
+    "scpp_hip_sc_setup_lander3dof", "scpp_hip_scvx_setup_lander3dof", "scpp_hip_scvx_solve_stream_lander3dof",
     "scpp_hip_scvx_record_iterates", "scpp_hip_scvx_download_iterates",
 ]
 
@@ -176,6 +187,10 @@ def query(what, lib=None):
     return int(v.value)
 
 
+# suffix of a model's set-up / streaming entry points in the C ABI (include/scpp_hip.h)
+_MODEL_SUFFIX = {MODEL_ROCKETQUAT: "", MODEL_ROCKET2D: "_rocket2d", MODEL_LANDER3DOF: "_lander3dof"}
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -191,7 +206,7 @@ class Context:
     def __init__(self, model=MODEL_ROCKETQUAT, K=50, batch_max=256, device=0, library=None):
         self.lib = load_library(library)
         self.model, self.K, self.batch_max = model, K, batch_max
-        self.nx, self.nu, self.np_ = (14, 4, 10) if model == MODEL_ROCKETQUAT else (6, 2, 6)
+        self.nx, self.nu, self.np_ = {MODEL_ROCKETQUAT: (14, 4, 10), MODEL_ROCKET2D: (6, 2, 6), MODEL_LANDER3DOF: (7, 3, 4)}[model]
         h = C.c_void_p()
         _chk(self.lib.scpp_hip_create(C.byref(h), int(device), int(model), int(K), int(batch_max), C.c_uint(0)), "scpp_hip_create")
         self.h = h
@@ -274,7 +289,7 @@ class Context:
     def sc_setup(self, model_params, sc_opts, x_init, warm_start=False):
         x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         self.B = x_init.shape[0]
-        fn = self.lib.scpp_hip_sc_setup if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_sc_setup_rocket2d
+        fn = getattr(self.lib, "scpp_hip_sc_setup" + _MODEL_SUFFIX[self.model])
         _chk(fn(self.h, C.byref(model_params), C.byref(sc_opts), _p(x_init), int(self.B), int(warm_start)), "sc_setup")
 
     def sc_set_active(self, mask):
@@ -290,7 +305,7 @@ class Context:
     def scvx_setup(self, model_params, scvx_opts, x_init, warm_start=False):
         x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         self.B = x_init.shape[0]
-        fn = self.lib.scpp_hip_scvx_setup if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_scvx_setup_rocket2d
+        fn = getattr(self.lib, "scpp_hip_scvx_setup" + _MODEL_SUFFIX[self.model])
         _chk(fn(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(self.B), int(warm_start)), "scvx_setup")
 
     def scvx_solve(self):
@@ -327,7 +342,7 @@ class Context:
         x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(-1, self.nx)
         n = C.c_int(0)
         self._stream_N = x_init.shape[0]
-        fn = self.lib.scpp_hip_scvx_solve_stream if self.model == MODEL_ROCKETQUAT else self.lib.scpp_hip_scvx_solve_stream_rocket2d
+        fn = getattr(self.lib, "scpp_hip_scvx_solve_stream" + _MODEL_SUFFIX[self.model])
         _chk(fn(self.h, C.byref(model_params), C.byref(scvx_opts), _p(x_init), int(x_init.shape[0]), int(slots), int(pools), C.byref(n)),
              "scvx_solve_stream")
         return n.value

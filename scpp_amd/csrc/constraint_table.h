@@ -141,6 +141,32 @@ struct Rocket2dSC
     };
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// Lander3dof (csrc/model_lander3dof.h): NOT a model of the reference -- this repository's third model, written the way a user's
+// addApplicationConstraints would be (the RocketQuat rows without the attitude states).  w = (m, r_x, r_y, r_z, v_x, v_y, v_z, T_x, T_y, T_z).
+// ------------------------------------------------------------------------------------------------------------
+struct Lander3dofSC
+{
+    static constexpr int MODEL_ID = 2;
+    static constexpr int NX = 7, NU = 3, NXV = 7, NUV = 3;
+    static constexpr int XMAP[NXV] = {0, 1, 2, 3, 4, 5, 6};
+    static constexpr int UMAP[NUV] = {0, 1, 2};
+    // equalTo(X.col(0), x_init); equalTo(X(i, K-1), x_final(i)) for position and velocity (the final mass is free); equalTo(U({0,1}, K-1), 0)
+    static constexpr unsigned FIXED_FIRST = 0x7Fu;
+    static constexpr unsigned FIXED_LAST = (0x3Fu << 1) | (1u << 7) | (1u << 8);
+    static constexpr int NCONE = 3;
+    static constexpr Cone CONES[NCONE] = {
+        {3, {rowParVar(IP_GS, 3), rowVar(1), rowVar(2), {}}},       // glide slope      ||r_xy|| <= tan(gamma_gs) r_z
+        {4, {rowConst(IP_TMAX), rowVar(7), rowVar(8), rowVar(9)}},  // maximum thrust   ||T|| <= T_max
+        {3, {rowParVar(IP_GIM, 9), rowVar(7), rowVar(8), {}}},      // thrust pointing  ||T_xy|| <= tan(pointing_max) T_z
+    };
+    static constexpr int NLP = 2;
+    static constexpr Row LPS[NLP] = {
+        rowLower(0, IP_MDRY),                                                                         // mass >= m_dry
+        Row{IP_TMIN, -1., {Term{7, CF_UHAT0, 1.}, Term{8, CF_UHAT1, 1.}, Term{9, CF_UHAT2, 1.}}},    // uhat . T >= T_min (uhat = (0,0,1) without exact_minimum_thrust)
+    };
+};
+
 // Zero-order-hold variant of a table (SCProblem.cpp:37-59,116-120 with td.interpolatedInput() == false: K-1 inputs).  The stage
 // structure keeps an input slot at every node; at the LAST node the inputs do not exist -- they are pinned (to 0, which is
 // also what the device stores in U[K-1]) so that every cone / LP row on them drops out and the trust-region cone of that node

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -32,6 +33,28 @@ using namespace scpp;
         if (e_ != hipSuccess)            \
             return SCPP_E_HIP;           \
     } while (0)
+
+// ---- dispatch over the registered model plugins (csrc/sc_kernels.h: `Plugins` is the one list) ----
+template <class L>
+struct ParamsOf;
+template <class... PL>
+struct ParamsOf<PluginList<PL...>>
+{
+    using type = std::tuple<typename PL::Params...>;
+};
+// f(Plugin{}) for the plugin whose ID is `model`; SCPP_E_ARG for an id nobody registered
+template <class F, class... PL>
+int withPluginOf(PluginList<PL...>, int model, F &&f)
+{
+    int rc = SCPP_E_ARG;
+    (void)((model == PL::ID ? (rc = f(PL{}), true) : false) || ...);
+    return rc;
+}
+template <class F>
+int withPlugin(int model, F &&f)
+{
+    return withPluginOf(Plugins{}, model, std::forward<F>(f));
+}
 
 struct scpp_hip_ctx
 {
@@ -78,8 +101,8 @@ struct scpp_hip_ctx
     // simulate scratch
     double *sim_dt = nullptr, *sim_u0 = nullptr, *sim_u1 = nullptr, *sim_x = nullptr;
     scpp_sc_opts sc{};
-    scpp_rocketquat_params mp{};
-    scpp_rocket2d_params mp2{};
+    ParamsOf<Plugins>::type model_params{}; // the C-ABI parameter struct of every registered model (the context's own is the one in use)
+    size_t ws_per = 0;                      // doubles of interior-point workspace per instance (Lay<Table> of the context's model)
     scpp_socp_opts socp{1e-8, 1e-7, 1e-7, 60, 1};
     bool sc_ready = false, par_from_ip = false;
     bool sc_warm = false; // the last scpp_hip_sc_setup was a warm start
@@ -285,9 +308,7 @@ int launchDiscretize(scpp_hip_ctx *c, int mode, const double *par0, int stride, 
 
 int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst, Range r)
 {
-    if (c->model == SCPP_MODEL_ROCKETQUAT)
-        return launchDiscretize<RocketQuatModel>(c, mode, par, stride, active, ninst, r);
-    return launchDiscretize<Rocket2dModel>(c, mode, par, stride, active, ninst, r);
+    return withPlugin(c->model, [&](auto pl) { return launchDiscretize<typename decltype(pl)::Model>(c, mode, par, stride, active, ninst, r); });
 }
 int discretizeDispatch(scpp_hip_ctx *c, int mode, const double *par, int stride, const int *active, long long ninst)
 {
@@ -341,18 +362,16 @@ SCBuffers scBuffersRange(scpp_hip_ctx *c, Range r)
     return b;
 }
 
-// the solver table of the persistent kernel: its own type, so that its phase functions are instantiated for this kernel's register budget only
-struct PersistRocketQuat : ipm::RocketQuatSC
+// the parameter struct of plugin PL inside a context
+template <class PL>
+typename PL::Params &paramsOf(scpp_hip_ctx *c)
 {
-};
-struct PersistRocket2d : ipm::Rocket2dSC
-{
-};
+    return std::get<typename PL::Params>(c->model_params);
+}
 ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r, bool snapshot)
 {
     ipm::KernelArgs a;
     const size_t f = size_t(r.first), K = size_t(c->K), seg = K - 1, nx = size_t(c->nx), nu = size_t(c->nu);
-    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
     a.B = r.count;
     a.K = c->K;
     a.X = c->X + f * K * nx;
@@ -365,7 +384,7 @@ ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r,
     a.Z = c->Z + f * seg * nx;
     a.ip = c->ip + f * ipm::IP_N;
     a.uhat = c->uhat + f * K * 3;
-    a.ws = c->ws + f * (rq ? ipm::workspaceDoubles<ipm::RocketQuatSC>(c->K) : ipm::workspaceDoubles<ipm::Rocket2dSC>(c->K));
+    a.ws = c->ws + f * c->ws_per;
     a.wtrx = c->wtrx + f;
     a.active = (do_sc_update || masked) ? c->active + f : nullptr;
     a.converged = c->converged + f;
@@ -395,40 +414,49 @@ ipm::KernelArgs ipmArgs(scpp_hip_ctx *c, int do_sc_update, bool masked, Range r,
 int launchIpm(scpp_hip_ctx *c, int do_sc_update, long long ninst, bool masked, Range r, unsigned lds_pad = 0, bool snapshot = false)
 {
     const ipm::KernelArgs a = ipmArgs(c, do_sc_update, masked, r, snapshot);
-    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
     const bool timed = spanBegin(c, 1, ninst, r.stream);
     // lds_pad: dynamic LDS that is never touched -- it only limits how many ipm workgroups fit on a CU (pipelined loop)
-    // one instantiation of the solver per model table (csrc/constraint_table.h)
+    // one instantiation of the solver per model table (csrc/constraint_table.h) and input hold
     const bool zoh = !(c->mode & SCPP_MODE_FOH); // zero-order hold: the table's ZeroOrderHold variant (same record layout)
-    if (rq && !zoh && c->ipm_schedule == SCPP_IPM_SPLIT)
-    {
-        // split schedule (ipm_split.h): A(first) [F A] x pairs.  An instance asks for at most maxit factor sweeps per attempt plus one for the cold
-        // initialisation, and a warm attempt that breaks down is repeated cold: 2 maxit + 1 pairs cover every instance; one that has finished
-        // returns at the top of each later launch.
-        using W = ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>;
-        const int pairs = c->ipm_split_pairs > 0 ? c->ipm_split_pairs : 2 * a.opt.maxit + 1;
-        hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a, 1);
-        for (int i = 0; i < pairs; i++)
+    (void)withPlugin(c->model, [&](auto pl) {
+        using PL = decltype(pl);
+        using T = typename PL::Table;
+        const unsigned grid = unsigned(r.count);
+        if constexpr (PL::SPLIT_SCHEDULE)
         {
-            hipLaunchKernelGGL(ipm::ipm_factor_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a);
-            hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, a, 0);
-        }
-        // a truncated schedule (measurement hook) may leave instances waiting for a factor sweep: retire them as failures instead of reporting stale rows
-        if (pairs < 2 * a.opt.maxit + 1)
-            hipLaunchKernelGGL(ipm::ipm_split_finalize_kernel<ipm::RocketQuatSC>, dim3(unsigned((r.count + WAVE - 1) / WAVE)), dim3(WAVE), 0, r.stream, a);
-    }
+            if (!zoh && c->ipm_schedule == SCPP_IPM_SPLIT)
+            {
+                // split schedule (ipm_split.h): A(first) [F A] x pairs.  An instance asks for at most maxit factor sweeps per attempt plus one for the cold
+                // initialisation, and a warm attempt that breaks down is repeated cold: 2 maxit + 1 pairs cover every instance; one that has finished
+                // returns at the top of each later launch.
+                using W = ipm::SegFieldsInWorkspace<T>;
+                const int pairs = c->ipm_split_pairs > 0 ? c->ipm_split_pairs : 2 * a.opt.maxit + 1;
+                hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(grid), dim3(WAVE), 0, r.stream, a, 1);
+                for (int i = 0; i < pairs; i++)
+                {
+                    hipLaunchKernelGGL(ipm::ipm_factor_kernel<T>, dim3(grid), dim3(WAVE), 0, r.stream, a);
+                    hipLaunchKernelGGL(ipm::ipm_split_kernel<W>, dim3(grid), dim3(WAVE), 0, r.stream, a, 0);
+                }
+                // a truncated schedule (measurement hook) may leave instances waiting for a factor sweep: retire them as failures instead of reporting stale rows
+                if (pairs < 2 * a.opt.maxit + 1)
+                    hipLaunchKernelGGL(ipm::ipm_split_finalize_kernel<T>, dim3(unsigned((r.count + WAVE - 1) / WAVE)), dim3(WAVE), 0, r.stream, a);
+                return 0;
+            }
 #ifdef SCPP_HIP_EMU // (diagnostic of the layout policy; the device library does not carry a third instantiation of the solver for it)
-    else if (rq && !zoh && c->ipm_schedule == SCPP_IPM_RESIDENT_WS)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::SegFieldsInWorkspace<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad, r.stream, a);
+            if (!zoh && c->ipm_schedule == SCPP_IPM_RESIDENT_WS)
+            {
+                hipLaunchKernelGGL(ipm::ipm_kernel<ipm::SegFieldsInWorkspace<T>>, dim3(grid), dim3(WAVE), lds_pad, r.stream, a);
+                return 0;
+            }
 #endif
-    else if (rq && !zoh)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::RocketQuatSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
-    else if (rq)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::RocketQuatSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::RocketQuatSC>(c->K), r.stream, a);
-    else if (!zoh)
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::Rocket2dSC>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::Rocket2dSC>(c->K), r.stream, a);
-    else
-        hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<ipm::Rocket2dSC>>, dim3(unsigned(r.count)), dim3(WAVE), lds_pad + ipm::segLdsBytes<ipm::Rocket2dSC>(c->K), r.stream, a);
+        }
+        const unsigned lds = lds_pad + unsigned(ipm::segLdsBytes<T>(c->K));
+        if (!zoh)
+            hipLaunchKernelGGL(ipm::ipm_kernel<T>, dim3(grid), dim3(WAVE), lds, r.stream, a);
+        else
+            hipLaunchKernelGGL(ipm::ipm_kernel<ipm::ZeroOrderHold<T>>, dim3(grid), dim3(WAVE), lds, r.stream, a);
+        return 0;
+    });
     spanEnd(c, timed, r.stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
@@ -443,9 +471,7 @@ int ensureWorkspace(scpp_hip_ctx *c)
 {
     if (c->ws)
         return 0;
-    const size_t per = c->model == SCPP_MODEL_ROCKETQUAT ? ipm::workspaceDoubles<ipm::RocketQuatSC>(c->K)
-                                                          : ipm::workspaceDoubles<ipm::Rocket2dSC>(c->K);
-    return devAlloc(&c->ws, size_t(c->Bmax) * per) ? SCPP_E_HIP : 0;
+    return devAlloc(&c->ws, size_t(c->Bmax) * c->ws_per) ? SCPP_E_HIP : 0;
 }
 
 // ---- create-time self-test of the tile engine on the device the context is created on ----
@@ -572,7 +598,7 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
 {
     if (!out || K < 3 || K > WAVE || batch_max < 1)
         return SCPP_E_ARG;
-    if (model_id != SCPP_MODEL_ROCKETQUAT && model_id != SCPP_MODEL_ROCKET2D)
+    if (withPlugin(model_id, [](auto) { return 0; }) != 0) // a model nobody registered (csrc/sc_kernels.h: Plugins)
         return SCPP_E_ARG;
 #if !defined(SCPP_HIP_EMU) && !SCPP_TOOLCHAIN_VALIDATED
     {
@@ -617,18 +643,14 @@ int scpp_hip_create(scpp_hip_ctx **out, int device_id, int model_id, int K, int 
     if (const char *e = std::getenv("SCPP_IPM_SPLIT_PAIRS"))
         if (std::atoi(e) > 0)
             c->ipm_split_pairs = std::atoi(e);
-    if (model_id == SCPP_MODEL_ROCKETQUAT)
-    {
-        c->nx = RocketQuatModel::NX;
-        c->nu = RocketQuatModel::NU;
-        c->np = RocketQuatModel::NP;
-    }
-    else
-    {
-        c->nx = Rocket2dModel::NX;
-        c->nu = Rocket2dModel::NU;
-        c->np = Rocket2dModel::NP;
-    }
+    (void)withPlugin(model_id, [&](auto pl) {
+        using PL = decltype(pl);
+        c->nx = PL::Model::NX;
+        c->nu = PL::Model::NU;
+        c->np = PL::Model::NP;
+        c->ws_per = ipm::workspaceDoubles<typename PL::Table>(K);
+        return 0;
+    });
     if (hipStreamCreate(&c->stream) != hipSuccess)
     {
         delete c;
@@ -815,14 +837,11 @@ int scpp_hip_simulate(scpp_hip_ctx *c, const double *dt, const double *u0, const
     const double *par = c->par_from_ip ? c->ip + ipm::IP_PAR : c->par;
     const int stride = c->par_from_ip ? ipm::IP_N : c->np;
     const unsigned grid = unsigned((B + 63) / 64);
-    if (c->model == SCPP_MODEL_ROCKETQUAT)
-        hipLaunchKernelGGL((simulate_kernel<RocketQuatModel>), dim3(grid), dim3(64), 0, c->stream, B, par, stride,
-                           (const double *)c->sim_dt, (const double *)c->sim_u0, (const double *)c->sim_u1, c->sim_x,
-                           (const int *)nullptr);
-    else
-        hipLaunchKernelGGL((simulate_kernel<Rocket2dModel>), dim3(grid), dim3(64), 0, c->stream, B, par, stride,
-                           (const double *)c->sim_dt, (const double *)c->sim_u0, (const double *)c->sim_u1, c->sim_x,
-                           (const int *)nullptr);
+    (void)withPlugin(c->model, [&](auto pl) {
+        hipLaunchKernelGGL((simulate_kernel<typename decltype(pl)::Model>), dim3(grid), dim3(64), 0, c->stream, B, par, stride,
+                           (const double *)c->sim_dt, (const double *)c->sim_u0, (const double *)c->sim_u1, c->sim_x, (const int *)nullptr);
+        return 0;
+    });
     CHECK_HIP(hipMemcpyAsync(x, c->sim_x, size_t(B) * c->nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CHECK_HIP(hipStreamSynchronize(c->stream));
     return SCPP_OK;
@@ -875,77 +894,74 @@ int scpp_hip_set_socp_opts(scpp_hip_ctx *c, const scpp_socp_opts *o)
     return SCPP_OK;
 }
 
-int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_sc_opts *so, const double *x_init,
-                      int B, int warm_start)
+extern "C++"
+{
+namespace
+{
+// scpp_hip_sc_setup of every model (PL = its plugin): SCAlgorithm::initialize + the start of solve(warm_start) for B instances
+template <class PL>
+int scSetupT(scpp_hip_ctx *c, const typename PL::Params *mp, const scpp_sc_opts *so, const double *x_init, int B, int warm_start)
 {
     DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKETQUAT)
+    if (c->model != PL::ID)
         return SCPP_E_UNSUPPORTED;
-    /* roll control off (the configuration SC_oneshot / SC_sim run for RocketQuat); first-order or zero-order hold, free or fixed
-       final time (SCProblem.cpp:33-59,78-100,116-120) */
-    if (so->K != c->K || mp->enable_roll_control)
+    /* first-order or zero-order hold, free or fixed final time (SCProblem.cpp:33-59,78-100,116-120); what the plugin refuses (RocketQuat: roll
+       control on -- SC_oneshot / SC_sim run with it off) */
+    if (so->K != c->K || !PL::supported(*mp))
         return SCPP_E_UNSUPPORTED;
     if (warm_start && (!c->sc_ready || B != c->B))
         return SCPP_E_STATE;
     if (int rc = ensureWorkspace(c))
         return rc;
     c->B = B;
-    c->mp = *mp;
+    paramsOf<PL>(c) = *mp;
     c->sc = *so;
     c->mode = (so->interpolate_input ? SCPP_MODE_FOH : 0) | (so->free_final_time ? SCPP_MODE_VT : 0);
     if (!so->free_final_time) // fixed final time (SCProblem.cpp:33-35): dS/dsigma = 0, the discretisation does not write it
         CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
     if (!so->interpolate_input) // zero-order hold: no C in the dynamics (discretizationData.hpp:56-59)
         CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * size_t(c->nu) * sizeof(double), c->stream));
-    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 14 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * size_t(PL::NX) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (!warm_start || c->scvx_ready) // cold SC solve (or a context last used in SCvx mode): cold interior-point start
         CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
     c->scvx_ready = false;
     SCBuffers b = scBuffers(c);
-    hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp, c->sc, warm_start);
+    hipLaunchKernelGGL((sc_setup_kernel<PL>), dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, paramsOf<PL>(c), c->sc, warm_start);
     c->sc_ready = true;
     c->sc_warm = warm_start != 0;
     c->par_from_ip = true;
     c->last_active = B;
     return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
 }
+// redimensionalizeTrajectory of the batch, on the context's stream
+void launchRedim(scpp_hip_ctx *c)
+{
+    (void)withPlugin(c->model, [&](auto pl) {
+        hipLaunchKernelGGL((sc_redim_kernel<decltype(pl)>), dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
+        return 0;
+    });
+}
+} // namespace
+} // extern "C++"
+
+int scpp_hip_sc_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_sc_opts *so, const double *x_init,
+                      int B, int warm_start)
+{
+    return scSetupT<RocketQuatPlugin>(c, mp, so, x_init, B, warm_start);
+}
 
 int scpp_hip_sc_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_sc_opts *so, const double *x_init,
                                int B, int warm_start)
 {
-    DeviceGuard guard(c);
-    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
-        return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKET2D)
-        return SCPP_E_UNSUPPORTED;
-    /* first-order or zero-order hold, free or fixed final time */
-    if (so->K != c->K)
-        return SCPP_E_UNSUPPORTED;
-    if (warm_start && (!c->sc_ready || B != c->B))
-        return SCPP_E_STATE;
-    if (int rc = ensureWorkspace(c))
-        return rc;
-    c->B = B;
-    c->mp2 = *mp;
-    c->sc = *so;
-    c->mode = (so->interpolate_input ? SCPP_MODE_FOH : 0) | (so->free_final_time ? SCPP_MODE_VT : 0);
-    if (!so->free_final_time)
-        CHECK_HIP(hipMemsetAsync(c->S, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * sizeof(double), c->stream));
-    if (!so->interpolate_input)
-        CHECK_HIP(hipMemsetAsync(c->C, 0, size_t(B) * (c->K - 1) * size_t(c->nx) * size_t(c->nu) * sizeof(double), c->stream));
-    CHECK_HIP(hipMemcpyAsync(c->x_init, x_init, size_t(B) * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (!warm_start)
-        CHECK_HIP(hipMemsetAsync(c->ipm_warm, 0, size_t(c->Bmax) * sizeof(int), c->stream));
-    c->scvx_ready = false;
-    SCBuffers b = scBuffers(c);
-    hipLaunchKernelGGL(sc_setup_r2d_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, b, c->mp2, c->sc, warm_start);
-    c->sc_ready = true;
-    c->sc_warm = warm_start != 0;
-    c->par_from_ip = true;
-    c->last_active = B;
-    return hipGetLastError() == hipSuccess ? SCPP_OK : SCPP_E_HIP;
+    return scSetupT<Rocket2dPlugin>(c, mp, so, x_init, B, warm_start);
+}
+
+int scpp_hip_sc_setup_lander3dof(scpp_hip_ctx *c, const scpp_lander3dof_params *mp, const scpp_sc_opts *so, const double *x_init,
+                                 int B, int warm_start)
+{
+    return scSetupT<Lander3dofPlugin>(c, mp, so, x_init, B, warm_start);
 }
 
 int scpp_hip_sc_set_active(scpp_hip_ctx *c, const int32_t *mask, int B)
@@ -995,13 +1011,7 @@ int scpp_hip_sc_finish(scpp_hip_ctx *c, int *n_converged)
     if (!c || !c->sc_ready)
         return SCPP_E_STATE;
     if (c->sc.nondimensionalize)
-    {
-        SCBuffers b = scBuffers(c);
-        if (c->model == SCPP_MODEL_ROCKETQUAT)
-            hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
-        else
-            hipLaunchKernelGGL(sc_redim_r2d_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, b);
-    }
+        launchRedim(c);
     CHECK_HIP(hipStreamSynchronize(c->stream));
     if (n_converged)
     {
@@ -1020,10 +1030,11 @@ extern "C++"
 namespace
 {
 // the whole SCAlgorithm::solve loop of every instance in ONE launch (scvx_persistent.h: sc_persistent_kernel) for the configuration the kernel is
-// instantiated for: RocketQuat, first-order hold, free final time (the shipped SC.info).  -1: not available.
-int scSolvePersistent(scpp_hip_ctx *c)
+// instantiated for: the plugins that ask for it (SC_PERSISTENT: RocketQuat), first-order hold, free final time (the shipped SC.info).  -1: not available.
+template <class PL>
+int scSolvePersistentT(scpp_hip_ctx *c)
 {
-    if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->model != SCPP_MODEL_ROCKETQUAT || c->mode != (SCPP_MODE_FOH | SCPP_MODE_VT) || c->sc.max_iterations <= 0)
+    if (c->stream_engine != SCPP_STREAM_PERSISTENT || c->mode != (SCPP_MODE_FOH | SCPP_MODE_VT) || c->sc.max_iterations <= 0)
         return -1;
     // Where it pays (measured, same box, alternating: profiles/r05_ab_persistent_batch_sizes.json): a COLD solve of a batch that fills the chip more than
     // once.  A wavefront integrates its instance's 49 segments one after the other here, where discretize_kernel spreads them over 49 wavefronts: below
@@ -1047,12 +1058,23 @@ int scSolvePersistent(scpp_hip_ctx *c)
     args.S = c->S;
     args.Z = c->Z;
     args.active = c->active;
-    const size_t seg_b = ipm::segLdsBytes<PersistRocketQuat>(c->K), disc_b = sizeof(DiscLds<RocketQuatModel, true, true>);
+    using Model = typename PL::Model;
+    using PT = typename PL::PersistTable;
+    const size_t seg_b = ipm::segLdsBytes<PT>(c->K), disc_b = sizeof(DiscLds<Model, true, true>);
     const bool timed = spanBegin(c, 1, c->B, c->stream);
-    hipLaunchKernelGGL((sc_persistent_kernel<RocketQuatModel, PersistRocketQuat, true, true>), dim3(unsigned(c->B)), dim3(WAVE), seg_b > disc_b ? seg_b : disc_b,
-                       c->stream, args);
+    hipLaunchKernelGGL((sc_persistent_kernel<Model, PT, true, true>), dim3(unsigned(c->B)), dim3(WAVE), seg_b > disc_b ? seg_b : disc_b, c->stream, args);
     spanEnd(c, timed, c->stream);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
+}
+int scSolvePersistent(scpp_hip_ctx *c)
+{
+    return withPlugin(c->model, [&](auto pl) {
+        using PL = decltype(pl);
+        if constexpr (PL::SC_PERSISTENT)
+            return scSolvePersistentT<PL>(c);
+        else
+            return -1;
+    });
 }
 } // namespace
 } // extern "C++"
@@ -1104,7 +1126,12 @@ int scpp_hip_sc_solve(scpp_hip_ctx *c, int *n_converged)
             // a measurement knob: never-touched dynamic LDS that limits the ipm workgroups per CU.  Clamped so that pad + the LDS-resident segment
             // fields (up to 21.5 KB at K = 64) + the kernel's 3 KB of static LDS stay inside the 64 KB a workgroup may ask for -- an unclamped
             // value surfaced only as SCPP_E_HIP from the launch
-            const long want = std::atol(e), room = 65536 - 4096 - long(ipm::segLdsBytes<ipm::RocketQuatSC>(c->K));
+            long seg_b = 0;
+            (void)withPlugin(c->model, [&](auto pl) {
+                seg_b = long(ipm::segLdsBytes<typename decltype(pl)::Table>(c->K));
+                return 0;
+            });
+            const long want = std::atol(e), room = 65536 - 4096 - seg_b;
             c->ipm_lds_pad = unsigned(want < 0 ? 0 : (want > room ? room : want));
         }
         CHECK_HIP(hipStreamCreate(&c->stream2));
@@ -1291,34 +1318,43 @@ int scvxSetupDone(scpp_hip_ctx *c, double final_time, int B, int warm_start)
 }
 } // namespace
 
-int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
-                        int B, int warm_start)
+extern "C++"
+{
+namespace
+{
+template <class PL>
+int scvxSetupT(scpp_hip_ctx *c, const typename PL::Params *mp, const scpp_scvx_opts *so, const double *x_init, int B, int warm_start)
 {
     DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
         return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKETQUAT || mp->enable_roll_control)
+    if (c->model != PL::ID || !PL::supported(*mp))
         return SCPP_E_UNSUPPORTED;
     if (int rc = scvxSetupCommon(c, so, x_init, B, warm_start))
         return rc;
-    c->mp = *mp;
-    hipLaunchKernelGGL(sc_setup_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), c->mp, c->sc, warm_start);
+    paramsOf<PL>(c) = *mp;
+    hipLaunchKernelGGL((sc_setup_kernel<PL>), dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), paramsOf<PL>(c), c->sc, warm_start);
     return scvxSetupDone(c, mp->final_time, B, warm_start);
+}
+} // namespace
+} // extern "C++"
+
+int scpp_hip_scvx_setup(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                        int B, int warm_start)
+{
+    return scvxSetupT<RocketQuatPlugin>(c, mp, so, x_init, B, warm_start);
 }
 
 int scpp_hip_scvx_setup_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x_init,
                                  int B, int warm_start)
 {
-    DeviceGuard guard(c);
-    if (!c || !mp || !so || !x_init || B < 1 || B > c->Bmax)
-        return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKET2D)
-        return SCPP_E_UNSUPPORTED;
-    if (int rc = scvxSetupCommon(c, so, x_init, B, warm_start))
-        return rc;
-    c->mp2 = *mp;
-    hipLaunchKernelGGL(sc_setup_r2d_kernel, dim3(unsigned((B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c), c->mp2, c->sc, warm_start);
-    return scvxSetupDone(c, mp->final_time, B, warm_start);
+    return scvxSetupT<Rocket2dPlugin>(c, mp, so, x_init, B, warm_start);
+}
+
+int scpp_hip_scvx_setup_lander3dof(scpp_hip_ctx *c, const scpp_lander3dof_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                                   int B, int warm_start)
+{
+    return scvxSetupT<Lander3dofPlugin>(c, mp, so, x_init, B, warm_start);
 }
 
 namespace
@@ -1358,10 +1394,10 @@ int scvxRound(scpp_hip_ctx *c, Range r)
         return rc;
     const SCBuffers b = scBuffersRange(c, r);
     const SCvxBuffers v = scvxBuffersRange(c, r);
-    if (c->model == SCPP_MODEL_ROCKETQUAT)
-        hipLaunchKernelGGL((scvx_cost_update_kernel<RocketQuatModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
-    else
-        hipLaunchKernelGGL((scvx_cost_update_kernel<Rocket2dModel>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
+    (void)withPlugin(c->model, [&](auto pl) {
+        hipLaunchKernelGGL((scvx_cost_update_kernel<typename decltype(pl)::Model>), dim3(unsigned(r.count)), dim3(WAVE), 0, r.stream, b, v, c->scvx);
+        return 0;
+    });
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
 
@@ -1417,18 +1453,24 @@ int launchPersistentT(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers
         hipLaunchKernelGGL((scvx_persistent_kernel<T, Model, PZ, false>), dim3(unsigned(S)), dim3(WAVE), lds, c->stream, args);
     return hipGetLastError() == hipSuccess ? 0 : SCPP_E_HIP;
 }
+template <class PL>
 int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
-                     const scpp_rocketquat_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
+                     const typename PL::Params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
 {
-    return launchPersistentT<RefillRocketQuat, RocketQuatModel, PersistRocketQuat, ipm::ZeroOrderHold<PersistRocketQuat>>(c, a, b, v, q, mp, sc, so, o, S);
-}
-int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers &b, const SCvxBuffers &v, const StreamQueue &q,
-                     const scpp_rocket2d_params &mp, const scpp_sc_opts &sc, const scpp_scvx_opts &so, const PersistentOut &o, int S)
-{
-    return launchPersistentT<RefillRocket2d, Rocket2dModel, PersistRocket2d, ipm::ZeroOrderHold<PersistRocket2d>>(c, a, b, v, q, mp, sc, so, o, S);
+    if constexpr (PL::SCVX_PERSISTENT)
+    {
+        using PT = typename PL::PersistTable;
+        return launchPersistentT<PL, typename PL::Model, PT, ipm::ZeroOrderHold<PT>>(c, a, b, v, q, mp, sc, so, o, S);
+    }
+    else
+        return -1; // (persistentAvailable() said so before anything was set up)
 }
 // the persistent kernel runs a job when the context's engine asks for it and there is at least one iteration to run
-bool persistentAvailable(const scpp_hip_ctx *c, int max_iterations) { return c->stream_engine == SCPP_STREAM_PERSISTENT && max_iterations > 0; }
+// (and the model's plugin instantiates the kernel: its cost step gives two lanes one segment and needs an even number of states)
+bool persistentAvailable(const scpp_hip_ctx *c, int max_iterations)
+{
+    return c->stream_engine == SCPP_STREAM_PERSISTENT && max_iterations > 0 && withPlugin(c->model, [](auto pl) { return decltype(pl)::SCVX_PERSISTENT ? 0 : 1; }) == 0;
+}
 
 // queue arrays of the streaming engine (also used, with an empty queue, by the persistent batch solve)
 int ensureQueue(scpp_hip_ctx *c)
@@ -1475,8 +1517,10 @@ int scvxSolvePersistent(scpp_hip_ctx *c)
     o.disc_steps = c->disc_steps;
     o.shares = c->persist_shares;
     const bool timed = spanBegin(c, 1, c->B, c->stream);
-    const int rc = c->model == SCPP_MODEL_ROCKETQUAT ? launchPersistent(c, a, b, v, q, c->mp, c->sc, c->scvx, o, c->B)
-                                                     : launchPersistent(c, a, b, v, q, c->mp2, c->sc, c->scvx, o, c->B);
+    const int rc = withPlugin(c->model, [&](auto pl) {
+        using PL = decltype(pl);
+        return launchPersistent<PL>(c, a, b, v, q, paramsOf<PL>(c), c->sc, c->scvx, o, c->B);
+    });
     spanEnd(c, timed, c->stream);
     return rc;
 }
@@ -1530,12 +1574,7 @@ int scpp_hip_scvx_solve(scpp_hip_ctx *c, int *n_converged)
         }
     }
     if (c->scvx.nondimensionalize)
-    {
-        if (c->model == SCPP_MODEL_ROCKETQUAT)
-            hipLaunchKernelGGL(sc_redim_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
-        else
-            hipLaunchKernelGGL(sc_redim_r2d_kernel, dim3(unsigned((c->B + 63) / 64)), dim3(64), 0, c->stream, scBuffers(c));
-    }
+        launchRedim(c);
     CHECK_HIP(hipStreamSynchronize(c->stream));
     {
         int n = 0;
@@ -1561,14 +1600,6 @@ extern "C++"
 {
 namespace
 {
-int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocketquat_params *mp, const scpp_scvx_opts *so, const double *x, int B)
-{
-    return scpp_hip_scvx_setup(c, mp, so, x, B, 0);
-}
-int scvxSetupFor(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x, int B)
-{
-    return scpp_hip_scvx_setup_rocket2d(c, mp, so, x, B, 0);
-}
 template <class T>
 int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_scvx_opts *so, const double *x_init, int N, int slots,
                     int pools, int *n_converged)
@@ -1578,7 +1609,7 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
     c->q_N = 0; // whatever fails from here on, the rows of a previous job are no longer valid (stream_download -> SCPP_E_STATE)
     // the engine's per-slot state is the batch state of scvx_setup: set it up on the first S instances' worth of slots
     // WITHOUT starting them (every slot starts empty and is filled by the first refill)
-    if (int rc = scvxSetupFor(c, mp, so, x_init, S))
+    if (int rc = scvxSetupT<T>(c, mp, so, x_init, S, 0))
         return rc;
     const size_t K = size_t(c->K), rowd = size_t(streamRowDoubles(c->K, NX, NU));
     if (c->q_cap < size_t(N))
@@ -1687,7 +1718,7 @@ int scvxSolveStream(scpp_hip_ctx *c, const typename T::Params *mp, const scpp_sc
         o.disc_steps = c->disc_steps;
         o.shares = c->persist_shares;
         const bool timed = spanBegin(c, 1, N, c->stream);
-        const int prc = launchPersistent(c, a, b, v, qp, *mp, sc, *so, o, S);
+        const int prc = launchPersistent<T>(c, a, b, v, qp, *mp, sc, *so, o, S);
         spanEnd(c, timed, c->stream);
         {
             int counters[4] = {0, 0, 0, 0};
@@ -1796,9 +1827,9 @@ int scpp_hip_scvx_solve_stream(scpp_hip_ctx *c, const scpp_rocketquat_params *mp
     DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
         return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKETQUAT || mp->enable_roll_control)
+    if (c->model != RocketQuatPlugin::ID || !RocketQuatPlugin::supported(*mp))
         return SCPP_E_UNSUPPORTED;
-    return scvxSolveStream<RefillRocketQuat>(c, mp, so, x_init, N, slots, pools, n_converged);
+    return scvxSolveStream<RocketQuatPlugin>(c, mp, so, x_init, N, slots, pools, n_converged);
 }
 
 int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_params *mp, const scpp_scvx_opts *so, const double *x_init,
@@ -1807,9 +1838,20 @@ int scpp_hip_scvx_solve_stream_rocket2d(scpp_hip_ctx *c, const scpp_rocket2d_par
     DeviceGuard guard(c);
     if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
         return SCPP_E_ARG;
-    if (c->model != SCPP_MODEL_ROCKET2D)
+    if (c->model != Rocket2dPlugin::ID || !Rocket2dPlugin::supported(*mp))
         return SCPP_E_UNSUPPORTED;
-    return scvxSolveStream<RefillRocket2d>(c, mp, so, x_init, N, slots, pools, n_converged);
+    return scvxSolveStream<Rocket2dPlugin>(c, mp, so, x_init, N, slots, pools, n_converged);
+}
+
+int scpp_hip_scvx_solve_stream_lander3dof(scpp_hip_ctx *c, const scpp_lander3dof_params *mp, const scpp_scvx_opts *so, const double *x_init,
+                                          int N, int slots, int pools, int *n_converged)
+{
+    DeviceGuard guard(c);
+    if (!c || !mp || !so || !x_init || N < 1 || slots < 0 || slots > c->Bmax || pools < 0 || pools > 8)
+        return SCPP_E_ARG;
+    if (c->model != Lander3dofPlugin::ID || !Lander3dofPlugin::supported(*mp))
+        return SCPP_E_UNSUPPORTED;
+    return scvxSolveStream<Lander3dofPlugin>(c, mp, so, x_init, N, slots, pools, n_converged);
 }
 
 int scpp_hip_stream_rows(scpp_hip_ctx *c, void **rows, int *row_doubles, int *n)
@@ -1892,7 +1934,15 @@ int scpp_hip_scvx_download_iterates(scpp_hip_ctx *c, int first, int count, int c
     CHECK_HIP(hipMemcpy(cnt.data(), c->vx_iter_count + first, size_t(count) * sizeof(int), hipMemcpyDeviceToHost));
     std::vector<double> ip(size_t(count) * ipm::IP_N), buf(cap * rec);
     CHECK_HIP(hipMemcpy(ip.data(), c->ip + size_t(first) * ipm::IP_N, ip.size() * sizeof(double), hipMemcpyDeviceToHost));
-    const bool rq = c->model == SCPP_MODEL_ROCKETQUAT;
+    // factor that redimensionalises entry e of a state (is_u = 0) / input (is_u = 1) vector: the plugin's rx / ru
+    auto redim = [&](int is_u, int e, double ms, double rs) {
+        double f = 1.;
+        (void)withPlugin(c->model, [&](auto pl) {
+            f = is_u ? decltype(pl)::ru(e, ms, rs) : decltype(pl)::rx(e, ms, rs);
+            return 0;
+        });
+        return f;
+    };
     for (int b = 0; b < count; b++)
     {
         const int n = cnt[size_t(b)] < capacity ? cnt[size_t(b)] : capacity;
@@ -1902,7 +1952,7 @@ int scpp_hip_scvx_download_iterates(scpp_hip_ctx *c, int first, int count, int c
             continue;
         CHECK_HIP(hipMemcpy(buf.data(), c->vx_iter_ring + (size_t(first + b) * cap) * rec, size_t(n) * rec * sizeof(double), hipMemcpyDeviceToHost));
         // redimensionalizeTrajectory of every recorded trajectory (SCvxAlgorithm.cpp:247-255; rocketQuat.cpp:188-201, rocket2d.cpp:108-118): the
-        // factors of the result rows (csrc/scvx_kernels.h: RefillRocketQuat / RefillRocket2d); 1 when the run is not nondimensionalised
+        // factors of the result rows (the plugin's rx / ru, csrc/sc_kernels.h); 1 when the run is not nondimensionalised
         const double ms = ip[size_t(b) * ipm::IP_N + ipm::IP_MSCALE], rs = ip[size_t(b) * ipm::IP_N + ipm::IP_RSCALE];
         for (int j = 0; j < n; j++)
         {
@@ -1914,13 +1964,13 @@ int scpp_hip_scvx_download_iterates(scpp_hip_ctx *c, int first, int count, int c
                 if (X)
                     for (size_t e = 0; e < nx; e++)
                     {
-                        const double f = rq ? (e == 0 ? ms : (e < 7 ? rs : 1.)) : (e < 4 ? rs : 1.);
+                        const double f = redim(0, int(e), ms, rs);
                         X[((size_t(b) * size_t(capacity) + size_t(j)) * K + k) * nx + e] = buf[size_t(j) * rec + k * nx + e] * f;
                     }
                 if (U)
                     for (size_t e = 0; e < nu; e++)
                     {
-                        const double f = rq ? (e < 3 ? ms * rs : ms * rs * rs) : (e == 1 ? ms * rs : 1.);
+                        const double f = redim(1, int(e), ms, rs);
                         U[((size_t(b) * size_t(capacity) + size_t(j)) * K + k) * nu + e] = buf[size_t(j) * rec + K * nx + k * nu + e] * f;
                     }
             }

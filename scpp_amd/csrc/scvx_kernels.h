@@ -451,31 +451,10 @@ struct StreamQueue
     int *warm;             // [B] interior-point warm-start flag of the slot
 };
 
-// What the refill kernel needs to know about a model: its C-ABI parameter struct, the cold start of one instance and the
-// factors that redimensionalise a result row.
-struct RefillRocketQuat
-{
-    using Params = scpp_rocketquat_params;
-    static constexpr int NX = 14, NU = 4;
-    static __device__ void coldStart(const SCBuffers &b, const Params &mp, const scpp_sc_opts &sc, long slot, const double *xi, int lane)
-    {
-        scSetupOne(b, mp, sc, 0, slot, xi, lane, WAVE);
-    }
-    static __device__ double rx(int j, double ms, double rs) { return redimX(j, ms, rs); }
-    static __device__ double ru(int j, double ms, double rs) { return redimU(j, ms, rs); }
-};
-struct RefillRocket2d
-{
-    using Params = scpp_rocket2d_params;
-    static constexpr int NX = 6, NU = 2;
-    static __device__ void coldStart(const SCBuffers &b, const Params &mp, const scpp_sc_opts &sc, long slot, const double *xi, int lane)
-    {
-        if (lane == 0)
-            scSetupOneR2d(b, mp, sc, 0, slot, xi);
-    }
-    static __device__ double rx(int j, double, double rs) { return j < 4 ? rs : 1.; }        // rocket2d.cpp:108-118
-    static __device__ double ru(int j, double ms, double rs) { return j == 1 ? ms * rs : 1.; }
-};
+// What the refill kernel needs to know about a model is part of its plugin (sc_kernels.h): the C-ABI parameter struct, the cold start
+// of one instance spread over a wavefront's lanes (setupOne with k0 = lane, kstep = 64) and the factors that redimensionalise a result row.
+using RefillRocketQuat = RocketQuatPlugin;
+using RefillRocket2d = Rocket2dPlugin;
 
 // One wavefront per slot, at the top of every round: harvest a terminated instance (redimensionalised row -> rows[inst]),
 // then pull the next instance id off the queue and run its cold start (the model's set-up + scvxSetupOne).
@@ -531,7 +510,7 @@ __device__ __forceinline__ void scvxStreamRefill(const SCBuffers &b, const SCvxB
     if (next >= 0)
     {
         const double *xi = q.x_init + size_t(next) * NX;
-        T::coldStart(b, mp, sc, slot, xi, lane);
+        T::setupOne(b, mp, sc, 0, slot, xi, lane, WAVE);
         if (lane == 0)
         {
             scvxSetupOne(b, v, so, mp.final_time, 0, slot);

@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from ._lib import MODEL_ROCKET2D, MODEL_ROCKETQUAT, Rocket2dParams, RocketQuatParams, ScppHipError
+from ._lib import MODEL_LANDER3DOF, MODEL_ROCKET2D, MODEL_ROCKETQUAT, Lander3dofParams, Rocket2dParams, RocketQuatParams, ScppHipError
 from .parameter_server import ParameterServer
 
 CONFIG_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
@@ -197,5 +197,77 @@ class Rocket2D:
             x[2] = 0.05 * abs(x[3]) * counter_uniform(seed, i, 1)
             x[3] *= 1.0 + 0.2 * counter_uniform(seed, i, 2)
             x[4] *= counter_uniform(seed, i, 3)
+            out[b] = x
+        return out
+
+
+class Lander3dofParameters:
+    """Parameters of the Lander3dof model after loadFromFile: SI units, radians."""
+
+
+class Lander3dof:
+    """Host-side configuration half of the Lander3dof plugin -- NOT a model of the reference: this repository's third model (a point-mass
+    powered-descent vehicle, states [m, r, v], input T), added in round 6 through the model-plugin path; the flow map, the constraint table
+    and the per-instance set-up are device code (csrc/model_lander3dof.h, constraint_table.h: Lander3dofSC, sc_kernels.h: Lander3dofPlugin).
+    Same call order as the reference's models: loadParameters -> (algorithm).  config/Lander3dof/{model,SC,SCvx}.info."""
+    modelName = "Lander3dof"
+    model_id = MODEL_LANDER3DOF
+    state_dim, input_dim, param_dim = 7, 3, 4
+
+    def __init__(self, param_folder=CONFIG_ROOT):
+        self.param_folder = param_folder
+        self.p = None
+
+    @property
+    def x_init(self):
+        return self.p.x_init
+
+    def getParameterFolder(self):
+        return os.path.join(self.param_folder, self.modelName)
+
+    def loadParameters(self):
+        ps = ParameterServer(os.path.join(self.getParameterFolder(), "model.info"))
+        d2r = math.pi / 180.0
+        p = Lander3dofParameters()
+        p.g_I = ps.load_vector("g_I", 3)
+        p.exact_minimum_thrust = ps.load_scalar("exact_minimum_thrust", bool)
+        p.alpha_m = 1.0 / (ps.load_scalar("I_sp") * abs(p.g_I[2]))
+        p.T_min, p.T_max = ps.load_scalar("T_min"), ps.load_scalar("T_max")
+        p.pointing_max = ps.load_scalar("pointing_max") * d2r
+        p.gamma_gs = ps.load_scalar("gamma_gs") * d2r
+        p.final_time = ps.load_scalar("final_time")
+        p.x_init = np.array([ps.load_scalar("m_init")] + ps.load_vector("r_init", 3) + ps.load_vector("v_init", 3))
+        p.x_final = np.array([ps.load_scalar("m_dry")] + ps.load_vector("r_final", 3) + ps.load_vector("v_final", 3))
+        self.p = p
+        return self
+
+    def sc_params(self):
+        """scpp_lander3dof_params for scpp_hip_sc_setup_lander3dof / scpp_hip_scvx_setup_lander3dof"""
+        p, q = self.p, Lander3dofParams()
+        q.exact_minimum_thrust = int(p.exact_minimum_thrust)
+        q.g_I[:] = p.g_I
+        q.alpha_m, q.T_min, q.T_max, q.pointing_max, q.gamma_gs = p.alpha_m, p.T_min, p.T_max, p.pointing_max, p.gamma_gs
+        q.x_final[:] = list(p.x_final)
+        q.final_time = p.final_time
+        return q
+
+    def flow_params(self, nondimensionalize=False, x_init=None):
+        """par = [alpha_m, g_I]; nondimensionalize=True: in the units of the instance (m_scale = m_init, r_scale = |r_init|)"""
+        x = self.x_init if x_init is None else np.asarray(x_init)
+        r_s = float(np.linalg.norm(x[1:4])) if nondimensionalize else 1.0
+        return np.array([self.p.alpha_m * r_s] + [g / r_s for g in self.p.g_I])
+
+    def randomized_initial_states(self, batch, seed=20260927, first=0):
+        """Synthetic start states around the shipped x_init, RocketQuat's recipe without the attitude: lateral position and velocity
+        scaled by U(-1,1), descent rate by 1 + 0.2 U; mass and altitude unchanged."""
+        out = np.zeros((batch, 7))
+        for b in range(batch):
+            i = first + b
+            x = self.p.x_init.copy()
+            x[1] *= counter_uniform(seed, i, 0)
+            x[2] *= counter_uniform(seed, i, 1)
+            x[4] *= counter_uniform(seed, i, 2)
+            x[5] *= counter_uniform(seed, i, 3)
+            x[6] *= 1.0 + 0.2 * counter_uniform(seed, i, 4)
             out[b] = x
         return out

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 CONFIG_ROOT = os.path.join(ROOT, "scpp_amd", "config")
 
-ROCKETQUAT, ROCKET2D = 0, 1
+ROCKETQUAT, ROCKET2D, LANDER3DOF = 0, 1, 2
 
 _lib = None
 

@@ -12,6 +12,7 @@ from conftest import GOLDEN, ROOT
 SRC = r'''
 #include "hip_emu.h"
 #include "model_rocketquat.h"
+#include "model_lander3dof.h"
 #include <cstdio>
 using namespace scpp;
 template <class M> int run()
@@ -86,7 +87,7 @@ template <class M> int run()
     }
     return 0;
 }
-int main(int argc, char **argv) { return argv[1][0] == 'q' ? run<RocketQuatModel>() : run<Rocket2dModel>(); }
+int main(int argc, char **argv) { return argv[1][0] == 'q' ? run<RocketQuatModel>() : argv[1][0] == 'l' ? run<Lander3dofModel>() : run<Rocket2dModel>(); }
 '''
 
 
@@ -100,7 +101,7 @@ def rows_bin(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("name,flag,nx,nu", [("rocketquat", "q", 14, 4), ("rocket2d", "2", 6, 2)])
+@pytest.mark.parametrize("name,flag,nx,nu", [("rocketquat", "q", 14, 4), ("rocket2d", "2", 6, 2), ("lander3dof", "l", 7, 3)])
 def test_generated_rows_match_sympy_golden_and_forward_ad(rows_bin, name, flag, nx, nu):
     g = np.load(os.path.join(GOLDEN, f"{name}_jacobians.npz"))
     n = g["x"].shape[0]

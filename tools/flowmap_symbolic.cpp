@@ -42,6 +42,7 @@ inline Sym dcos(const Sym &a) { return Sym("cos(" + a.e + ")"); }
 } // namespace scpp
 
 #include "model_rocketquat.h"
+#include "model_lander3dof.h"
 
 template <class Model>
 static void dump(const char *name)
@@ -64,5 +65,6 @@ int main()
 {
     dump<scpp::RocketQuatModel>("RocketQuat");
     dump<scpp::Rocket2dModel>("Rocket2d");
+    dump<scpp::Lander3dofModel>("Lander3dof");
     return 0;
 }

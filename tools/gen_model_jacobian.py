@@ -91,6 +91,15 @@ def rocket2d():
     return "Rocket2d", x, u, p, f, hoist
 
 
+def lander3dof():
+    """csrc/model_lander3dof.h: Lander3dofModel::systemFlowMap (this repository's third model)"""
+    m_ = flowmaps_from_cpp()["Lander3dof"]
+    x, u, p, f = m_["x"], m_["u"], m_["p"], m_["f"]
+    tn = sp.Symbol("t_norm", real=True)
+    hoist = [("inv_m", 1 / x[0]), ("t_norm", sp.sqrt(u[0]**2 + u[1]**2 + u[2]**2)), ("inv_t_norm", 1 / tn)]
+    return "Lander3dof", x, u, p, f, hoist
+
+
 def emit(model):
     name, x, u, p, f, hoist = model
     nx, nu = len(x), len(u)
@@ -332,7 +341,7 @@ def main(out=None):
            "// Analytic rows of [df/dx | df/du] of the model plugins (the build-time analogue of the reference's CppADCodeGen step,",
            "// scpp_core/include/systemDynamics.hpp:109-168).  One `case` per state row: discretize_kernel keeps one Jacobian row per lane.",
            "#pragma once", "#include \"common.h\"", "", "namespace scpp", "{", ""]
-    body = [emit(rocketquat()), emit_table(rocketquat()), emit(rocket2d()), emit_table(rocket2d())]
+    body = [emit(rocketquat()), emit_table(rocketquat()), emit(rocket2d()), emit_table(rocket2d()), emit(lander3dof()), emit_table(lander3dof())]
     with open(out, "w") as fh:
         fh.write("\n".join(hdr) + "\n".join(body) + "} // namespace scpp\n")
     print("wrote", out)
