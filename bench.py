@@ -484,7 +484,8 @@ def main():
             import shutil, tempfile
 
             legs = {}
-            for mdl, foh, Kx in (("RocketQuat", False, K), ("Rocket2D", True, 30), ("Rocket2D", False, 30)):
+            # (+ the third model, Lander3dof: registered through the plugin list, pool engine -- csrc/sc_kernels.h; not a model of the reference)
+            for mdl, foh, Kx in (("RocketQuat", False, K), ("Rocket2D", True, 30), ("Rocket2D", False, 30), ("Lander3dof", True, 30)):
                 d = tempfile.mkdtemp()
                 cfg = os.path.join(d, "config")
                 shutil.copytree(os.path.join(os.path.dirname(scpp_amd.__file__), "config"), cfg)
@@ -495,7 +496,7 @@ def main():
                 if mdl == "Rocket2D":  # the shipped file runs in SI units and does not converge; nondimensionalised it does
                     t = t.replace("nondimensionalize                   false", "nondimensionalize                   true")
                 open(pth, "w").write(t)
-                mx = (scpp_amd.RocketQuat if mdl == "RocketQuat" else scpp_amd.Rocket2D)(cfg).loadParameters()
+                mx = {"RocketQuat": scpp_amd.RocketQuat, "Rocket2D": scpp_amd.Rocket2D, "Lander3dof": scpp_amd.Lander3dof}[mdl](cfg).loadParameters()
                 ax = scpp_amd.SCvxAlgorithm(mx, K=Kx, batch_max=B, device=dev_index, library=args.library).initialize()
                 xx = mx.randomized_initial_states(2 * B, seed=args.seed, first=40_000_000)
                 ax.solveStream(xx[:256], slots=256)

@@ -450,9 +450,9 @@ struct Lander3dofPlugin
     using PersistTable = PersistLander3dof;
     using Params = scpp_lander3dof_params;
     static constexpr int NX = Model::NX, NU = Model::NU;
-    // the persistent SCvx kernel's cost step gives two lanes one segment (scvx_kernels.h: scvxCostUpdateSplit): an even number of states; this model
-    // has seven and runs the pool engine (scpp_hip_scvx_solve's rounds, the streaming engine's slot pools)
-    static constexpr bool SPLIT_SCHEDULE = false, SC_PERSISTENT = false, SCVX_PERSISTENT = false;
+    // SCVX_PERSISTENT: the persistent SCvx kernel is instantiated for this model (scvx_persistent.h; the default streaming engine).  false would run the
+    // pool engine (scpp_hip_scvx_solve's rounds, the streaming engine's slot pools) -- same rows, bitwise
+    static constexpr bool SPLIT_SCHEDULE = false, SC_PERSISTENT = false, SCVX_PERSISTENT = true;
     static bool supported(const Params &) { return true; }
     static __device__ void setupOne(const SCBuffers &b, const Params &mp, const scpp_sc_opts &so, int warm, long i, const double *xi, int k0, int kstep)
     {

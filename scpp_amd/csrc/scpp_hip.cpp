@@ -1466,7 +1466,7 @@ int launchPersistent(scpp_hip_ctx *c, const ipm::KernelArgs &a, const SCBuffers 
         return -1; // (persistentAvailable() said so before anything was set up)
 }
 // the persistent kernel runs a job when the context's engine asks for it and there is at least one iteration to run
-// (and the model's plugin instantiates the kernel: its cost step gives two lanes one segment and needs an even number of states)
+// (and the model's plugin instantiates the kernel: SCVX_PERSISTENT)
 bool persistentAvailable(const scpp_hip_ctx *c, int max_iterations)
 {
     return c->stream_engine == SCPP_STREAM_PERSISTENT && max_iterations > 0 && withPlugin(c->model, [](auto pl) { return decltype(pl)::SCVX_PERSISTENT ? 0 : 1; }) == 0;

@@ -302,8 +302,9 @@ template <class Model>
 __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SCvxBuffers &v, const scpp_scvx_opts &so, const long i, double *seg_sum /* [64] LDS */)
 {
     using namespace ipm;
-    constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NH = NX / 2;
-    static_assert(NX % 2 == 0, "two lanes share a segment: an even number of states");
+    // half 0 keeps components [0, NH), half 1 components [NH, NX): NH = NX / 2 for an even number of states; for an odd one (round 6: Lander3dof
+    // has seven) half 1 holds one component less and its last slot is padding that is carried as 0 and never stored or summed
+    constexpr int NX = Model::NX, NU = Model::NU, NP = Model::NP, NH = (NX + 1) / 2, NH1 = NX - NH;
     if (i >= b.B || b.active[i] == 0)
         return;
     const int K = b.K, lane = threadIdx.x;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SC
         }
 #pragma unroll
         for (int j = 0; j < NH; j++)
-            y[j] = X[half * NH + j];
+            y[j] = (j < NH1 || !half) ? X[half * NH + j] : 0.;
         const double dt = b.sigma[i] / double(K - 1);
         const double h = dt / 20.;
         for (int step = 0; step < 20; step++)
@@ -359,7 +360,8 @@ __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SC
                 {
                     const double other = __shfl_xor(mine[j], 1);
                     ys[j] = half ? other : mine[j];
-                    ys[NH + j] = half ? mine[j] : other;
+                    if (j < NH1)
+                        ys[NH + j] = half ? mine[j] : other;
                 }
 #pragma unroll
                 for (int j = 0; j < NU; j++)
@@ -367,7 +369,7 @@ __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SC
                 Model::template systemFlowMap<double>(ys, u, p, f);
 #pragma unroll
                 for (int j = 0; j < NH; j++)
-                    kk[s][j] = half ? f[NH + j] : f[j];
+                    kk[s][j] = half ? (j < NH1 ? f[NH + j < NX ? NH + j : 0] : 0.) : f[j];
             }
 #pragma unroll
             for (int j = 0; j < NH; j++)
@@ -393,7 +395,7 @@ __device__ __forceinline__ void scvxCostUpdateSplit(const SCBuffers &b, const SC
         {
             part = from0;
 #pragma unroll
-            for (int j = 0; j < NH; j++)
+            for (int j = 0; j < NH1; j++)
                 part += fabs(y[j] - X[NX + NH + j]);
             if (on)
                 seg_sum[k] = part;

@@ -73,7 +73,7 @@ def _sc_case(oracle, lib, K, B):
         sc = oracle.SC(oracle.LANDER3DOF, K=K); sc.set_x_init(x0[b]); sc.solve()
         X, U, t = sc.solution()
         assert out["sc_iters"][b] == sc.meta()["iterations"] and out["converged"][b] == sc.meta()["converged"]
-        assert abs(out["sigma"][b] - t) <= 1e-6 * t
+        assert abs(out["sigma"][b] - t) <= 1e-5 * t  # north_star's 1e-5 (K = 30: 1.1e-6 after 15 iterations of a loop that stalls at ||nu||_1 = 0.065, like RocketQuat's)
         dX = np.abs(out["X"][b] - X).max() / np.abs(X).max()
         dU = np.abs(out["U"][b] - U).max() / np.abs(U).max()
         assert dX <= 1e-5 and dU <= 1e-4, (b, dX, dU)
@@ -113,21 +113,32 @@ def test_emu_lander3dof_scvx_matches_the_oracle_literal_run(oracle, emu_lib):
     _scvx_case(oracle, emu_lib, 8, 2)
 
 
-def test_emu_lander3dof_stream_rows_equal_the_batch_solve(emu_lib):
-    """The streaming engine (slot pools: the persistent kernel's cost step needs an even number of states, this model has seven) gives every instance
-    the row the batch entry point gives it, bitwise."""
+def _engines_case(lib, K, N, slots):
+    """Streaming job through fewer slots than instances on BOTH engines (persistent kernel: its cost step gives two lanes one segment, and this
+    model has an ODD number of states -- half 1 carries one padding slot; pool engine: one lane per segment) and the batch entry point:
+    every instance's row is bitwise the same from all three."""
     m = _model()
-    K, N = 8, 5
     x0 = m.randomized_initial_states(N, first=10)
-    a = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=N, library=emu_lib).initialize()
+    a = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=N, library=lib).initialize()
     a.solve(x0)
     ref = a.getSolution()
     a.ctx.close()
-    s = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=2, library=emu_lib).initialize()
-    s.solveStream(x0, slots=2)
-    rows = s.getStreamSolution()
-    assert np.array_equal(rows["X"], ref["X"]) and np.array_equal(rows["U"], ref["U"]) and np.array_equal(rows["sc_iters"], ref["sc_iters"])
-    s.ctx.close()
+    engines = {}
+    for engine in (scpp_amd._lib.STREAM_PERSISTENT, scpp_amd._lib.STREAM_POOLS):
+        s = scpp_amd.SCvxAlgorithm(m, K=K, batch_max=slots, library=lib).initialize()
+        s.ctx.set_stream_engine(engine)
+        n = s.solveStream(x0, slots=slots)
+        rows = s.getStreamSolution()
+        engines[engine] = s.ctx.stream_rounds()["pools"]
+        for k in ("X", "U", "sc_iters", "solves", "ipm_iters", "status"):
+            assert np.array_equal(rows[k], ref[k]), (engine, k)
+        s.ctx.close()
+    assert engines[scpp_amd._lib.STREAM_PERSISTENT] == 0 and engines[scpp_amd._lib.STREAM_POOLS] >= 1  # (pools = 0: the persistent kernel ran the job)
+    return n, ref
+
+
+def test_emu_lander3dof_stream_rows_equal_the_batch_solve_on_both_engines(emu_lib):
+    _engines_case(emu_lib, 8, 5, 2)
 
 
 @pytest.mark.gpu
@@ -142,14 +153,7 @@ def test_lander3dof_sc_and_scvx_match_the_oracle_on_gpu(oracle, hip_lib):
     failure; a streaming job through fewer slots than instances returns the batch entry point's rows bitwise."""
     out, worst = _sc_case(oracle, hip_lib, 30, 64)
     vx = _scvx_case(oracle, hip_lib, 30, 64)
-    m = _model()
-    x0 = np.tile(m.x_init, (64, 1))
-    x0[1:] = m.randomized_initial_states(63, first=1)
-    s = scpp_amd.SCvxAlgorithm(m, K=30, batch_max=24, library=hip_lib).initialize()
-    n = s.solveStream(x0, slots=24)
-    rows = s.getStreamSolution()
-    assert np.array_equal(rows["X"], vx["X"]) and np.array_equal(rows["U"], vx["U"]) and np.array_equal(rows["sc_iters"], vx["sc_iters"])
-    s.ctx.close()
+    n, ref = _engines_case(hip_lib, 30, 64, 24)
     print("Lander3dof on the GPU: SC converged %d / 64 (worst rel dX vs the literal run %.1e), SCvx converged %d / 64 in %.1f iterations on average; "
-          "streaming job of 64 instances through 24 slots: %d converged, rows bitwise the batch solve's"
+          "streaming job of 64 instances through 24 slots: %d converged, rows bitwise the batch solve's on the persistent kernel and on the pool engine"
           % (int(out["converged"].sum()), worst, int(vx["converged"].sum()), float(vx["sc_iters"].mean()), n))
