@@ -641,6 +641,14 @@ int oracle_scvx_set_twin_tolerances(void *h, double feastol, double abstol, doub
         return 0;
     });
 }
+// primal and dual step lengths of their own in the structured twin (default: on, like the device kernel's IPM_SPLIT_STEPS); 0: ECOS's common one
+int oracle_scvx_set_twin_split_steps(void *h, int on)
+{
+    return withScvx(h, [&](auto &a) {
+        a.structured_settings.split_steps = on != 0;
+        return 0;
+    });
+}
 int oracle_scvx_verbose(void *h, int v)
 {
     return withScvx(h, [&](auto &a) {

@@ -55,6 +55,11 @@ struct RQSocpSettings
     double feastol = 1e-8, abstol = 1e-7, reltol = 1e-7;
     int maxit = 60;
     double gamma = 0.99;
+    // step lengths of their own for the primal variables (x, s) and the dual ones (multipliers, z): the device kernel's IPM_SPLIT_STEPS (round 6;
+    // csrc/ipm_solve.h).  false: ECOS's single step length, the largest that keeps s AND z in their cones (rounds 1 - 6a).  The centring
+    // parameter follows ECOS's rule on the COMMON affine step length either way.  tools/experiments/split_step_study.py: 366 -> 327
+    // interior-point iterations per RocketQuat K = 50 SCvx trajectory.
+    bool split_steps = true;
     double rfloor = 0.;       // optional floor on s/z of the virtual-control rows (0 = exact Newton) // floor on the nu Hessian inverse (inexact-Newton safeguard)
     bool verbose = false;
 };
@@ -1325,7 +1330,7 @@ class RQStructuredSocp
             }
             applyW(scsig, 3, zc3, lamC);
 
-            double sigma_c = 0., alpha = 1.;
+            double sigma_c = 0., alpha = 1., alpha_pr = 1., alpha_du = 1.;
             for (int pass = 0; pass < 2; pass++)
             {
                 const double om = 1. - sigma_c; // residual scaling
@@ -1444,7 +1449,7 @@ class RQStructuredSocp
                         return inacc_ok ? 0 : -2;
                 }
                 // ---------- dz = -W^-2 L dx + t ;  ds = -rz' + L dx ----------
-                double ainv = 0.;
+                double ainv = 0., ainv_p = 0., ainv_d = 0.; // 1 / alpha_max: common, of the slack directions, of the multiplier directions
                 for (int k = 0; k < K; k++)
                 {
                     double Ld[NS];
@@ -1464,8 +1469,8 @@ class RQStructuredSocp
                         }
                         applyWinv(sc, d, &ds[o], &dsS[o]);
                         applyW(sc, d, &dz[o], &dzS[o]);
-                        ainv = std::max(ainv, stepInv(d, &lamS[o], &dsS[o]));
-                        ainv = std::max(ainv, stepInv(d, &lamS[o], &dzS[o]));
+                        ainv_p = std::max(ainv_p, stepInv(d, &lamS[o], &dsS[o]));
+                        ainv_d = std::max(ainv_d, stepInv(d, &lamS[o], &dzS[o]));
                     }
                     for (int which = 0; which < 2; which++)
                     {
@@ -1475,7 +1480,8 @@ class RQStructuredSocp
                             continue;
                         dz[o] = -(z[o] / s[o]) * Ld[li] + tz[o];
                         ds[o] = -om * rz[o] + Ld[li];
-                        ainv = std::max(ainv, std::max(-ds[o] / s[o], -dz[o] / z[o]));
+                        ainv_p = std::max(ainv_p, -ds[o] / s[o]);
+                        ainv_d = std::max(ainv_d, -dz[o] / z[o]);
                     }
                 }
                 for (size_t o = 0; o < s1.size(); o++)
@@ -1485,19 +1491,23 @@ class RQStructuredSocp
                     ds1[o] = -om * rz1[o] + L1v;
                     dz2[o] = -dNu(s2[o], z2[o]) * L2v + tz2[o];
                     ds2[o] = -om * rz2[o] + L2v;
-                    ainv = std::max(ainv, std::max(-ds1[o] / s1[o], -dz1[o] / z1[o]));
-                    ainv = std::max(ainv, std::max(-ds2[o] / s2[o], -dz2[o] / z2[o]));
+                    ainv_p = std::max(ainv_p, -ds1[o] / s1[o]);
+                    ainv_d = std::max(ainv_d, -dz1[o] / z1[o]);
+                    ainv_p = std::max(ainv_p, -ds2[o] / s2[o]);
+                    ainv_d = std::max(ainv_d, -dz2[o] / z2[o]);
                 }
                 dzs = -(zs / ss) * dsig + tzs;
                 dss = -om * rzs + dsig;
-                ainv = std::max(ainv, std::max(-dss / ss, -dzs / zs));
+                ainv_p = std::max(ainv_p, -dss / ss);
+                ainv_d = std::max(ainv_d, -dzs / zs);
                 // r3: saff = n1 - sum nub
                 {
                     double sumnb = 0.;
                     for (double v : dnub)
                         sumnb += v;
                     ds3 = -om * rz3 + (dn1 - sumnb);
-                    ainv = std::max(ainv, std::max(-ds3 / s3, -dz3 / z3));
+                    ainv_p = std::max(ainv_p, -ds3 / s3);
+                    ainv_d = std::max(ainv_d, -dz3 / z3);
                 }
                 {
                     const double Ld[3] = {0.5 * ddsg, -0.5 * ddsg, dsig};
@@ -1510,8 +1520,9 @@ class RQStructuredSocp
                     }
                     applyWinv(scsig, 3, dsc3, dsC);
                     applyW(scsig, 3, dzc3, dzC);
-                    ainv = std::max(ainv, stepInv(3, lamC, dsC));
-                    ainv = std::max(ainv, stepInv(3, lamC, dzC));
+                    ainv_p = std::max(ainv_p, stepInv(3, lamC, dsC));
+                    ainv_d = std::max(ainv_d, stepInv(3, lamC, dzC));
+                    ainv = std::max(ainv_p, ainv_d);
                 }
                 if (pass == 0)
                 {
@@ -1524,36 +1535,43 @@ class RQStructuredSocp
                     alpha = ainv > 0. ? std::min(opt.gamma / ainv, 1.) : 1.;
                     alpha = std::min(alpha, 0.999);
                     alpha = std::max(alpha, 1e-8);
+                    alpha_pr = alpha_du = alpha;
+                    if (opt.split_steps)
+                    {
+                        alpha_pr = ainv_p > 0. ? std::min(opt.gamma / ainv_p, 1.) : 1.;
+                        alpha_du = ainv_d > 0. ? std::min(opt.gamma / ainv_d, 1.) : 1.;
+                        alpha_pr = std::max(std::min(alpha_pr, 0.999), 1e-8);
+                        alpha_du = std::max(std::min(alpha_du, 0.999), 1e-8);
+                    }
                 }
             }
             // ---------- update ----------
-            applyPrimalStep(alpha);
+            applyPrimalStep(alpha_pr);
             for (size_t i = 0; i < lam.size(); i++)
-                lam[i] += alpha * dlam[i];
+                lam[i] += alpha_du * dlam[i];
             for (size_t i = 0; i < s.size(); i++)
             {
-                s[i] += alpha * ds[i];
-                z[i] += alpha * dz[i];
+                s[i] += alpha_pr * ds[i];
+                z[i] += alpha_du * dz[i];
             }
             for (size_t i = 0; i < s1.size(); i++)
             {
-                s1[i] += alpha * ds1[i];
-                z1[i] += alpha * dz1[i];
-                s2[i] += alpha * ds2[i];
-                z2[i] += alpha * dz2[i];
+                s1[i] += alpha_pr * ds1[i];
+                z1[i] += alpha_du * dz1[i];
+                s2[i] += alpha_pr * ds2[i];
+                z2[i] += alpha_du * dz2[i];
             }
-            ss += alpha * dss;
-            zs += alpha * dzs;
-            s3 += alpha * ds3;
-            z3 += alpha * dz3;
+            ss += alpha_pr * dss;
+            zs += alpha_du * dzs;
+            s3 += alpha_pr * ds3;
+            z3 += alpha_du * dz3;
             for (int i = 0; i < 3; i++)
             {
-                sc3[i] += alpha * dsc3[i];
-                zc3[i] += alpha * dzc3[i];
+                sc3[i] += alpha_pr * dsc3[i];
+                zc3[i] += alpha_du * dzc3[i];
             }
         }
     }
-
     void applyPrimalStep(double alpha)
     {
         using namespace sipm;

@@ -18,6 +18,16 @@ namespace ipm
 // handed inputs of 1e154 N to the next discretisation.  The sub-problems are nondimensional (costs 1e-2 .. 1e3; Rocket2D in SI units: 1e5, gaps up to
 // 1e9 at the cold start): 1e30 is never a value of a working iterate.
 #define IPM_BLOWN 1e30
+// Step lengths of their own for the primal variables (x, s) and the dual ones (multipliers, z) -- round 6.  ECOS takes ONE step length, the largest
+// that keeps s AND z in their cones; here s += alpha_p ds with the largest step that keeps s in the cone and z += alpha_d dz likewise (each with the
+// same 0.99 / [1e-8, 0.999] safeguards), the way SDPT3-style solvers do.  The primal residuals still shrink by (1 - alpha_p (1 - sigma)), the dual ones by
+// (1 - alpha_d (1 - sigma)); the centring parameter keeps ECOS's rule on the COMMON affine step length.  Measured on the scalar twin before it was
+// built (16 RocketQuat K = 50 SCvx trajectories, tools/experiments/split_step_study.py): 366.1 -> 326.6 interior-point iterations per trajectory
+// (16.0 -> 14.2 after an accepted step, 9.4 -> 8.9 after a rejection, 19.6 -> 17.5 for the first solve), all runs converged.  0: ECOS's common step
+// (rounds 1 - 6a; the twin has the same switch, StructuredSettings::split_steps).
+#ifndef IPM_SPLIT_STEPS
+#define IPM_SPLIT_STEPS 1
+#endif
 #ifndef IPM_FUSE_UPDATE
 #define IPM_FUSE_UPDATE 1 // the step x += alpha dx is applied by the NEXT residual pass on its way in (phResiduals<P, true>; round 6).  0: the two phases of
                           // rounds 1 - 5 (phUpdate, then phResiduals<P, false>) -- bitwise the same results (tests/tools/lib_equal.py on the GPU), 0.8 % slower
@@ -612,10 +622,10 @@ __device__ inline void coneT(const SV &st, int cix, int pass, double om, double 
     for (int i = 0; i < D; i++)
         tout[OFF + i] = t[i]; // stays in registers for the L't product of the same phase (no re-read of F_TZ)
 }
-// dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone
+// dz = -W^-2 L dx + t ; ds = -rz' + L dx ; scaled directions ; returns 1/alpha_max of this cone's slack direction (the multiplier direction's in ainv_dual)
 // store_final = false (predictor pass): only the scaled directions are needed afterwards (corrector term)
 template <class P, int OFF, int D>
-__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final, const SV &stz)
+__device__ inline double coneDir(const SV &st, int cix, double om, const double *Ldall, bool store_final, const SV &stz, double &ainv_dual)
 {
     using L = Lay<P>;
     double w[D], Ld[D], aa[D], t[D], rz[D], dz[D], ds[D], dss[D], dzs[D], ls[D];
@@ -649,8 +659,10 @@ __device__ inline double coneDir(const SV &st, int cix, double om, const double 
         cone::conicProductS<D>(dss, dzs, prod);
         stv<P, OFF, D>(st, L::F_DSS, prod, stz);
     }
+    // 1 / alpha_max of the slack direction (returned) and of the multiplier direction (running maximum of the caller)
     const double a1 = cone::stepInvS<D>(ls, dss), a2 = cone::stepInvS<D>(ls, dzs);
-    return a1 > a2 ? a1 : a2;
+    ainv_dual = a2 > ainv_dual ? a2 : ainv_dual;
+    return a1;
 }
 template <class P, int OFF, int D>
 __device__ inline void zeroT(const SV &st)
@@ -687,12 +699,12 @@ struct Iter
     double resx0, resy0, resz0;
     double mu, gap, pres, dres, pcost;
     double rzs, rz3, rzc[3], rxs, rxds, rxn1;
-    double sigma_c, alpha, tzs, tzc[3];
+    double sigma_c, alpha, alpha_d, tzs, tzc[3]; // alpha: step length of the primal variables, alpha_d: of the dual ones (== alpha without IPM_SPLIT_STEPS)
     Rhs b;
     double bts;
     // ECOS-style safeguarding: scalars of the last iterate that met the reduced tolerances (its W / delta are in L::F_WBK)
     double bk_sig, bk_dsg, bk_n1, pres_prev;
-    double part_ainv, part_fin; // partial step-length bound / finiteness check handed from phDirStage to phDirSeg
+    double part_ainv, part_ainv_d, part_fin; // partial step-length bounds (primal, dual) / finiteness check handed from phDirStage to phDirSeg
     int D, bad, bk_valid;
 };
 
@@ -1328,7 +1340,7 @@ struct ResAcc
 // what the pending step of the previous iteration needs (UPD: phResiduals applies it on the way in, see there)
 struct PendingStep
 {
-    double om, sigmu, z3_old, dz3, dsig, alpha;
+    double om, sigmu, z3_old, dz3, dsig, alpha, alpha_d; // alpha: primal step length, alpha_d: dual (IPM_SPLIT_STEPS)
 };
 template <class P, int I0, int N, bool UPD>
 __device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz, const SV &xs, const SV &xsz, double z3, ResAcc &p, const PendingStep &u)
@@ -1361,11 +1373,11 @@ __device__ inline void resSegChunk(const SV &sg, const SegLds &sl, const SV &dyz
             const SegDirRow d = segDirRow(r, vl[i], bcl[i], u.om, u.dsig);
             nu[i] = nu[i] + u.alpha * d.dnu;
             nub[i] = nub[i] + u.alpha * d.dnub;
-            lam[i] = lam[i] + u.alpha * d.dlam;
+            lam[i] = lam[i] + u.alpha_d * d.dlam;
             s1[i] = s1[i] + u.alpha * d.ds1;
-            z1[i] = z1[i] + u.alpha * d.dz1;
+            z1[i] = z1[i] + u.alpha_d * d.dz1;
             s2[i] = s2[i] + u.alpha * d.ds2;
-            z2[i] = z2[i] + u.alpha * d.dz2;
+            z2[i] = z2[i] + u.alpha_d * d.dz2;
         }
         stl<P, SL_NU, I0, N>(sl, nu);
         stl<P, SL_NUB, I0, N>(sl, nub);
@@ -1411,30 +1423,31 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const SV &st = v.st, &stN = v.stN, &sg = v.sg, &sgP = v.sgP, &dy = v.dy, &dyP = v.dyP;
     const double *ip = c.ip;
     const unsigned fm = v.fm;
-    PendingStep u{0., 0., 0., 0., 0., 0.};
+    PendingStep u{0., 0., 0., 0., 0., 0., 0.};
     if constexpr (UPD)
     {
         // the wave-uniform rows of the step (phUpdate's tail), first: everything below reads the new point
         Glob g = loadPriv(gp);
         const double sigma_c = ip_->sigma_c;
         u.alpha = ip_->alpha;
+        u.alpha_d = ip_->alpha_d;
         u.om = 1. - sigma_c;
         u.sigmu = sigma_c * double(ip_->mu);
         u.z3_old = g.z3;
         u.dz3 = g.dz3;
         u.dsig = g.dsig;
-        const double alpha = u.alpha;
+        const double alpha = u.alpha, alpha_d = u.alpha_d;
         g.sig += alpha * g.dsig;
         g.dsg += alpha * g.ddsg;
         g.n1 += alpha * g.dn1;
         g.ss += alpha * g.dss;
-        g.zs += alpha * g.dzs;
+        g.zs += alpha_d * g.dzs;
         g.s3 += alpha * g.ds3;
-        g.z3 += alpha * g.dz3;
+        g.z3 += alpha_d * g.dz3;
         for (int i = 0; i < 3; i++)
         {
             g.sc3[i] += alpha * g.dsc3[i];
-            g.zc3[i] += alpha * g.dzc3[i];
+            g.zc3[i] += alpha_d * g.dzc3[i];
         }
         PUT_BEGIN();
         PUT(gp, g, sig);
@@ -1534,7 +1547,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                     LOADS_ISSUED();
 #pragma unroll
                     for (int i = 0; i < H0; i++)
-                        zv[i] = zv[i] + u.alpha * d[i];
+                        zv[i] = zv[i] + u.alpha_d * d[i];
                 }
                 {
                     double d[H1];
@@ -1542,7 +1555,7 @@ PHASE_FN void phResiduals(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                     LOADS_ISSUED();
 #pragma unroll
                     for (int i = 0; i < H1; i++)
-                        zv[H0 + i] = zv[H0 + i] + u.alpha * d[i];
+                        zv[H0 + i] = zv[H0 + i] + u.alpha_d * d[i];
                 }
                 stPad<L::NS, P::NXV>(st, stz, L::F_Z, zv);
             }
@@ -1950,7 +1963,7 @@ PHASE_FN void phRhs(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
 // ---- recover the eliminated variables, dz / ds, step length (pass 0: centering parameter) ----
 template <class P, int I0, int N, int PASS>
 __device__ inline void dirSegChunk(const SV &sg, const SegLds &sl, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3,
-                                   double dsig, double &ainv, double &sumdnb)
+                                   double dsig, double &ainv, double &ainv_d, double &sumdnb)
 {
     using L = Lay<P>;
     SegState<N> q;
@@ -1977,10 +1990,21 @@ __device__ inline void dirSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
 #else
         double m1 = -d.ds1 / q.s1[i], m2 = -d.dz1 / q.z1[i], m3 = -d.ds2 / q.s2[i], m4 = -d.dz2 / q.z2[i];
 #endif
-        m1 = m1 > m2 ? m1 : m2;
-        m3 = m3 > m4 ? m3 : m4;
-        m1 = m1 > m3 ? m1 : m3;
-        ainv = m1 > ainv ? m1 : ainv;
+        if (IPM_SPLIT_STEPS && PASS)
+        {
+            // corrector: the slacks' bound (m1, m3) and the multipliers' (m2, m4) apart
+            m1 = m1 > m3 ? m1 : m3;
+            m2 = m2 > m4 ? m2 : m4;
+            ainv = m1 > ainv ? m1 : ainv;
+            ainv_d = m2 > ainv_d ? m2 : ainv_d;
+        }
+        else
+        {
+            m1 = m1 > m2 ? m1 : m2;
+            m3 = m3 > m4 ? m3 : m4;
+            m1 = m1 > m3 ? m1 : m3;
+            ainv = m1 > ainv ? m1 : ainv;
+        }
         o1[i] = d.ds1 * d.dz1;
         o2[i] = d.ds2 * d.dz2;
     }
@@ -1997,21 +2021,21 @@ __device__ inline void dirSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
 // arithmetic, one batch of stores.  (Calls cost nothing here: no callee-saved registers, see PHASE_FN.)
 struct DirChunkOut
 {
-    double ainv, sumdnb;
+    double ainv, ainv_d, sumdnb;
 };
 template <class P, int I0, int N, int PASS>
-PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu, double z3, double dz3, double dsig, double ainv, double sumdnb)
+PHASE_FN DirChunkOut dirSegChunkFn(const PRIV Ctx *cin, double om, double sigmu, double z3, double dz3, double dsig, double ainv, double ainv_d, double sumdnb)
 {
     EMU_PHASE(PASS ? "phDirSeg<1>" : "phDirSeg<0>");
     using L = Lay<P>;
     const Ctx c = uniformCtx(cin);
     const int k = c.lane, K = c.K;
-    DirChunkOut o{ainv, sumdnb}; // running maximum / sum of this lane (same order of additions as one pass over all rows)
+    DirChunkOut o{ainv, ainv_d, sumdnb}; // running maxima / sum of this lane (same order of additions as one pass over all rows)
     if (k < K - 1)
     {
         const SV sg = makeSV(c.sg, (G_NFIELDS * L::NL), unsigned(k), c.pitch);
         const SV xs = makeSX(c.sx, L::XREC, K, unsigned(k));
-        dirSegChunk<P, I0, N, PASS>(sg, makeSegLds<P>(c, k), xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.sumdnb);
+        dirSegChunk<P, I0, N, PASS>(sg, makeSegLds<P>(c, k), xs, padView(xs, scvxMode(c.ip)), om, sigmu, z3, dz3, dsig, o.ainv, o.ainv_d, o.sumdnb);
     }
     return o;
 }
@@ -2070,7 +2094,10 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         g.dsig = (ip_->bts - cv) / g.schur;
         g.ddsg = (ip_->b.ds - gp->Hsd * g.dsig) / gp->Hdd;
     }
-    double ainv = 0., finite_chk = g.dsig * 0. + g.ddsg * 0.;
+    // ainv: 1 / (largest step that keeps the slacks in their cones); ainv_d: the same for the multipliers -- kept apart in the corrector pass only
+    // (IPM_SPLIT_STEPS), folded into ainv in the predictor pass, whose centring rule uses the common step length
+    constexpr bool split = IPM_SPLIT_STEPS && pass != 0;
+    double ainv = 0., ainv_d = 0., finite_chk = g.dsig * 0. + g.ddsg * 0.;
     if (v.vst)
     {
         double Ld[L::NS];
@@ -2102,7 +2129,7 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             constexpr int C = decltype(ci)::value;
             if (act & (1u << C))
             {
-                const double a0 = coneDir<P, L::coneOff(C), L::coneDim(C)>(st, C, om, Ld, pass != 0, stz);
+                const double a0 = coneDir<P, L::coneOff(C), L::coneDim(C)>(st, C, om, Ld, pass != 0, stz, ainv_d);
                 ainv = a0 > ainv ? a0 : ainv;
             }
         });
@@ -2122,21 +2149,28 @@ PHASE_FN void phDirStage(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
                 dsv[w] = on ? -om * rz[w] + Ld[LP0 + w] : 0.;
                 const double a1 = on ? -dsv[w] / sv[w] : 0., a2 = on ? -dzv[w] / zv[w] : 0.;
                 ainv = a1 > ainv ? a1 : ainv;
-                ainv = a2 > ainv ? a2 : ainv;
+                ainv_d = a2 > ainv_d ? a2 : ainv_d;
             }
             stf<NLP>(st, L::F_DZ + LP0, dzv);
             stf<NLP>(st, L::F_DS + LP0, dsv);
         }
     }
+    if (!split)
+        ainv = ainv_d > ainv ? ainv_d : ainv;
     ainv = waveMaxDpp(ainv);
+    if (split)
+        ainv_d = waveMaxDpp(ainv_d);
     finite_chk = waveSumDpp(finite_chk);
     it.part_ainv = ainv;
+    it.part_ainv_d = ainv_d;
     it.part_fin = finite_chk;
     PUT_BEGIN();
     if (pass == 0)
         PUT(gp, g, schur);
     PUT(ip_, it, bad);
     PUT(ip_, it, part_ainv);
+    if (split)
+        PUT(ip_, it, part_ainv_d);
     PUT(ip_, it, part_fin);
     PUT(gp, g, dsig);
     PUT(gp, g, ddsg);
@@ -2159,12 +2193,14 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     g.ddsg = gp->ddsg;
     const double sigma_c = pass ? double(ip_->sigma_c) : 0.;
     const double om = 1. - sigma_c;
-    double ainv = ip_->part_ainv, finite_chk = ip_->part_fin;
+    constexpr bool split = IPM_SPLIT_STEPS && pass != 0; // corrector: primal (ainv) and dual (ainv_d) step-length bounds apart
+    double ainv = ip_->part_ainv, ainv_d = split ? double(ip_->part_ainv_d) : 0., finite_chk = ip_->part_fin;
     double sumdnb = 0.;
     const double sigmu = sigma_c * double(ip_->mu), z3 = gp->z3, dz3 = gp->dz3;
     forSegChunks<P, chunkFor<P>(IPM_DIR_CHUNK, IPM_DIR_CHUNK_W)>([&](auto i0, auto n) {
-        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, PASS>(cin, om, sigmu, z3, dz3, g.dsig, ainv, sumdnb);
+        const DirChunkOut o = dirSegChunkFn<P, decltype(i0)::value, decltype(n)::value, PASS>(cin, om, sigmu, z3, dz3, g.dsig, ainv, ainv_d, sumdnb);
         ainv = o.ainv;
+        ainv_d = o.ainv_d;
         sumdnb = o.sumdnb;
     });
     sumdnb = waveSumDpp(sumdnb);
@@ -2181,13 +2217,13 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     {
         const double m1 = -g.dss / gt.ss, m2 = -g.dzs / gt.zs;
         ainv = m1 > ainv ? m1 : ainv;
-        ainv = m2 > ainv ? m2 : ainv;
+        ainv_d = m2 > ainv_d ? m2 : ainv_d;
     }
     g.ds3 = -om * itt.rz3 + (g.dn1 - sumdnb);
     {
         const double m1 = -g.ds3 / gt.s3, m2 = -gt.dz3 / gt.z3;
         ainv = m1 > ainv ? m1 : ainv;
-        ainv = m2 > ainv ? m2 : ainv;
+        ainv_d = m2 > ainv_d ? m2 : ainv_d;
     }
     {
         const double Ld[3] = {0.5 * g.ddsg, -0.5 * g.ddsg, g.dsig};
@@ -2202,9 +2238,13 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         cone::applyW(gt.seta, gt.sw, 3, g.dzc3, g.dzC);
         const double a1 = cone::stepInv(3, gt.lamC, g.dsC), a2 = cone::stepInv(3, gt.lamC, g.dzC);
         ainv = a1 > ainv ? a1 : ainv;
-        ainv = a2 > ainv ? a2 : ainv;
+        ainv_d = a2 > ainv_d ? a2 : ainv_d;
     }
+    if (!split)
+        ainv = ainv_d > ainv ? ainv_d : ainv;
     ainv = waveMaxDpp(ainv);
+    if (split)
+        ainv_d = waveMaxDpp(ainv_d);
     if (pass == 0)
     {
         double alpha_a = ainv > 0. ? 1. / ainv : 1.;
@@ -2221,12 +2261,24 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         alpha = alpha < 0.999 ? alpha : 0.999;
         alpha = alpha > 1e-8 ? alpha : 1e-8;
         it.alpha = alpha;
+        double alpha_d = alpha; // ECOS: one step length
+        if (split)
+        {
+            alpha_d = ainv_d > 0. ? itt.gamma / ainv_d : 1.;
+            alpha_d = alpha_d < 1. ? alpha_d : 1.;
+            alpha_d = alpha_d < 0.999 ? alpha_d : 0.999;
+            alpha_d = alpha_d > 1e-8 ? alpha_d : 1e-8;
+        }
+        it.alpha_d = alpha_d;
     }
     PUT_BEGIN();
     if (pass == 0)
         PUT(ip_, it, sigma_c);
     else
+    {
         PUT(ip_, it, alpha);
+        PUT(ip_, it, alpha_d);
+    }
     PUT(ip_, it, bad);
     PUT(gp, g, dn1);
     PUT(gp, g, dzs);
@@ -2290,7 +2342,7 @@ __device__ inline void axpyFieldGroup(const SV &rec, const int (&fDst)[NF], cons
 }
 template <class P, int I0, int N>
 __device__ inline void updSegChunk(const SV &sg, const SegLds &sl, const SV &xs, const SV &xsz, double om, double sigmu, double z3, double dz3, double dsig,
-                                   double alpha)
+                                   double alpha, double alpha_d)
 {
     using L = Lay<P>;
     SegState<N> q;
@@ -2308,11 +2360,11 @@ __device__ inline void updSegChunk(const SV &sg, const SegLds &sl, const SV &xs,
         const SegDirRow d = segDirRow(r, vl[i], bcl[i], om, dsig);
         q.nu[i] = q.nu[i] + alpha * d.dnu;
         q.nub[i] = q.nub[i] + alpha * d.dnub;
-        q.lam[i] = q.lam[i] + alpha * d.dlam;
+        q.lam[i] = q.lam[i] + alpha_d * d.dlam;
         q.s1[i] = q.s1[i] + alpha * d.ds1;
-        q.z1[i] = q.z1[i] + alpha * d.dz1;
+        q.z1[i] = q.z1[i] + alpha_d * d.dz1;
         q.s2[i] = q.s2[i] + alpha * d.ds2;
-        q.z2[i] = q.z2[i] + alpha * d.dz2;
+        q.z2[i] = q.z2[i] + alpha_d * d.dz2;
     }
     stl<P, SL_NU, I0, N>(sl, q.nu);
     stl<P, SL_NUB, I0, N>(sl, q.nub);
@@ -2369,7 +2421,7 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
     const Views v = makeViews<P>(c);
     const SV &st = v.st, &sg = v.sg;
     Glob g = loadPriv(gp);
-    const double alpha = ip_->alpha;
+    const double alpha = ip_->alpha, alpha_d = ip_->alpha_d;
     const bool scvx = scvxMode(c.ip);
     const SV stz = padView(v.st, scvx);
     // few, large load groups: a group's loads wait for the stores of the group before it (one memory round trip per group)
@@ -2389,7 +2441,7 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
             st[L::F_W + j] = d[j] + ((v.fm & (1u << j)) ? 0. : alpha * x[j]);
         st[L::F_DL] = dl + alpha * ddl;
         axpyPad<L::NS, P::NXV>(st, stz, L::F_S, L::F_DS, alpha);
-        axpyPad<L::NS, P::NXV>(st, stz, L::F_Z, L::F_DZ, alpha);
+        axpyPad<L::NS, P::NXV>(st, stz, L::F_Z, L::F_DZ, alpha_d);
     }
     if (v.vsg)
     {
@@ -2398,20 +2450,20 @@ PHASE_FN void phUpdate(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         const double sigma_c = ip_->sigma_c, om = 1. - sigma_c, sigmu = sigma_c * double(ip_->mu);
         const SV xsz = padView(v.xs, scvx);
         forSegChunks<P, chunkFor<P>(IPM_UPD_CHUNK, IPM_UPD_CHUNK_W)>([&](auto i0, auto n) {
-            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, makeSegLds<P>(c, v.k), v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha);
+            updSegChunk<P, decltype(i0)::value, decltype(n)::value>(sg, makeSegLds<P>(c, v.k), v.xs, xsz, om, sigmu, g.z3, g.dz3, g.dsig, alpha, alpha_d);
         });
     }
     g.sig += alpha * g.dsig;
     g.dsg += alpha * g.ddsg;
     g.n1 += alpha * g.dn1;
     g.ss += alpha * g.dss;
-    g.zs += alpha * g.dzs;
+    g.zs += alpha_d * g.dzs;
     g.s3 += alpha * g.ds3;
-    g.z3 += alpha * g.dz3;
+    g.z3 += alpha_d * g.dz3;
     for (int i = 0; i < 3; i++)
     {
         g.sc3[i] += alpha * g.dsc3[i];
-        g.zc3[i] += alpha * g.dzc3[i];
+        g.zc3[i] += alpha_d * g.dzc3[i];
     }
     PUT_BEGIN();
     PUT(gp, g, sig);
@@ -2536,6 +2588,7 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     it.gamma = opt.gamma;
     it.sigma_c = 0.;
     it.alpha = 1.;
+    it.alpha_d = 1.;
     it.bk_valid = 0;
     it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
 
@@ -2612,6 +2665,11 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
             const double pres = it.pres, dres = it.dres, gap = it.gap;
             const double apc = fabs(it.pcost) > 1e-300 ? fabs(it.pcost) : 1e-300;
             const double relgap = gap / apc;
+#ifdef SCPP_HIP_EMU
+            if (c.lane == 0 && getenv("SCPP_EMU_DEBUG"))
+                printf("[emu] iter %d pres %.3e dres %.3e gap %.3e pcost %.9e | last step: alpha %.3e alpha_d %.3e sigma_c %.3e\n", iter, pres, dres, gap, double(it.pcost),
+                       double(it.alpha), double(it.alpha_d), double(it.sigma_c));
+#endif
             const bool nonfinite = !(pres == pres) || !(dres == dres) || !(gap == gap) || fabs(pres) > 1e300 || fabs(dres) > 1e300 || fabs(gap) > 1e300 ||
                                    fabs(it.pcost) > IPM_BLOWN || ipmGapBroken(gap); // a BLOWN-UP iterate is a broken one: see IPM_BLOWN, IPM_NEG_GAP
             // ECOS-style safeguarding: residual explosion after an acceptable iterate -> return that iterate

@@ -205,7 +205,7 @@ def test_emu_rocket2d_sc_matches_oracle_literal(oracle, emu_lib):
         sc = oracle.SC(oracle.ROCKET2D, K=K); sc.set_x_init(x0[b]); sc.solve()
         X, U, t = sc.solution()
         assert out["sc_iters"][b] == sc.meta()["iterations"] and sc.meta()["converged"] == 1
-        assert abs(out["sigma"][b] - t) <= 1e-6 * t
+        assert abs(out["sigma"][b] - t) <= 1e-5 * t  # north_star's 1e-5 (1.3e-6 after five iterations: the device's split step lengths vs the literal solver's common one)
         assert np.abs(out["X"][b] - X).max() <= 1e-5 * np.abs(X).max()
         assert np.abs(out["U"][b] - U).max() <= 1e-4 * np.abs(U).max()
 
