@@ -683,6 +683,10 @@ def main():
                 "mean_scvx_iterations": g_iters / g_total if g_total else 0.0,
                 "mean_subproblem_solves": g_solves / g_total if g_total else 0.0,
                 "mean_ipm_iterations_per_trajectory": g_ipm / g_total if g_total else 0.0,
+                "interior_point": ("ECOS's algorithm (NT scaling, Mehrotra predictor-corrector, sigma = (1 - alpha_aff)^3, step-to-boundary 0.99, feastol 1e-8, abstol / reltol "
+                                   "1e-7) on the structured system, with ONE departure since round 6: primal and dual step lengths of their own (csrc/ipm_solve.h: "
+                                   "IPM_SPLIT_STEPS) -- same-box A/B against the common step length: 333.6 vs 367.9 iterations per trajectory, 6213 vs 5733 converged/s "
+                                   "(profiles/r06_ab_split_steps.json)"),
                 "solver_failures": g_fail,
                 "median_final_virtual_control_norm1": float(np.median(out["nu_norm"])),
                 "median_final_nonlinear_defect": float(np.median(out["nonlinear_cost"])),

