@@ -327,6 +327,14 @@ int oracle_sc_check_point(void *h, const double *Xbar, const double *Ubar, doubl
         return -2;
     }
 }
+// primal and dual step lengths of their own in the structured twin (default on = the device's IPM_SPLIT_STEPS); 0: ECOS's common one
+int oracle_sc_set_twin_split_steps(void *h, int on)
+{
+    return withAlg(h, [&](auto &a) {
+        a.structured_settings.split_steps = on != 0;
+        return 0;
+    });
+}
 int oracle_sc_set_solver(void *h, int kind)
 {
     return withAlg(h, [&](auto &a) {

@@ -9,6 +9,7 @@ export GRAFT_COMMIT=$(cat tools/commit_id.txt 2>/dev/null || echo worktree)
 python tools/csrc_hash.py > $OUT/csrc_sha.txt
 timeout -k 5 2700 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 cp gpurun_out/r06_parity_at_scale.json $OUT/parity_at_scale.json 2>/dev/null
+cp $OUT/parity_at_scale.json profiles/r06_parity_at_scale.json 2>/dev/null  # the bench lines below import it (config.parity): this session's, not an older one's
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log
 [ -f build/pre_registry.so ] && { timeout 300 python tests/tools/lib_equal.py scpp_amd/libscpp_hip.so build/pre_registry.so > $OUT/pre_registry_equal.log 2>&1; echo "pre_registry rc=$?"; tail -2 $OUT/pre_registry_equal.log; }
 [ -f build/prevlane_memory.so ] && { timeout 300 python tests/tools/lib_equal.py scpp_amd/libscpp_hip.so build/prevlane_memory.so > $OUT/prevlane_equal.log 2>&1; echo "prevlane rc=$?"; tail -2 $OUT/prevlane_equal.log; }
