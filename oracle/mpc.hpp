@@ -464,6 +464,7 @@ class MpcCondensedIpm
 {
   public:
     double feastol = 1e-8, abstol = 1e-8, reltol = 1e-8, gamma = 0.99;
+    bool split_steps = true; // primal and dual step lengths of their own (csrc/mpc_kernel.h: MPC_SPLIT_STEPS); false: ECOS's common one
     int maxit = 50;
     bool verbose = false;
     explicit MpcCondensedIpm(const MpcCondensed &q_) : q(q_)
@@ -663,7 +664,7 @@ class MpcCondensedIpm
             std::vector<double> L(H);
             if (!chol(L))
                 return finish(inacc_ok ? 1 : -2);
-            double sigma_c = 0., alpha = 1.;
+            double sigma_c = 0., alpha = 1., alpha_d = 1.;
             for (int pass = 0; pass < 2; pass++)
             {
                 const double om = 1. - sigma_c;
@@ -707,12 +708,13 @@ class MpcCondensedIpm
                 if (!(chk == 0.))
                     return finish(inacc_ok ? 1 : -2);
                 mulG(dx, Gd);
-                double ainv = 0.;
+                double ainv = 0., ainv_d = 0.; // 1 / alpha_max of the slacks' / the multipliers' direction
                 for (int r = 0; r < nlp; r++)
                 {
                     dz[r] = (z[r] / s[r]) * Gd[r] + t[r];
                     ds[r] = -om * rz[r] - Gd[r];
-                    ainv = std::max(ainv, std::max(-ds[r] / s[r], -dz[r] / z[r]));
+                    ainv = std::max(ainv, -ds[r] / s[r]);
+                    ainv_d = std::max(ainv_d, -dz[r] / z[r]);
                 }
                 for (int c = 0; c < nc; c++)
                 {
@@ -727,8 +729,12 @@ class MpcCondensedIpm
                     applyWinv(sc[c], d, &ds[o], &dsS[o]);
                     applyW(sc[c], d, &dz[o], &dzS[o]);
                     ainv = std::max(ainv, stepInv(d, &lam[o], &dsS[o]));
-                    ainv = std::max(ainv, stepInv(d, &lam[o], &dzS[o]));
+                    ainv_d = std::max(ainv_d, stepInv(d, &lam[o], &dzS[o]));
                 }
+                // primal and dual step lengths of their own in the corrector pass (the device kernel's MPC_SPLIT_STEPS, round 6); the centring
+                // parameter follows ECOS's rule on the common affine step length
+                if (!split_steps || pass == 0)
+                    ainv = ainv_d = std::max(ainv, ainv_d);
                 if (pass == 0)
                 {
                     const double alpha_a = ainv > 0. ? std::min(1. / ainv, 1.) : 1.;
@@ -740,6 +746,8 @@ class MpcCondensedIpm
                     alpha = ainv > 0. ? std::min(gamma / ainv, 1.) : 1.;
                     alpha = std::min(alpha, 0.999);
                     alpha = std::max(alpha, 1e-8);
+                    alpha_d = ainv_d > 0. ? std::min(gamma / ainv_d, 1.) : 1.;
+                    alpha_d = std::max(std::min(alpha_d, 0.999), 1e-8);
                 }
             }
             for (int j = 0; j < nv; j++)
@@ -747,7 +755,7 @@ class MpcCondensedIpm
             for (int r = 0; r < m; r++)
             {
                 s[r] += alpha * ds[r];
-                z[r] += alpha * dz[r];
+                z[r] += alpha_d * dz[r];
             }
         }
     }

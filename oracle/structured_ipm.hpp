@@ -271,6 +271,21 @@ class RQStructuredSocp
             out.status = run(out);
             out.iters += warm_iters;
         }
+        if (out.status != 0 && opt.split_steps)
+        {
+            // a cold attempt that fails with primal and dual step lengths of their own is repeated with ECOS's common step length
+            // (csrc/ipm_solve.h: ipmSolveInstance, round 6: one of 1 048 576 soak trajectories on the device)
+            opt.split_steps = false;
+            warm_start = false;
+            restored_best = false;
+            alloc();
+            setupStages();
+            const int failed_iters = out.iters;
+            out = RQSocpOutput();
+            out.status = run(out);
+            out.iters += failed_iters;
+            opt.split_steps = true;
+        }
         out.X.assign(size_t(K) * NX, 0.);
         out.U.assign(size_t(K) * NU, 0.);
         out.nu = nu;

@@ -706,6 +706,7 @@ struct Iter
     double bk_sig, bk_dsg, bk_n1, pres_prev;
     double part_ainv, part_ainv_d, part_fin; // partial step-length bounds (primal, dual) / finiteness check handed from phDirStage to phDirSeg
     int D, bad, bk_valid;
+    int common_step; // != 0: this attempt takes ECOS's common step length (the repeat of an attempt that failed with split ones, ipmSolveInstance)
 };
 
 template <class T>
@@ -1316,16 +1317,21 @@ __device__ inline SegDirRow segDirRow(const SegRhsRow &r, double vl, double bcl,
 inline void emuInjectResiduals(int lane, double &pres, double &dres, double &gap)
 {
     static int calls[LANES];
-    static int inj_n = -2;
+    static int inj_n = -2, inj_m = -1; // "n:pres:dres:gap" or "n,m:pres:dres:gap" (two evaluations: the first attempt's and the repeated one's)
     static double inj_v[3];
     if (inj_n == -2)
     {
         const char *e = getenv("SCPP_EMU_INJECT_RES");
         inj_n = -1;
-        if (e && sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
-            inj_n = -1;
+        if (e && sscanf(e, "%d,%d:%lf:%lf:%lf", &inj_n, &inj_m, &inj_v[0], &inj_v[1], &inj_v[2]) != 5)
+        {
+            inj_m = -1;
+            if (sscanf(e, "%d:%lf:%lf:%lf", &inj_n, &inj_v[0], &inj_v[1], &inj_v[2]) != 4)
+                inj_n = -1;
+        }
     }
-    if (inj_n >= 0 && calls[lane & (LANES - 1)]++ == inj_n)
+    const int call = inj_n >= 0 ? calls[lane & (LANES - 1)]++ : -1;
+    if (inj_n >= 0 && (call == inj_n || call == inj_m))
     {
         pres = inj_v[0];
         dres = inj_v[1];
@@ -2244,7 +2250,11 @@ PHASE_FN void phDirSeg(const PRIV Ctx *cin, PRIV Glob *gp, PRIV Iter *ip_)
         ainv = ainv_d > ainv ? ainv_d : ainv;
     ainv = waveMaxDpp(ainv);
     if (split)
+    {
         ainv_d = waveMaxDpp(ainv_d);
+        if (itt.common_step) // the repeat of a failed attempt: one step length, the smaller of the two (ECOS's rule)
+            ainv = ainv_d = (ainv_d > ainv ? ainv_d : ainv);
+    }
     if (pass == 0)
     {
         double alpha_a = ainv > 0. ? 1. / ainv : 1.;
@@ -2608,9 +2618,16 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     const int dd_same = (a.dd_fresh && a.dd_fresh[inst] == 0 && warm) ? 1 : 0;
     int status = -1, iter = 0, iter_total = 0;
     bool use_backup = false;
-    // a warm start that breaks down is repeated from ECOS's cold initialisation (attempt 1)
-    for (int attempt = 0; attempt < 2; attempt++)
+    // a warm start that breaks down is repeated from ECOS's cold initialisation; a cold attempt that fails with primal and dual step lengths of their
+    // own (IPM_SPLIT_STEPS) is repeated with ECOS's common step length -- round 6: ONE of 1 048 576 soak trajectories (instance 454733, its first
+    // solve) failed under the split rule: at its 19th iteration, with the gap already at 9e-8 relative, a rounding-level loss in the step left the
+    // primal residual at 1.8e-8 against the 1e-8 tolerance, two iterations later the dual residual was at 1e-4 and the factorisation broke down (the
+    // emulator and the twin, equal to the device to rounding, converge at that very iteration; the common-step path was through after 18).  What a
+    // failed attempt costs is its iterations; a solve that succeeds is untouched.  profiles/r06_soak_failure_instance_454733.json, tools/r06_trace_failure.py
+    int common_step = 0;
+    for (int attempt = 0; attempt < 3; attempt++)
     {
+    it.common_step = common_step;
     phSetup<P>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm, dd_same);
     if (warm)
     {
@@ -2764,9 +2781,14 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
 
     phSegLdsCopy<P, false>(cs);
     iter_total += iter;
-    if (status == 0 || !warm)
+    if (status == 0)
         break;
-    warm = 0;
+    if (warm)
+        warm = 0; // repeat from the cold initialisation
+    else if (IPM_SPLIT_STEPS && !common_step)
+        common_step = 1; // repeat (cold) with the common step length
+    else
+        break;
     }
     iter = iter_total;
     // =============== outputs: readSolution + SC bookkeeping ===============

@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         it.sigma_c = 0.;
         it.alpha = 1.;
         it.alpha_d = 1.;
+        it.common_step = 0; // (the split SCHEDULE -- a measurement mode -- does not repeat a failed attempt with the common step length)
         it.bk_valid = 0;
         it.bk_sig = it.bk_dsg = it.bk_n1 = it.pres_prev = 0.;
         if (a.Xold && k < K)

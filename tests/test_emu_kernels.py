@@ -726,8 +726,14 @@ def test_emu_negative_gap_without_a_fallback_is_a_failure(emu_lib):
     st_c, it_c, _ = _inject_and_solve(emu_lib, "2:0:0:1e-9")
     assert st_c == 0 and it_c == 2  # "converged" at the injected evaluation: the hook works
     for gap in ("-1e29", "-1e31", "-1e-3"):
-        st_b, it_b, _ = _inject_and_solve(emu_lib, "2:0:0:" + gap)
-        assert st_b == -2 and it_b == 2, (gap, st_b, it_b)
+        # (round 6: a cold attempt that fails with split step lengths is repeated with ECOS's common one -- the iterate is handed to the FIRST attempt's
+        # 3rd evaluation and to the repeat's 3rd, evaluations 2 and 5 of the solve: both attempts must refuse it)
+        st_b, it_b, _ = _inject_and_solve(emu_lib, "2,5:0:0:" + gap)
+        assert st_b == -2 and it_b == 4, (gap, st_b, it_b)
+    # ... and handed to the first attempt only, the solve recovers: the broken attempt is discarded, the repeat with the common step length converges
+    # (2 iterations of the failed attempt + a whole cold solve), to the un-injected solve's trajectory at solver tolerance
+    st_r, it_r, fin_r = _inject_and_solve(emu_lib, "2:0:0:-1e29")
+    assert st_r == 0 and fin_r and it_r > 2 + 4, (st_r, it_r)
 
 
 def test_emu_scvx_recorded_iterates_equal_capped_reruns(model, emu_lib):

@@ -95,7 +95,10 @@ def test_condensed_and_literal_solvers_agree_and_satisfy_the_reference_problem(o
         ca, cb = a["input_cost"] + a["error_cost"], b["input_cost"] + b["error_cost"]
         rt = 1e-6 if b["status"] == 0 else 5e-5
         assert abs(ca - cb) < rt * ca
-        assert np.abs(a["U"][:, 0] - b["U"][:, 0]).max() < 20 * rt * d["gim"] and np.abs(a["U"][:, 1] - b["U"][:, 1]).max() < 20 * rt * d["Tmax"]
+        # (the gimbal angles: costs equal to 1e-6 as before, but where the gimbal sits AT its bound the condensed solver -- primal and dual step lengths of
+        # their own since round 6 -- stops 2e-5 .. 1e-4 rad inside it, the literal solver with ECOS's common step 1e-9: both are 1e-8-optimal, the cost
+        # is flat there (input weight 0.1 against state weights of 5); 5e-4 relative to the bound instead of 2e-5)
+        assert np.abs(a["U"][:, 0] - b["U"][:, 0]).max() < 500 * rt * d["gim"] and np.abs(a["U"][:, 1] - b["U"][:, 1]).max() < 20 * rt * d["Tmax"]
 
 
 def test_optimum_against_a_general_purpose_nlp_solver(oracle):
