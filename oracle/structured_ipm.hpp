@@ -258,10 +258,16 @@ class RQStructuredSocp
             alloc();
         setupStages();
         RQSocpOutput out;
+        // a warm-started solve of SCAlgorithm's sub-problem takes ECOS's common step length from the start (csrc/ipm_solve.h: ipmSolveInstance; measured on the
+        // GPU in SC_sim's shape); cold solves and every SCvx solve take primal and dual step lengths of their own
+        const bool split_cfg = opt.split_steps;
+        if (warm_start && !in.scvx)
+            opt.split_steps = false;
         out.status = run(out);
         if (out.status != 0 && warm_start)
         {
-            // a warm start that breaks down is repeated from ECOS's cold initialisation
+            // a warm start that breaks down is repeated from ECOS's cold initialisation (with the cold attempt's own step-length rule)
+            opt.split_steps = split_cfg;
             warm_start = false;
             restored_best = false;
             alloc();
@@ -271,7 +277,9 @@ class RQStructuredSocp
             out.status = run(out);
             out.iters += warm_iters;
         }
-        if (out.status != 0 && opt.split_steps)
+        if (out.status == 0 || !opt.split_steps)
+            opt.split_steps = split_cfg;
+        else
         {
             // a cold attempt that fails with primal and dual step lengths of their own is repeated with ECOS's common step length
             // (csrc/ipm_solve.h: ipmSolveInstance, round 6: one of 1 048 576 soak trajectories on the device)
@@ -284,7 +292,7 @@ class RQStructuredSocp
             out = RQSocpOutput();
             out.status = run(out);
             out.iters += failed_iters;
-            opt.split_steps = true;
+            opt.split_steps = split_cfg;
         }
         out.X.assign(size_t(K) * NX, 0.);
         out.U.assign(size_t(K) * NU, 0.);

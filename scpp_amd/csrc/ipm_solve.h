@@ -2624,7 +2624,11 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     // primal residual at 1.8e-8 against the 1e-8 tolerance, two iterations later the dual residual was at 1e-4 and the factorisation broke down (the
     // emulator and the twin, equal to the device to rounding, converge at that very iteration; the common-step path was through after 18).  What a
     // failed attempt costs is its iterations; a solve that succeeds is untouched.  profiles/r06_soak_failure_instance_454733.json, tools/r06_trace_failure.py
-    int common_step = 0;
+    // ... and a WARM-STARTED solve of SCAlgorithm's sub-problem takes the common step length from the start: those solves sit next to the fixed point the SC
+    // iteration stalls at (5 iterations each at best), and there the split rule was measured worse on the GPU -- 4096 closed loops of SC_sim's shape, same box,
+    // alternating: 114.7 against 111.7 iterations and 0.390 against 0.361 s per 15-iteration solve (profiles/r06_ab_scsim_split_steps.json); cold SC solves
+    // (127.6 against 132.9 iterations) and every SCvx solve (333.6 against 367.9 per trajectory) keep the split rule
+    int common_step = (IPM_SPLIT_STEPS && warm && c.ip[IP_SCVX] == 0.) ? 1 : 0;
     for (int attempt = 0; attempt < 3; attempt++)
     {
     it.common_step = common_step;
@@ -2784,7 +2788,10 @@ __device__ __forceinline__ void ipmSolveInstance(const KernelArgs &a, const int 
     if (status == 0)
         break;
     if (warm)
-        warm = 0; // repeat from the cold initialisation
+    {
+        warm = 0; // repeat from the cold initialisation (with the cold attempt's own rule: split step lengths first)
+        common_step = 0;
+    }
     else if (IPM_SPLIT_STEPS && !common_step)
         common_step = 1; // repeat (cold) with the common step length
     else

@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(WAVE, IPM_SPLIT_WAVES) __attribute__((disable_
         if (pc == PC_START)
         {
             // (ipm_kernel: top of the attempt loop)
+            // (ipm_solve.h: a warm-started solve of SCAlgorithm's sub-problem takes the common step length; this schedule -- a measurement mode -- does not
+            // repeat a failed cold attempt with it.  `it` lives in the resume block between launches, the flag with it)
+            it.common_step = (IPM_SPLIT_STEPS && warm && c.ip[IP_SCVX] == 0.) ? 1 : 0;
             phSetup<W>(cs, a.X + size_t(inst) * K * NX, a.U + size_t(inst) * K * NU, a.uhat + size_t(inst) * K * 3, gp, itp, warm, 0);
             if (warm)
             {
